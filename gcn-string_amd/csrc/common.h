@@ -1,0 +1,59 @@
+// Shared internals of libgcnx (not part of the ABI; the ABI is include/gcnx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "gcnx.h"
+
+struct gcnx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // Scratch owned by the ctx (split-K partials, column-sum partials, flags).  Grown on demand
+  // outside stream capture; a capture that would need growth fails with a clear message.
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int* flag = nullptr;       // device int[4] for validation kernels
+  bool capturing = false;
+  int num_cus = 256;
+  std::string arch;
+};
+
+struct gcnx_event { hipEvent_t ev; };
+struct gcnx_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+extern thread_local std::string gcnx_tls_error;
+
+int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...);
+int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes);  // ensures ctx->ws has >= bytes
+
+#define GCNX_CHECK_CTX(ctx) \
+  do { if (!(ctx)) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "%s: ctx is NULL", __func__); } while (0)
+
+#define GCNX_HIP(ctx, expr)                                                                   \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return gcnx_fail((ctx), GCNX_ERR_HIP, "%s: %s -> %s", __func__, #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define GCNX_REQUIRE(ctx, cond, ...)                                          \
+  do { if (!(cond)) return gcnx_fail((ctx), GCNX_ERR_INVALID, __VA_ARGS__); } while (0)
+
+// Launch-error check that is legal during stream capture (no sync).
+#define GCNX_LAUNCH_OK(ctx) GCNX_HIP(ctx, hipGetLastError())
+
+static inline int gcnx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Blocks b and b+8 share an XCD (observed round-robin dealing; speed only, never correctness).
+// Bijective remap that gives every XCD one contiguous range of logical work items, so that
+// neighbouring row chunks -- which gather the same feature rows -- share one L2.
+__device__ __forceinline__ int gcnx_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}

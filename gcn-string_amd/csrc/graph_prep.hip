@@ -1,0 +1,166 @@
+// Graph preparation: DisjointLoader COO -> CSR, gcn_filter normalisation, CSR transpose.
+// These run once per batch (or once per dataset), not once per layer.
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+// rows[] is non-decreasing (tf.sparse.reorder order).  Thread e owns the rowptr entries of the
+// rows that START at e: every r in (rows[e-1], rows[e]].  No atomics, no scan.
+__global__ __launch_bounds__(256) void coo_to_csr_kernel(const int64_t* __restrict__ rows,
+                                                         const int64_t* __restrict__ cols, int64_t nnz,
+                                                         int64_t n, int32_t* __restrict__ rowptr,
+                                                         int32_t* __restrict__ colidx, int* __restrict__ flag) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e > nnz) return;
+  if (e == nnz) {  // tail: rows after the last stored row, and rowptr[n]
+    const int64_t last = nnz > 0 ? rows[nnz - 1] : -1;
+    if (last >= -1 && last < n)
+      for (int64_t r = last + 1; r <= n; ++r) rowptr[r] = (int32_t)nnz;
+    return;
+  }
+  const int64_t r = rows[e], c = cols[e];
+  const int64_t rp = e > 0 ? rows[e - 1] : -1;
+  if (r < 0 || r >= n || c < 0 || c >= n || rp > r) {
+    atomicOr(flag, 1);
+    return;
+  }
+  colidx[e] = (int32_t)c;
+  for (int64_t q = (rp < -1 ? -1 : rp) + 1; q <= r; ++q) rowptr[q] = (int32_t)e;
+}
+
+// One thread per row: degree of A~ and presence of the stored diagonal.
+__global__ __launch_bounds__(256) void gcn_degree_kernel(const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ colidx,
+                                                         const float* __restrict__ vals, int32_t n, int mode,
+                                                         float* __restrict__ dinv, int* __restrict__ flag) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int a = rowptr[r], b = rowptr[r + 1];
+  float deg = 0.f;
+  bool has_diag = false;
+  for (int e = a; e < b; ++e) {
+    const float v = vals ? vals[e] : 1.0f;
+    deg += v;
+    has_diag |= (colidx[e] == r);
+  }
+  if (!has_diag) atomicOr(flag, 1);
+  if (mode == GCNX_NORM_SPEKTRAL) deg += 1.0f;
+  dinv[r] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gcn_scale_kernel(const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ colidx,
+                                                        const float* __restrict__ vals, int32_t n, int mode,
+                                                        const float* __restrict__ dinv,
+                                                        float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int a = rowptr[r], b = rowptr[r + 1];
+  const float dr = dinv[r];
+  for (int e = a; e < b; ++e) {
+    const int c = colidx[e];
+    float v = vals ? vals[e] : 1.0f;
+    if (mode == GCNX_NORM_SPEKTRAL && c == r) v += 1.0f;
+    out[e] = v * dr * dinv[c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcnx_coo_to_csr(gcnx_ctx* ctx, const int64_t* rows, const int64_t* cols, int64_t nnz, int64_t n,
+                    int32_t* rowptr, int32_t* colidx) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && nnz >= 0, "gcnx_coo_to_csr: negative size");
+  GCNX_REQUIRE(ctx, n < 2147483647LL && nnz < 2147483647LL,
+               "gcnx_coo_to_csr: N=%lld nnz=%lld do not fit the int32 CSR", (long long)n, (long long)nnz);
+  GCNX_REQUIRE(ctx, rowptr != nullptr, "gcnx_coo_to_csr: rowptr is NULL");
+  GCNX_REQUIRE(ctx, nnz == 0 || (rows && cols && colidx), "gcnx_coo_to_csr: NULL index array");
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_coo_to_csr synchronises and cannot be captured");
+  GCNX_HIP(ctx, hipMemsetAsync(ctx->flag, 0, sizeof(int), ctx->stream));
+  const int grid = gcnx_cdiv(nnz + 1, 256);
+  hipLaunchKernelGGL(coo_to_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream, rows, cols, nnz, n, rowptr,
+                     colidx, ctx->flag);
+  GCNX_LAUNCH_OK(ctx);
+  int h = 0;
+  GCNX_HIP(ctx, hipMemcpyAsync(&h, ctx->flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_coo_to_csr: indices out of [0,%lld) or rows not sorted row-major", (long long)n);
+  return GCNX_OK;
+}
+
+int gcnx_gcn_norm(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals_in,
+                  int32_t n, int mode, float* vals_out) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0, "gcnx_gcn_norm: negative n");
+  GCNX_REQUIRE(ctx, mode == GCNX_NORM_SPEKTRAL || mode == GCNX_NORM_PYG, "gcnx_gcn_norm: unknown mode %d", mode);
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_gcn_norm synchronises and cannot be captured");
+  if (n == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, rowptr && colidx && vals_out, "gcnx_gcn_norm: NULL pointer");
+  int rc = gcnx_ws_reserve(ctx, (size_t)n * sizeof(float));
+  if (rc) return rc;
+  float* dinv = (float*)ctx->ws;
+  GCNX_HIP(ctx, hipMemsetAsync(ctx->flag, 0, sizeof(int), ctx->stream));
+  const int grid = gcnx_cdiv(n, 256);
+  hipLaunchKernelGGL(gcn_degree_kernel, dim3(grid), dim3(256), 0, ctx->stream, rowptr, colidx, vals_in, n, mode,
+                     dinv, ctx->flag);
+  GCNX_LAUNCH_OK(ctx);
+  hipLaunchKernelGGL(gcn_scale_kernel, dim3(grid), dim3(256), 0, ctx->stream, rowptr, colidx, vals_in, n, mode,
+                     dinv, vals_out);
+  GCNX_LAUNCH_OK(ctx);
+  int h = 0;
+  GCNX_HIP(ctx, hipMemcpyAsync(&h, ctx->flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_gcn_norm: a row stores no diagonal entry (add self-loops on the host: GCNConv.preprocess)");
+  return GCNX_OK;
+}
+
+// Prep step used only when A^ is not symmetric: stable counting sort on the host (bitwise
+// reproducible entry order), staged through pageable host memory.
+int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                       int32_t n, int32_t nnz, int32_t* rowptr_t, int32_t* colidx_t, float* vals_t) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && nnz >= 0, "gcnx_csr_transpose: negative size");
+  GCNX_REQUIRE(ctx, rowptr && rowptr_t, "gcnx_csr_transpose: NULL rowptr");
+  GCNX_REQUIRE(ctx, nnz == 0 || (colidx && colidx_t), "gcnx_csr_transpose: NULL colidx");
+  GCNX_REQUIRE(ctx, (vals == nullptr) == (vals_t == nullptr), "gcnx_csr_transpose: vals and vals_t must both be given or both NULL");
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_csr_transpose synchronises and cannot be captured");
+  try {
+    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz), rpt((size_t)n + 1, 0), cit((size_t)nnz);
+    std::vector<float> v, vt;
+    GCNX_HIP(ctx, hipMemcpyAsync(rp.data(), rowptr, rp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (nnz) GCNX_HIP(ctx, hipMemcpyAsync(ci.data(), colidx, ci.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (vals && nnz) {
+      v.resize((size_t)nnz);
+      vt.resize((size_t)nnz);
+      GCNX_HIP(ctx, hipMemcpyAsync(v.data(), vals, v.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rp[n] != nnz) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_csr_transpose: rowptr[n]=%d != nnz=%d", rp[n], nnz);
+    for (int32_t e = 0; e < nnz; ++e) {
+      if (ci[e] < 0 || ci[e] >= n) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_csr_transpose: colidx[%d]=%d out of range", e, ci[e]);
+      rpt[(size_t)ci[e] + 1]++;
+    }
+    for (int32_t r = 0; r < n; ++r) rpt[r + 1] += rpt[r];
+    std::vector<int32_t> cur(rpt.begin(), rpt.end() - 1);
+    for (int32_t r = 0; r < n; ++r)
+      for (int32_t e = rp[r]; e < rp[r + 1]; ++e) {
+        const int32_t p = cur[ci[e]]++;
+        cit[p] = r;
+        if (!v.empty()) vt[p] = v[e];
+      }
+    GCNX_HIP(ctx, hipMemcpyAsync(rowptr_t, rpt.data(), rpt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) GCNX_HIP(ctx, hipMemcpyAsync(colidx_t, cit.data(), cit.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!v.empty()) GCNX_HIP(ctx, hipMemcpyAsync(vals_t, vt.data(), vt.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } catch (const std::bad_alloc&) {
+    return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_csr_transpose: out of host memory");
+  }
+  return GCNX_OK;
+}
+
+}  // extern "C"

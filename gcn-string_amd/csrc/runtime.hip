@@ -1,0 +1,259 @@
+// libgcnx runtime: context lifecycle, device memory, events, HIP-graph capture.
+#include <new>
+
+#include "common.h"
+
+thread_local std::string gcnx_tls_error;
+
+int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  gcnx_tls_error = buf;
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return GCNX_OK;
+  if (ctx->capturing)
+    return gcnx_fail(ctx, GCNX_ERR_INVALID,
+                     "workspace of %zu bytes needed during stream capture (have %zu): run the "
+                     "call sequence once eagerly before capturing", bytes, ctx->ws_bytes);
+  size_t want = bytes + (bytes >> 2);
+  if (ctx->ws) {
+    GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GCNX_HIP(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  hipError_t e = hipMalloc(&ctx->ws, want);
+  if (e != hipSuccess) return gcnx_fail(ctx, GCNX_ERR_NOMEM, "workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  ctx->ws_bytes = want;
+  return GCNX_OK;
+}
+
+extern "C" {
+
+int gcnx_version(void) { return 100; }
+
+int gcnx_device_count(int* n) {
+  if (!n) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "gcnx_device_count: n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *n = 0; return gcnx_fail(nullptr, GCNX_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *n = c;
+  return GCNX_OK;
+}
+
+int gcnx_ctx_create(int device, gcnx_ctx** out) {
+  if (!out) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "gcnx_ctx_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return gcnx_fail(nullptr, GCNX_ERR_HIP, "gcnx_ctx_create: no HIP device (%s); libgcnx has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= count)
+    return gcnx_fail(nullptr, GCNX_ERR_INVALID, "gcnx_ctx_create: device %d outside [0,%d)", device, count);
+  gcnx_ctx* ctx = new (std::nothrow) gcnx_ctx();
+  if (!ctx) return gcnx_fail(nullptr, GCNX_ERR_NOMEM, "gcnx_ctx_create: out of host memory");
+  ctx->device = device;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->flag, 4 * sizeof(int));
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    int rc = gcnx_fail(nullptr, GCNX_ERR_HIP, "gcnx_ctx_create(device %d): %s", device, hipGetErrorString(e));
+    delete ctx;
+    return rc;
+  }
+  ctx->num_cus = prop.multiProcessorCount;
+  ctx->arch = prop.gcnArchName;
+  if (ctx->arch.rfind("gfx950", 0) != 0) {
+    int rc = gcnx_fail(nullptr, GCNX_ERR_UNSUPPORTED, "gcnx_ctx_create: device %d is %s; libgcnx is built for gfx950 only",
+                       device, ctx->arch.c_str());
+    (void)hipFree(ctx->flag);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return GCNX_OK;
+}
+
+int gcnx_ctx_destroy(gcnx_ctx* ctx) {
+  if (!ctx) return GCNX_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->flag) (void)hipFree(ctx->flag);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GCNX_OK;
+}
+
+const char* gcnx_last_error(gcnx_ctx* ctx) {
+  if (ctx && !ctx->err.empty()) return ctx->err.c_str();
+  return gcnx_tls_error.c_str();
+}
+
+int gcnx_device_info(gcnx_ctx* ctx, char* name, int len, int* cus, size_t* hbm_bytes) {
+  GCNX_CHECK_CTX(ctx);
+  if (name && len > 0) snprintf(name, (size_t)len, "%s", ctx->arch.c_str());
+  if (cus) *cus = ctx->num_cus;
+  if (hbm_bytes) {
+    size_t fr = 0, tot = 0;
+    GCNX_HIP(ctx, hipSetDevice(ctx->device));
+    GCNX_HIP(ctx, hipMemGetInfo(&fr, &tot));
+    *hbm_bytes = tot;
+  }
+  return GCNX_OK;
+}
+
+int gcnx_malloc(gcnx_ctx* ctx, size_t bytes, void** dptr) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, dptr != nullptr, "gcnx_malloc: dptr is NULL");
+  *dptr = nullptr;
+  if (bytes == 0) return GCNX_OK;
+  GCNX_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess) return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_malloc(%zu): %s", bytes, hipGetErrorString(e));
+  return GCNX_OK;
+}
+
+int gcnx_free(gcnx_ctx* ctx, void* dptr) {
+  GCNX_CHECK_CTX(ctx);
+  if (!dptr) return GCNX_OK;
+  GCNX_HIP(ctx, hipSetDevice(ctx->device));
+  GCNX_HIP(ctx, hipFree(dptr));
+  return GCNX_OK;
+}
+
+int gcnx_memset(gcnx_ctx* ctx, void* dptr, int value, size_t bytes) {
+  GCNX_CHECK_CTX(ctx);
+  if (bytes == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, dptr != nullptr, "gcnx_memset: dptr is NULL");
+  GCNX_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_h2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  GCNX_CHECK_CTX(ctx);
+  if (bytes == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, dst && src, "gcnx_h2d: NULL pointer");
+  GCNX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_d2h(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  GCNX_CHECK_CTX(ctx);
+  if (bytes == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, dst && src, "gcnx_d2h: NULL pointer");
+  GCNX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_d2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  GCNX_CHECK_CTX(ctx);
+  if (bytes == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, dst && src, "gcnx_d2d: NULL pointer");
+  GCNX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_sync(gcnx_ctx* ctx) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_event_create(gcnx_ctx* ctx, gcnx_event** out) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, out != nullptr, "gcnx_event_create: out is NULL");
+  gcnx_event* ev = new (std::nothrow) gcnx_event();
+  if (!ev) return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_event_create: out of host memory");
+  hipError_t e = hipEventCreate(&ev->ev);
+  if (e != hipSuccess) { delete ev; return gcnx_fail(ctx, GCNX_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+  *out = ev;
+  return GCNX_OK;
+}
+
+int gcnx_event_record(gcnx_ctx* ctx, gcnx_event* ev) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, ev != nullptr, "gcnx_event_record: event is NULL");
+  GCNX_HIP(ctx, hipEventRecord(ev->ev, ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_event_elapsed_ms(gcnx_ctx* ctx, gcnx_event* start, gcnx_event* stop, float* ms) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, start && stop && ms, "gcnx_event_elapsed_ms: NULL argument");
+  GCNX_HIP(ctx, hipEventSynchronize(stop->ev));
+  GCNX_HIP(ctx, hipEventElapsedTime(ms, start->ev, stop->ev));
+  return GCNX_OK;
+}
+
+int gcnx_event_destroy(gcnx_ctx* ctx, gcnx_event* ev) {
+  GCNX_CHECK_CTX(ctx);
+  if (!ev) return GCNX_OK;
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return GCNX_OK;
+}
+
+int gcnx_capture_begin(gcnx_ctx* ctx) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_capture_begin: a capture is already active");
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GCNX_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return GCNX_OK;
+}
+
+int gcnx_capture_end(gcnx_ctx* ctx, gcnx_graph** out) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, ctx->capturing, "gcnx_capture_end: no capture active");
+  GCNX_REQUIRE(ctx, out != nullptr, "gcnx_capture_end: out is NULL");
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (e != hipSuccess || !g)
+    return gcnx_fail(ctx, GCNX_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    return gcnx_fail(ctx, GCNX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  gcnx_graph* gg = new (std::nothrow) gcnx_graph();
+  if (!gg) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); return gcnx_fail(ctx, GCNX_ERR_NOMEM, "out of host memory"); }
+  gg->graph = g;
+  gg->exec = ex;
+  *out = gg;
+  return GCNX_OK;
+}
+
+int gcnx_graph_launch(gcnx_ctx* ctx, gcnx_graph* g) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, g != nullptr, "gcnx_graph_launch: graph is NULL");
+  GCNX_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
+  return GCNX_OK;
+}
+
+int gcnx_graph_destroy(gcnx_ctx* ctx, gcnx_graph* g) {
+  GCNX_CHECK_CTX(ctx);
+  if (!g) return GCNX_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return GCNX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,25 @@
+"""gcnx -- MI355X-native GCN forward/backward for DisjointLoader batches.
+
+Host mirror of the Spektral call surface used by Sum02dean/GCN-STRING's src/scripts/gcn.py
+(DisjointLoader, GCNConv, GlobalSumPool, model(inputs, training=), train_step) over
+hand-written HIP kernels in libgcnx.so (C ABI: include/gcnx.h), bound with ctypes.
+No PyTorch, no TensorFlow, no CPU fallback.
+"""
+from . import _lib
+from .loader import Dataset, DisjointLoader, Graph, ListDataset, SparseTensor
+
+__all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "SparseTensor", "Context", "GCNConv",
+           "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "DeviceBatch"]
+
+
+def __getattr__(name):  # device-side names load libgcnx lazily, host-only use needs no .so
+    if name in ("Context", "DeviceArray", "DeviceCSR", "Segments"):
+        from . import device
+        return getattr(device, name)
+    if name in ("GCNConv", "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense"):
+        from . import layers
+        return getattr(layers, name)
+    if name in ("GCN2", "DeviceBatch"):
+        from . import models
+        return getattr(models, name)
+    raise AttributeError(name)

@@ -1,0 +1,106 @@
+"""ctypes binding of libgcnx.so (include/gcnx.h).  No PyTorch, no TensorFlow.
+
+The library is the product: if it is missing or cannot create a context this module raises --
+there is no CPU fallback (the CPU restatement under oracle/ is test infrastructure and is never
+imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgcnx.so")
+
+# enums of include/gcnx.h
+OK = 0
+ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+POOL_SUM, POOL_AVG, POOL_MAX = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+NORM_SPEKTRAL, NORM_PYG = 0, 1
+RED_SUM, RED_MAX = 0, 1
+UNIQUE_ID_BYTES = 128
+
+ACTS = {None: ACT_NONE, "linear": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "prelu": ACT_PRELU}
+POOLS = {"sum": POOL_SUM, "avg": POOL_AVG, "mean": POOL_AVG, "max": POOL_MAX}
+PRECS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_int = C.c_int
+
+# name -> argtypes (every function returns int unless listed in _RESTYPE)
+SIGNATURES = {
+    "gcnx_version": [],
+    "gcnx_device_count": [C.POINTER(_int)],
+    "gcnx_ctx_create": [_int, C.POINTER(_vp)],
+    "gcnx_ctx_destroy": [_vp],
+    "gcnx_last_error": [_vp],
+    "gcnx_device_info": [_vp, C.c_char_p, _int, C.POINTER(_int), C.POINTER(_sz)],
+    "gcnx_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "gcnx_free": [_vp, _vp],
+    "gcnx_memset": [_vp, _vp, _int, _sz],
+    "gcnx_h2d": [_vp, _vp, _vp, _sz],
+    "gcnx_d2h": [_vp, _vp, _vp, _sz],
+    "gcnx_d2d": [_vp, _vp, _vp, _sz],
+    "gcnx_sync": [_vp],
+    "gcnx_event_create": [_vp, C.POINTER(_vp)],
+    "gcnx_event_record": [_vp, _vp],
+    "gcnx_event_elapsed_ms": [_vp, _vp, _vp, C.POINTER(_f32)],
+    "gcnx_event_destroy": [_vp, _vp],
+    "gcnx_capture_begin": [_vp],
+    "gcnx_capture_end": [_vp, C.POINTER(_vp)],
+    "gcnx_graph_launch": [_vp, _vp],
+    "gcnx_graph_destroy": [_vp, _vp],
+    "gcnx_coo_to_csr": [_vp, _vp, _vp, _i64, _i64, _vp, _vp],
+    "gcnx_gcn_norm": [_vp, _vp, _vp, _vp, _i32, _int, _vp],
+    "gcnx_csr_transpose": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "gcnx_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp],
+    "gcnx_spmm_csr": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i32],
+    "gcnx_segment_pool": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _int, _vp],
+    "gcnx_softmax_cce": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
+    "gcnx_act_bias_grad": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp],
+    "gcnx_gemm_dw": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int],
+    "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],
+    "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
+    "gcnx_sgd": [_vp, _vp, _vp, _i64, _f32],
+    "gcnx_comm_unique_id": [C.c_char_p],
+    "gcnx_comm_init_rank": [_vp, C.c_char_p, _int, _int, C.POINTER(_vp)],
+    "gcnx_comm_destroy": [_vp],
+    "gcnx_allreduce_f32": [_vp, _vp, _vp, _i64, _int],
+}
+_RESTYPE = {"gcnx_last_error": C.c_char_p}
+
+_lib = None
+
+
+class GcnxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libgcnx error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """dlopen libgcnx.so and bind every symbol of include/gcnx.h; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GcnxError(-1, f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                            "(make -C gcn-string_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, _int)
+    _lib = lib
+    return lib
+
+
+def last_error(ctx_handle=None):
+    msg = load().gcnx_last_error(ctx_handle)
+    return msg.decode() if msg else ""
+
+
+def check(rc, ctx_handle=None):
+    if rc != OK:
+        raise GcnxError(rc, last_error(ctx_handle))

@@ -1,0 +1,347 @@
+"""Device context, device arrays and the thin op layer over the C ABI (include/gcnx.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Context:
+    """One GPU + one HIP stream (gcnx_ctx).  Not thread-safe; one per process per GPU."""
+
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(self.lib.gcnx_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self._live = True
+
+    # -- info ------------------------------------------------------------------------------
+    def info(self):
+        name = C.create_string_buffer(64)
+        cus = C.c_int()
+        hbm = C.c_size_t()
+        self._ck(self.lib.gcnx_device_info(self.h, name, 64, C.byref(cus), C.byref(hbm)))
+        return {"arch": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+    def _ck(self, rc):
+        L.check(rc, self.h)
+
+    # -- memory ----------------------------------------------------------------------------
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray.alloc(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        a = DeviceArray.alloc(self, shape, dtype)
+        a.fill_zero()
+        return a
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        a = DeviceArray.alloc(self, host.shape, host.dtype)
+        if host.nbytes:
+            self._ck(self.lib.gcnx_h2d(self.h, a.ptr, host.ctypes.data, host.nbytes))
+        return a
+
+    def sync(self):
+        self._ck(self.lib.gcnx_sync(self.h))
+
+    # -- events / graphs -------------------------------------------------------------------
+    def event(self):
+        return Event(self)
+
+    def capture(self, fn):
+        """Capture the gcnx calls made by fn() into a replayable HIP graph."""
+        self._ck(self.lib.gcnx_capture_begin(self.h))
+        try:
+            fn()
+        except Exception:
+            g = C.c_void_p()
+            self.lib.gcnx_capture_end(self.h, C.byref(g))
+            if g:
+                self.lib.gcnx_graph_destroy(self.h, g)
+            raise
+        g = C.c_void_p()
+        self._ck(self.lib.gcnx_capture_end(self.h, C.byref(g)))
+        return Graph(self, g)
+
+    def close(self):
+        if self._live:
+            self._live = False
+            self.lib.gcnx_ctx_destroy(self.h)
+
+    def __del__(self):
+        pass  # explicit close(); device arrays may outlive an implicit destructor order
+
+
+class Event:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._ck(ctx.lib.gcnx_event_create(ctx.h, C.byref(self.h)))
+
+    def record(self):
+        self.ctx._ck(self.ctx.lib.gcnx_event_record(self.ctx.h, self.h))
+        return self
+
+    def elapsed_ms_since(self, start):
+        ms = C.c_float()
+        self.ctx._ck(self.ctx.lib.gcnx_event_elapsed_ms(self.ctx.h, start.h, self.h, C.byref(ms)))
+        return ms.value
+
+
+class Graph:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def launch(self):
+        self.ctx._ck(self.ctx.lib.gcnx_graph_launch(self.ctx.h, self.h))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.gcnx_graph_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class DeviceArray:
+    """Row-major device buffer (1-D or 2-D) or a column-slice view of one (ld = row stride)."""
+
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "ld", "_base", "_owner")
+
+    def __init__(self, ctx, ptr, shape, dtype, ld=None, base=None, owner=False):
+        self.ctx, self.ptr, self.shape, self.dtype = ctx, ptr, tuple(int(s) for s in shape), np.dtype(dtype)
+        self.ld = int(ld) if ld is not None else (self.shape[-1] if self.shape else 1)
+        self._base, self._owner = base, owner
+
+    @classmethod
+    def alloc(cls, ctx, shape, dtype):
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        ctx._ck(ctx.lib.gcnx_malloc(ctx.h, max(nbytes, 16), C.byref(p)))
+        return cls(ctx, p.value, shape, dtype, owner=True)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def contiguous(self):
+        return len(self.shape) < 2 or self.ld == self.shape[1]
+
+    def cols(self, c0, c1):
+        """View of columns [c0, c1) -- Spektral's concat-skip is written in place through these."""
+        assert len(self.shape) == 2 and 0 <= c0 <= c1 <= self.shape[1]
+        return DeviceArray(self.ctx, self.ptr + c0 * self.dtype.itemsize, (self.shape[0], c1 - c0), self.dtype,
+                           ld=self.ld, base=self)
+
+    def flat(self, off, n, shape=None):
+        """View of n elements starting at element `off` of a contiguous buffer."""
+        assert self.contiguous and off + n <= self.size
+        return DeviceArray(self.ctx, self.ptr + off * self.dtype.itemsize, shape or (n,), self.dtype, base=self)
+
+    def fill_zero(self):
+        assert self.contiguous
+        self.ctx._ck(self.ctx.lib.gcnx_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+
+    def copy_from_host(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.size == self.size and self.contiguous
+        self.ctx._ck(self.ctx.lib.gcnx_h2d(self.ctx.h, self.ptr, host.ctypes.data, host.nbytes))
+
+    def numpy(self):
+        if self.contiguous:
+            out = np.empty(self.shape, dtype=self.dtype)
+            if out.nbytes:
+                self.ctx._ck(self.ctx.lib.gcnx_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+            return out
+        # strided view: fetch the enclosing rows and slice on the host
+        rows, cols = self.shape
+        span = (rows - 1) * self.ld + cols
+        buf = np.empty(span, dtype=self.dtype)
+        self.ctx._ck(self.ctx.lib.gcnx_d2h(self.ctx.h, buf.ctypes.data, self.ptr, buf.nbytes))
+        full = np.zeros(rows * self.ld, dtype=self.dtype)
+        full[:span] = buf
+        return full.reshape(rows, self.ld)[:, :cols].copy()
+
+    def free(self):
+        if self._owner and self.ptr and self.ctx._live:
+            self.ctx.lib.gcnx_free(self.ctx.h, self.ptr)
+        self.ptr = None
+        self._owner = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceCSR:
+    """Adjacency of a disjoint batch on the device: CSR int32 (+ fp32 values or None = ones).
+
+    ``block_ptr`` (= graph_ptr) marks the diagonal blocks; ``symmetric`` lets the backward pass
+    reuse this CSR for A^T (true for the reference's undirected contact graphs and for
+    gcn_filter of a symmetric A); otherwise ``transpose()`` builds the transposed CSR once.
+    """
+
+    def __init__(self, ctx, n, nnz, rowptr, colidx, vals=None, block_ptr=None, n_blocks=0, symmetric=True):
+        self.ctx, self.n, self.nnz = ctx, int(n), int(nnz)
+        self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
+        self.block_ptr, self.n_blocks = block_ptr, int(n_blocks)
+        self.symmetric = symmetric
+        self._t = None
+        self.dense_shape = (self.n, self.n)
+
+    @classmethod
+    def from_host_csr(cls, ctx, rowptr, colidx, vals=None, graph_ptr=None, symmetric=True):
+        n = len(rowptr) - 1
+        d_rp = ctx.to_device(rowptr, np.int32)
+        d_ci = ctx.to_device(colidx, np.int32)
+        d_v = ctx.to_device(vals, np.float32) if vals is not None else None
+        d_gp = ctx.to_device(graph_ptr, np.int32) if graph_ptr is not None else None
+        return cls(ctx, n, len(colidx), d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric)
+
+    @classmethod
+    def from_coo(cls, ctx, indices, values, n, graph_ptr=None, symmetric=True, weighted=True):
+        """DisjointLoader's SparseTensor (indices[nnz,2] int64 row-major sorted) -> device CSR
+        via gcnx_coo_to_csr (the COO never becomes a host CSR)."""
+        indices = np.asarray(indices)
+        nnz = indices.shape[0]
+        rows = ctx.to_device(indices[:, 0], np.int64)
+        cols = ctx.to_device(indices[:, 1], np.int64)
+        d_rp = ctx.empty(n + 1, np.int32)
+        d_ci = ctx.empty(max(nnz, 1), np.int32)
+        ctx._ck(ctx.lib.gcnx_coo_to_csr(ctx.h, rows.ptr, cols.ptr, nnz, n, d_rp.ptr, d_ci.ptr))
+        rows.free(); cols.free()
+        d_v = ctx.to_device(values, np.float32) if (weighted and values is not None) else None
+        d_gp = ctx.to_device(graph_ptr, np.int32) if graph_ptr is not None else None
+        return cls(ctx, n, nnz, d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric)
+
+    def gcn_norm(self, mode="spektral"):
+        """Device gcn_filter: returns a CSR sharing structure with self, values = A^."""
+        out = self.ctx.empty(max(self.nnz, 1), np.float32)
+        self.ctx._ck(self.ctx.lib.gcnx_gcn_norm(self.ctx.h, self.rowptr.ptr, self.colidx.ptr,
+                                                 self.vals.ptr if self.vals is not None else None, self.n,
+                                                 L.NORM_SPEKTRAL if mode == "spektral" else L.NORM_PYG, out.ptr))
+        return DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, out, self.block_ptr, self.n_blocks,
+                         self.symmetric)
+
+    def transpose(self):
+        if self.symmetric:
+            return self
+        if self._t is None:
+            ctx = self.ctx
+            rp = ctx.empty(self.n + 1, np.int32)
+            ci = ctx.empty(max(self.nnz, 1), np.int32)
+            v = ctx.empty(max(self.nnz, 1), np.float32) if self.vals is not None else None
+            ctx._ck(ctx.lib.gcnx_csr_transpose(ctx.h, self.rowptr.ptr, self.colidx.ptr,
+                                               self.vals.ptr if self.vals is not None else None, self.n, self.nnz,
+                                               rp.ptr, ci.ptr, v.ptr if v is not None else None))
+            self._t = DeviceCSR(ctx, self.n, self.nnz, rp, ci, v, self.block_ptr, self.n_blocks, False)
+        return self._t
+
+    def unweighted(self):
+        """Same structure, values ignored (GeneralConv aggregation)."""
+        return DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, None, self.block_ptr, self.n_blocks,
+                         self.symmetric)
+
+
+class Segments:
+    """Graph membership of the rows of a disjoint batch: graph_ptr int32[B+1] on the device
+    (the sorted id vector ``i`` of DisjointLoader, run-length encoded)."""
+
+    def __init__(self, ctx, graph_ptr_host):
+        gp = np.asarray(graph_ptr_host, dtype=np.int32)
+        self.ctx, self.n_graphs, self.n = ctx, len(gp) - 1, int(gp[-1])
+        self.host = gp
+        self.dev = ctx.to_device(gp, np.int32)
+
+    @classmethod
+    def from_ids(cls, ctx, i, n_graphs=None):
+        i = np.asarray(i)
+        b = int(i.max()) + 1 if n_graphs is None and i.size else (n_graphs or 0)
+        if i.size and np.any(np.diff(i) < 0):
+            raise ValueError("segment ids must be sorted (DisjointLoader order)")
+        gp = np.zeros(b + 1, dtype=np.int64)
+        np.cumsum(np.bincount(i, minlength=b), out=gp[1:])
+        return cls(ctx, gp)
+
+
+# ------------------------------------------------------------------------------------------- #
+# ops: one function per C entry point, operating on DeviceArrays
+# ------------------------------------------------------------------------------------------- #
+
+def _p(a):
+    return None if a is None else a.ptr
+
+
+def gemm(ctx, x, w, bias, out, act=None, prec="f32", alpha=None):
+    n, fi = x.shape
+    fo = w.shape[1]
+    assert w.shape[0] == fi and out.shape == (n, fo)
+    ctx._ck(ctx.lib.gcnx_gemm(ctx.h, x.ptr, x.ld, w.ptr, _p(bias), out.ptr, out.ld, n, fi, fo, L.PRECS[prec],
+                              L.ACTS[act], _p(alpha)))
+    return out
+
+
+def spmm(ctx, a, h, bias, out, act=None):
+    n, f = h.shape
+    assert a.n == n and out.shape == (n, f)
+    ctx._ck(ctx.lib.gcnx_spmm_csr(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), h.ptr, h.ld, _p(bias), out.ptr,
+                                  out.ld, n, f, L.ACTS[act], _p(a.block_ptr), a.n_blocks))
+    return out
+
+
+def segment_pool(ctx, seg, x, pooled, mode="sum", argmax=None):
+    ctx._ck(ctx.lib.gcnx_segment_pool(ctx.h, seg.dev.ptr, x.ptr, x.ld, pooled.ptr, seg.n_graphs, x.shape[1],
+                                      L.POOLS[mode], _p(argmax)))
+    return pooled
+
+
+def segment_pool_bwd(ctx, seg, dpooled, dx, mode="sum", argmax=None, y=None, db=None):
+    n, f = dx.shape
+    ctx._ck(ctx.lib.gcnx_segment_pool_bwd(ctx.h, seg.dev.ptr, dpooled.ptr, dx.ptr, dx.ld, n, seg.n_graphs, f,
+                                          L.POOLS[mode], _p(argmax), _p(y), y.ld if y is not None else 0, _p(db)))
+    return dx
+
+
+def softmax_cce(ctx, logits, y, probs, loss_acc, dlogits=None, denom=None):
+    b, c = logits.shape
+    ctx._ck(ctx.lib.gcnx_softmax_cce(ctx.h, logits.ptr, y.ptr, b, c, float(denom if denom else b), probs.ptr,
+                                     loss_acc.ptr, _p(dlogits)))
+
+
+def act_bias_grad(ctx, dy, y, dz, act, db=None, alpha=None, dalpha=None):
+    n, f = dy.shape
+    ctx._ck(ctx.lib.gcnx_act_bias_grad(ctx.h, dy.ptr, dy.ld, _p(y), y.ld if y is not None else 0, dz.ptr, dz.ld, n,
+                                       f, L.ACTS[act], _p(alpha), _p(db), _p(dalpha)))
+    return dz
+
+
+def gemm_dw(ctx, x, dh, dw, prec="f32"):
+    n, fi = x.shape
+    fo = dh.shape[1]
+    assert dh.shape[0] == n and dw.shape == (fi, fo) and dw.contiguous
+    ctx._ck(ctx.lib.gcnx_gemm_dw(ctx.h, x.ptr, x.ld, dh.ptr, dh.ld, dw.ptr, n, fi, fo, L.PRECS[prec]))
+    return dw
+
+
+def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
+    n, fo = dh.shape
+    fi = w.shape[0]
+    assert w.shape[1] == fo and dx.shape == (n, fi)
+    ctx._ck(ctx.lib.gcnx_gemm_dx(ctx.h, dh.ptr, dh.ld, w.ptr, dx.ptr, dx.ld, n, fi, fo, L.PRECS[prec],
+                                 1 if accumulate else 0, _p(y_mask), y_mask.ld if y_mask is not None else 0, _p(db)))
+    return dx
+
+
+def sgd(ctx, params, grads, lr):
+    ctx._ck(ctx.lib.gcnx_sgd(ctx.h, params.ptr, grads.ptr, params.size, float(lr)))

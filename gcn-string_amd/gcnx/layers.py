@@ -1,0 +1,216 @@
+"""Host mirror of the Spektral / Keras layer call surface used on the hot path.
+
+Upstream signatures kept: ``GCNConv(channels, activation=None, use_bias=True,
+kernel_initializer="glorot_uniform", bias_initializer="zeros")`` called as ``layer([x, a])``;
+``GCNConv.preprocess(a)``; ``GlobalSumPool()([x, i])`` (+ Avg/Max); ``Dense(units, activation)``.
+Reference topology: GCNConv -> GCNConv -> global pool -> Linear (gcn_utills.py:805-808,
+832-842); live model ctor gcn.py:320, forward gcn.py:334/351, gradients gcn.py:337.
+
+There is no autograd here: every layer has ``backward(dy)`` that returns dx and leaves the
+parameter gradients in ``layer.grads`` (what tape.gradient, gcn.py:337, would produce).
+All arithmetic runs in libgcnx (HIP); these classes only own buffers and sequence calls.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import device as D
+
+
+def glorot_uniform(rng, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(np.float32)
+
+
+class Layer:
+    """Keras-like lazy build: parameters are created on the first call, when the input width
+    is known.  ``storage`` lets a model place all parameters in one flat buffer."""
+
+    def __init__(self, ctx=None, seed=None):
+        self.ctx = ctx
+        self.built = False
+        self.params, self.grads = {}, {}
+        self._rng = np.random.default_rng(seed)
+        self._scratch = {}
+
+    # parameter spec: list of (name, shape, initial host array)
+    def _param_spec(self, in_dim):
+        return []
+
+    def n_params(self, in_dim):
+        return sum(int(np.prod(s)) for _, s, _ in self._param_spec(in_dim))
+
+    def build(self, ctx, in_dim, p_store=None, g_store=None, offset=0):
+        self.ctx = ctx
+        spec = self._param_spec(in_dim)
+        total = sum(int(np.prod(s)) for _, s, _ in spec)
+        if p_store is None:
+            p_store, g_store, offset = ctx.zeros(max(total, 1)), ctx.zeros(max(total, 1)), 0
+        off = offset
+        for name, shape, init in spec:
+            n = int(np.prod(shape))
+            self.params[name] = p_store.flat(off, n, shape)
+            self.grads[name] = g_store.flat(off, n, shape)
+            self.params[name].copy_from_host(init)
+            off += n
+        self.in_dim, self.built = in_dim, True
+        return off
+
+    def _buf(self, key, shape, dtype=np.float32):
+        b = self._scratch.get(key)
+        if b is None or b.shape != tuple(shape):
+            b = self.ctx.empty(shape, dtype)
+            self._scratch[key] = b
+        return b
+
+    def get_weights(self):
+        return [self.params[k].numpy() for k in self.params]
+
+    def set_weights(self, weights):
+        for k, w in zip(self.params, weights):
+            self.params[k].copy_from_host(w)
+
+    @property
+    def trainable_variables(self):
+        return list(self.params.values())
+
+    def __call__(self, inputs, **kw):
+        return self.call(inputs, **kw)
+
+
+class GCNConv(Layer):
+    """out = activation(A^ (x W) + b)   -- bias after aggregation."""
+
+    def __init__(self, channels, activation=None, use_bias=True, kernel_initializer="glorot_uniform",
+                 bias_initializer="zeros", prec="f32", **kw):
+        super().__init__(**kw)
+        if activation not in (None, "linear", "relu"):
+            raise NotImplementedError(f"GCNConv activation {activation!r}: only None/'relu' are fused in the SpMM epilogue")
+        if kernel_initializer != "glorot_uniform" or bias_initializer != "zeros":
+            raise NotImplementedError("only glorot_uniform / zeros initialisers (the Spektral defaults)")
+        self.channels, self.activation, self.use_bias, self.prec = int(channels), activation, use_bias, prec
+
+    @staticmethod
+    def preprocess(a, mode="spektral"):
+        """gcn_filter on one graph's scipy adjacency (a dataset transform in Spektral): adds I
+        unconditionally (diagonal 2 where a self-loop exists), D^-1/2 A~ D^-1/2 (8.A.2)."""
+        import scipy.sparse as sp
+
+        a = sp.csr_matrix(a, dtype=np.float64)
+        if mode == "spektral":
+            a = a + sp.identity(a.shape[0], format="csr")
+        else:  # PyG add_remaining_self_loops
+            a = a + sp.diags(np.where(a.diagonal() == 0, 1.0, 0.0))
+        a = sp.csr_matrix(a)
+        deg = np.asarray(a.sum(1)).ravel()
+        dinv = np.zeros_like(deg)
+        dinv[deg > 0] = 1.0 / np.sqrt(deg[deg > 0])
+        out = sp.csr_matrix(sp.diags(dinv) @ a @ sp.diags(dinv))
+        out.sort_indices()
+        return out
+
+    def _param_spec(self, in_dim):
+        spec = [("kernel", (in_dim, self.channels), glorot_uniform(self._rng, in_dim, self.channels))]
+        if self.use_bias:
+            spec.append(("bias", (self.channels,), np.zeros(self.channels, np.float32)))
+        return spec
+
+    def call(self, inputs, out=None):
+        x, a = inputs
+        if not self.built:
+            self.build(x.ctx, x.shape[1])
+        n = x.shape[0]
+        h = self._buf("h", (n, self.channels))
+        y = out if out is not None else self._buf("y", (n, self.channels))
+        D.gemm(self.ctx, x, self.params["kernel"], None, h, prec=self.prec)
+        D.spmm(self.ctx, a, h, self.params.get("bias"), y, act=self.activation)
+        self._saved = (x, a, y)
+        return y
+
+    def backward(self, dy, need_dx=True, dy_is_dz=False):
+        """dy: gradient wrt the layer output.  dy_is_dz=True when the caller already applied the
+        activation mask and filled grads['bias'] (fused upstream)."""
+        x, a, y = self._saved
+        n = x.shape[0]
+        dz = dy
+        if not dy_is_dz:
+            dz = self._buf("dz", (n, self.channels))
+            D.act_bias_grad(self.ctx, dy, y, dz, self.activation, db=self.grads.get("bias"))
+        dh = self._buf("h", (n, self.channels))  # forward scratch is dead by now
+        D.spmm(self.ctx, a.transpose(), dz, None, dh)
+        D.gemm_dw(self.ctx, x, dh, self.grads["kernel"], prec=self.prec)
+        if not need_dx:
+            return None
+        dx = self._buf("dx", (n, self.in_dim))
+        D.gemm_dx(self.ctx, dh, self.params["kernel"], dx, prec=self.prec)
+        return dx
+
+
+class Dense(Layer):
+    """Keras Dense: act(x W + b); activation None / 'relu' (softmax is fused with the loss)."""
+
+    def __init__(self, units, activation=None, use_bias=True, prec="f32", **kw):
+        super().__init__(**kw)
+        if activation not in (None, "linear", "relu"):
+            raise NotImplementedError(f"Dense activation {activation!r}")
+        self.units, self.activation, self.use_bias, self.prec = int(units), activation, use_bias, prec
+
+    def _param_spec(self, in_dim):
+        spec = [("kernel", (in_dim, self.units), glorot_uniform(self._rng, in_dim, self.units))]
+        if self.use_bias:
+            spec.append(("bias", (self.units,), np.zeros(self.units, np.float32)))
+        return spec
+
+    def call(self, x, out=None):
+        if not self.built:
+            self.build(x.ctx, x.shape[1])
+        y = out if out is not None else self._buf("y", (x.shape[0], self.units))
+        D.gemm(self.ctx, x, self.params["kernel"], self.params.get("bias"), y, act=self.activation, prec=self.prec)
+        self._saved = (x, y)
+        return y
+
+    def backward(self, dy, need_dx=True):
+        x, y = self._saved
+        dz = self._buf("dz", dy.shape)
+        D.act_bias_grad(self.ctx, dy, y, dz, self.activation, db=self.grads.get("bias"))
+        D.gemm_dw(self.ctx, x, dz, self.grads["kernel"], prec=self.prec)
+        if not need_dx:
+            return None
+        dx = self._buf("dx", (x.shape[0], self.in_dim))
+        D.gemm_dx(self.ctx, dz, self.params["kernel"], dx, prec=self.prec)
+        return dx
+
+
+class _GlobalPool(Layer):
+    mode = "sum"
+
+    def call(self, inputs, out=None):
+        x, seg = inputs
+        if not isinstance(seg, D.Segments):
+            seg = D.Segments.from_ids(x.ctx, seg)
+        self.ctx = x.ctx
+        pooled = out if out is not None else self._buf("p", (seg.n_graphs, x.shape[1]))
+        arg = self._buf("arg", (seg.n_graphs, x.shape[1]), np.int32) if self.mode == "max" else None
+        D.segment_pool(self.ctx, seg, x, pooled, self.mode, arg)
+        self._saved = (x.shape, seg, arg)
+        return pooled
+
+    def backward(self, dp, y_mask=None, db=None, out=None):
+        shape, seg, arg = self._saved
+        dx = out if out is not None else self._buf("dx", shape)
+        D.segment_pool_bwd(self.ctx, seg, dp, dx, self.mode, arg, y=y_mask, db=db)
+        return dx
+
+
+class GlobalSumPool(_GlobalPool):
+    """P[g] = sum_{n: i[n]=g} X[n]  (tf.math.segment_sum; GeneralGNN pool='sum', gcn.py:320)."""
+    mode = "sum"
+
+
+class GlobalAvgPool(_GlobalPool):
+    mode = "avg"
+
+
+class GlobalMaxPool(_GlobalPool):
+    """global_max_pool of the reference's torch topology (gcn_utills.py:842)."""
+    mode = "max"

@@ -1,0 +1,180 @@
+"""Host mirror of the Spektral data surface the reference uses: Graph, Dataset, DisjointLoader.
+
+Reference call sites: ``MyDataset(Dataset)`` src/scripts/gcn.py:66-197 builds
+``Graph(x=, a=, y=)`` objects (gcn.py:153-157); ``DisjointLoader(data, batch_size=, epochs=,
+shuffle=)`` gcn.py:316-317 is iterated at gcn.py:367 and stepped with ``__next__`` at
+gcn.py:350; ``steps_per_epoch`` is read at gcn.py:348,372.  Semantics restated from Spektral
+1.x; pure NumPy/SciPy, as upstream.
+"""
+from __future__ import annotations
+
+import math
+from collections import namedtuple
+
+import numpy as np
+
+# What tf.SparseTensor exposes and the model consumes: indices [nnz,2] int64 (row, col)
+# row-major sorted, values [nnz], dense_shape (N, N).
+SparseTensor = namedtuple("SparseTensor", ["indices", "values", "dense_shape"])
+
+
+class Graph:
+    """spektral.data.Graph: node features x [n,F], adjacency a (scipy sparse / dense [n,n]),
+    optional edge features e, label y."""
+
+    def __init__(self, x=None, a=None, e=None, y=None, **kwargs):
+        self.x, self.a, self.e, self.y = x, a, e, y
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def n_nodes(self):
+        return self.x.shape[0] if self.x is not None else self.a.shape[0]
+
+    @property
+    def n_node_features(self):
+        return self.x.shape[-1]
+
+    @property
+    def n_labels(self):
+        y = np.asarray(self.y)
+        return y.shape[-1] if y.ndim else 1
+
+    def numpy(self):
+        return tuple(v for v in (self.x, self.a, self.e, self.y) if v is not None)
+
+
+class Dataset:
+    """spektral.data.Dataset: subclass and implement read() -> list[Graph] (gcn.py:84-102);
+    supports len, integer / slice / index-array / boolean-mask indexing (gcn.py:282-294)."""
+
+    def __init__(self, transforms=None, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        self.graphs = self.read()
+        if transforms:
+            for t in (transforms if isinstance(transforms, (list, tuple)) else [transforms]):
+                self.apply(t)
+
+    def read(self):
+        raise NotImplementedError
+
+    def apply(self, transform):
+        self.graphs = [transform(g) for g in self.graphs]
+
+    def __len__(self):
+        return len(self.graphs)
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            return self.graphs[int(key)]
+        sub = object.__new__(type(self))
+        sub.__dict__.update({k: v for k, v in self.__dict__.items() if k != "graphs"})
+        if isinstance(key, slice):
+            sub.graphs = self.graphs[key]
+        else:
+            key = np.asarray(key)
+            idx = np.nonzero(key)[0] if key.dtype == bool else key
+            sub.graphs = [self.graphs[int(i)] for i in idx]
+        return sub
+
+    def __iter__(self):
+        return iter(self.graphs)
+
+    @property
+    def n_labels(self):
+        return self.graphs[0].n_labels
+
+    @property
+    def n_node_features(self):
+        return self.graphs[0].n_node_features
+
+
+class ListDataset(Dataset):
+    """A Dataset over an in-memory list of Graphs."""
+
+    def __init__(self, graphs, **kwargs):
+        self._graphs = list(graphs)
+        super().__init__(**kwargs)
+
+    def read(self):
+        return self._graphs
+
+
+def to_disjoint(x_list, a_list):
+    """spektral.data.utils.to_disjoint: x = vstack, a = block_diag, i = repeat(arange(B), n)."""
+    import scipy.sparse as sp
+
+    x = np.vstack(x_list)
+    a = sp.block_diag(list(a_list))
+    n_nodes = np.array([x_.shape[0] for x_ in x_list], dtype=np.int64)
+    i = np.repeat(np.arange(len(n_nodes), dtype=np.int64), n_nodes)
+    return x, a, i
+
+
+def sp_matrix_to_sp_tensor(a):
+    """spektral.layers.ops.sp_matrix_to_sp_tensor + tf.sparse.reorder: (row, col, val) of the
+    non-zero entries in row-major order."""
+    a = a.tocoo()
+    keep = a.data != 0                      # sp.find drops explicit zeros
+    row, col, val = a.row[keep], a.col[keep], a.data[keep]
+    order = np.lexsort((col, row))
+    idx = np.stack([row[order].astype(np.int64), col[order].astype(np.int64)], axis=1)
+    return SparseTensor(idx, val[order], (int(a.shape[0]), int(a.shape[1])))
+
+
+def collate_disjoint(graphs, node_level=False):
+    x, a, i = to_disjoint([g.x for g in graphs], [g.a for g in graphs])
+    y = np.vstack([g.y for g in graphs]) if node_level else np.array([g.y for g in graphs])
+    return (x, sp_matrix_to_sp_tensor(a), i), y
+
+
+class DisjointLoader:
+    """spektral.data.DisjointLoader(dataset, node_level=False, batch_size=1, epochs=None,
+    shuffle=True): an iterator that yields ``((x, a, i), y)`` per batch.
+
+    Each epoch optionally shuffles the graph order, then yields consecutive slices of
+    batch_size graphs (the last one may be smaller); epochs=None iterates forever, as the
+    reference's evaluate() relies on (gcn.py:317,348-350).
+    """
+
+    def __init__(self, dataset, node_level=False, batch_size=1, epochs=None, shuffle=True, seed=None):
+        self.dataset, self.node_level = dataset, node_level
+        self.batch_size, self.epochs, self.shuffle = int(batch_size), epochs, shuffle
+        self._rng = np.random.default_rng(seed) if seed is not None else np.random
+        self._gen = self._generator()
+
+    @property
+    def steps_per_epoch(self):
+        return int(math.ceil(len(self.dataset) / self.batch_size))
+
+    def _generator(self):
+        n = len(self.dataset)
+        epoch = 0
+        while self.epochs is None or epoch < self.epochs:
+            order = np.arange(n)
+            if self.shuffle:
+                self._rng.shuffle(order)
+            for s in range(0, n, self.batch_size):
+                yield [self.dataset[int(j)] for j in order[s:s + self.batch_size]]
+            epoch += 1
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return collate_disjoint(next(self._gen), self.node_level)
+
+    def collate(self, batch):
+        return collate_disjoint(batch, self.node_level)
+
+    def load(self):
+        return self
+
+    def tf_signature(self):
+        """Shape/dtype description of one batch (the reference feeds it to tf.function,
+        gcn.py:328); plain tuples here since there is no TensorFlow."""
+        g = self.dataset[0]
+        f = g.n_node_features
+        return ((("x", (None, f), np.float64), ("a", (None, None), "sparse"), ("i", (None,), np.int64)),
+                ("y", (None, g.n_labels), np.asarray(g.y).dtype))

@@ -1,0 +1,186 @@
+/*
+ * gcnx.h -- C ABI of libgcnx.so: MI355X (gfx950) kernels for the GCN forward/backward
+ * hot path of Sum02dean/GCN-STRING.
+ *
+ * The reference has no FFI or plugin interface for this path: its arithmetic runs inside
+ * un-vendored Spektral/TensorFlow ops reached from src/scripts/gcn.py (call sites cited per
+ * entry point below).  Each function here replaces one TensorFlow CPU op (SURVEY.md 2.3
+ * "implicit kernel inventory" K1..K9 and their gradients) behind plain C types, so that the
+ * Python host mirror of the Spektral call surface (gcn-string_amd/gcnx) binds it via ctypes.
+ *
+ * Conventions
+ *   - every function returns int: 0 = GCNX_OK, otherwise a gcnx_status; the message is
+ *     available from gcnx_last_error().  No C++ exception crosses this boundary.
+ *   - all matrix operands are DEVICE pointers obtained from gcnx_malloc(), row-major fp32
+ *     with an explicit leading dimension (elements) so that column slices of a wider buffer
+ *     can be read/written in place (Spektral's connectivity="cat" skip, K7).
+ *   - CSR: rowptr int32[N+1], colidx int32[nnz], vals fp32[nnz] or NULL (= all ones, the
+ *     GeneralConv "sum" aggregation which ignores adjacency values).
+ *   - a ctx is bound to one device and one HIP stream; calls are stream-ordered and return
+ *     before the device finishes unless documented as synchronising.  A ctx is not
+ *     thread-safe; distinct ctxs are independent.
+ *   - the caller owns every buffer it allocates; the library keeps no user pointer after a
+ *     call returns (captured graphs excepted: buffers used inside a capture must outlive it).
+ */
+#ifndef GCNX_H
+#define GCNX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define GCNX_API __attribute__((visibility("default")))
+#else
+#define GCNX_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gcnx_ctx gcnx_ctx;
+typedef struct gcnx_comm gcnx_comm;
+typedef struct gcnx_graph gcnx_graph;
+typedef struct gcnx_event gcnx_event;
+
+typedef enum {
+  GCNX_OK = 0,
+  GCNX_ERR_INVALID = 1,     /* bad argument / shape / alignment */
+  GCNX_ERR_HIP = 2,         /* HIP runtime error */
+  GCNX_ERR_RCCL = 3,        /* RCCL error or librccl missing */
+  GCNX_ERR_NOMEM = 4,
+  GCNX_ERR_UNSUPPORTED = 5, /* valid request this build has no kernel for */
+  GCNX_ERR_DATA = 6         /* device-side validation of input data failed */
+} gcnx_status;
+
+typedef enum { GCNX_ACT_NONE = 0, GCNX_ACT_RELU = 1, GCNX_ACT_PRELU = 2 } gcnx_act;
+typedef enum { GCNX_POOL_SUM = 0, GCNX_POOL_AVG = 1, GCNX_POOL_MAX = 2 } gcnx_pool;
+/* GEMM arithmetic: F32 = exact fp32 MFMA (v_mfma_f32_*_f32); BF16 = inputs rounded to bf16,
+ * fp32 accumulate; BF16X3 = hi/lo bf16 split, three MFMA passes, fp32-grade accuracy. */
+typedef enum { GCNX_PREC_F32 = 0, GCNX_PREC_BF16 = 1, GCNX_PREC_BF16X3 = 2 } gcnx_prec;
+typedef enum { GCNX_NORM_SPEKTRAL = 0, GCNX_NORM_PYG = 1 } gcnx_norm_mode;
+typedef enum { GCNX_RED_SUM = 0, GCNX_RED_MAX = 1 } gcnx_redop;
+
+#define GCNX_UNIQUE_ID_BYTES 128
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+GCNX_API int gcnx_version(void);
+GCNX_API int gcnx_device_count(int* n);
+GCNX_API int gcnx_ctx_create(int device, gcnx_ctx** out);
+GCNX_API int gcnx_ctx_destroy(gcnx_ctx* ctx);
+/* Message of the last failing call on ctx (ctx may be NULL: last error of this thread). */
+GCNX_API const char* gcnx_last_error(gcnx_ctx* ctx);
+/* Fills name[len] with the device's gcnArchName and *cus with its compute-unit count. */
+GCNX_API int gcnx_device_info(gcnx_ctx* ctx, char* name, int len, int* cus, size_t* hbm_bytes);
+
+/* ---- memory / sync (h2d, d2h synchronise the ctx stream) ------------------------------- */
+GCNX_API int gcnx_malloc(gcnx_ctx* ctx, size_t bytes, void** dptr);
+GCNX_API int gcnx_free(gcnx_ctx* ctx, void* dptr);
+GCNX_API int gcnx_memset(gcnx_ctx* ctx, void* dptr, int value, size_t bytes);
+GCNX_API int gcnx_h2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
+GCNX_API int gcnx_d2h(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
+GCNX_API int gcnx_d2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
+GCNX_API int gcnx_sync(gcnx_ctx* ctx);
+
+/* ---- timing: HIP events on the ctx stream ---------------------------------------------- */
+GCNX_API int gcnx_event_create(gcnx_ctx* ctx, gcnx_event** out);
+GCNX_API int gcnx_event_record(gcnx_ctx* ctx, gcnx_event* ev);
+/* Synchronises on `stop`, then returns stop - start in milliseconds. */
+GCNX_API int gcnx_event_elapsed_ms(gcnx_ctx* ctx, gcnx_event* start, gcnx_event* stop, float* ms);
+GCNX_API int gcnx_event_destroy(gcnx_ctx* ctx, gcnx_event* ev);
+
+/* ---- HIP-graph capture of a call sequence (replaces tf.function, gcn.py:328) ----------- */
+GCNX_API int gcnx_capture_begin(gcnx_ctx* ctx);
+GCNX_API int gcnx_capture_end(gcnx_ctx* ctx, gcnx_graph** out);
+GCNX_API int gcnx_graph_launch(gcnx_ctx* ctx, gcnx_graph* g);
+GCNX_API int gcnx_graph_destroy(gcnx_ctx* ctx, gcnx_graph* g);
+
+/* ---- graph preparation ------------------------------------------------------------------ */
+/* DisjointLoader's SparseTensor (gcn.py:316-317 -> sp_matrix_to_sp_tensor + tf.sparse.reorder):
+ * row-major sorted COO int64 (rows[nnz], cols[nnz]) on the DEVICE -> CSR int32.  Synchronises.
+ * Fails with GCNX_ERR_DATA if rows are not non-decreasing or an index is outside [0,N). */
+GCNX_API int gcnx_coo_to_csr(gcnx_ctx* ctx, const int64_t* rows, const int64_t* cols, int64_t nnz,
+                    int64_t n, int32_t* rowptr, int32_t* colidx);
+/* Spektral GCNConv.preprocess = gcn_filter on a CSR whose every row stores its
+ * diagonal entry (true for the reference's data: gcn_utills.py:224-227 keeps the 0-Angstrom
+ * diagonal).  vals_in NULL = ones.  SPEKTRAL: diag += 1; PYG: existing loops kept.
+ * vals_out[e] = a~[e] * d^-1/2[row] * d^-1/2[col].  Synchronises; GCNX_ERR_DATA if a row has
+ * no stored diagonal. */
+GCNX_API int gcnx_gcn_norm(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx,
+                  const float* vals_in, int32_t n, int mode, float* vals_out);
+/* CSR of the transpose (for the backward SpMM when A^ is not symmetric).  Synchronises. */
+GCNX_API int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx,
+                       const float* vals, int32_t n, int32_t nnz, int32_t* rowptr_t,
+                       int32_t* colidx_t, float* vals_t);
+
+/* ---- forward ----------------------------------------------------------------------------- */
+/* K1 MatMul+BiasAdd (+activation): out[N,Fo] = act(X[N,Fi] * W[Fi,Fo] + bias).
+ * Replaces Dense / GCNConv.kernel / GeneralConv.kernel matmuls under gcn.py:334.
+ * bias may be NULL.  alpha[Fo] is the PReLU slope (NULL unless act == PRELU). */
+GCNX_API int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias,
+              float* out, int64_t ldo, int64_t n, int32_t fi, int32_t fo, int prec, int act,
+              const float* alpha);
+/* K2/K3 SparseTensorDenseMatMul / gather+unsorted_segment_sum:
+ * out[t,:] = act( sum_e vals[e] * h[colidx[e],:] + bias ), e over row t.
+ * GCNConv.call (bias AFTER aggregation) and GeneralConv.propagate (vals NULL).
+ * block_ptr (int32[nblocks+1], may be NULL) lists diagonal blocks of the disjoint batch
+ * (= graph_ptr): rows [block_ptr[g], block_ptr[g+1]) reference only columns of that range.
+ * It is a scheduling hint that enables the LDS-resident-tile kernel; results are identical. */
+GCNX_API int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx,
+                  const float* vals, const float* h, int64_t ldh, const float* bias, float* out,
+                  int64_t ldo, int32_t n, int32_t f, int act, const int32_t* block_ptr,
+                  int32_t nblocks);
+/* K4 SegmentSum / mean / max over sorted graph ids (GlobalSumPool, gcn.py:320 pool="sum";
+ * max variant: gcn_utills.py:842).  graph_ptr int32[B+1].  argmax int32[B*F] (row index of
+ * the maximum; required for MAX, else NULL). */
+GCNX_API int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx,
+                      float* pooled, int32_t b, int32_t f, int mode, int32_t* argmax);
+/* K8 Softmax + CategoricalCrossentropy + categorical_accuracy (gcn.py:326,335,339):
+ * probs = softmax(logits); loss_acc[0] += sum_g -sum_c y log clip(p)/ denom;
+ * loss_acc[1] += #(argmax p == argmax y); dlogits = (p*sum(y*m) - y*m)/denom with m = [1e-7 < p < 1-1e-7], the
+ * gradient of the clipped loss (= (p - y)/denom in the unclipped region; NULL to skip).
+ * denom = global batch size (so that shard gradients add up to the full-batch gradient).
+ * loss_acc is a device float[2] that the caller zeroes. */
+GCNX_API int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t b, int32_t c,
+                     float denom, float* probs, float* loss_acc, float* dlogits);
+
+/* ---- backward (what tape.gradient, gcn.py:337, generates) -------------------------------- */
+/* dZ = dY * act'(Y) (mask taken from the saved output Y; PReLU uses the saved pre-activation
+ * passed as y and alpha); db[f] = sum_rows dZ (BiasAddGrad).  dz may alias dy.  db/dalpha may
+ * be NULL.  For PRELU dalpha[f] = sum_rows dY*min(y,0). */
+GCNX_API int gcnx_act_bias_grad(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                       float* dz, int64_t lddz, int64_t n, int32_t f, int act,
+                       const float* alpha, float* db, float* dalpha);
+/* dW[Fi,Fo] = X^T[Fi,N] * dH[N,Fo]: deterministic two-stage split-K (no atomics). */
+GCNX_API int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh,
+                 float* dw, int64_t n, int32_t fi, int32_t fo, int prec);
+/* dX[N,Fi] (+)= dH[N,Fo] * W^T.  accumulate != 0 adds into dx (skip-connection gradients).
+ * y_mask (may be NULL): saved ReLU output of the layer that produced this GEMM's input; the
+ * epilogue then writes dZ = dX * (y_mask > 0), i.e. the activation gradient of that layer is
+ * fused.  db (may be NULL): column sums of what was written (BiasAddGrad of that layer). */
+GCNX_API int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx,
+                 int64_t lddx, int64_t n, int32_t fi, int32_t fo, int prec, int accumulate,
+                 const float* y_mask, int64_t ldy, float* db);
+/* Gradient of the global pool: SUM dX[r] = dP[g(r)]; AVG /n_g; MAX routed to argmax rows.
+ * If y (saved ReLU output of the last conv layer) is given its mask is fused:
+ * dX[r] *= (y[r] > 0).  db (may be NULL): column sums of dX (BiasAddGrad of that layer). */
+GCNX_API int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* dpooled,
+                          float* dx, int64_t lddx, int32_t n, int32_t b, int32_t f, int mode,
+                          const int32_t* argmax, const float* y, int64_t ldy, float* db);
+
+/* ---- optimiser --------------------------------------------------------------------------- */
+/* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
+GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (new capability) ---- */
+GCNX_API int gcnx_comm_unique_id(char id[GCNX_UNIQUE_ID_BYTES]);
+GCNX_API int gcnx_comm_init_rank(gcnx_ctx* ctx, const char id[GCNX_UNIQUE_ID_BYTES], int nranks,
+                        int rank, gcnx_comm** out);
+GCNX_API int gcnx_comm_destroy(gcnx_comm* comm);
+/* In-place all-reduce of a device fp32 buffer on the ctx stream. */
+GCNX_API int gcnx_allreduce_f32(gcnx_ctx* ctx, gcnx_comm* comm, float* buf, int64_t n, int op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCNX_H */

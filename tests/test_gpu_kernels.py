@@ -1,0 +1,307 @@
+"""GPU parity tests proper: every hot-path entry point of the C ABI (include/gcnx.h), called
+through ctypes, against the CPU oracle on the same seeded inputs.  Floating point, so the bar is
+north_star's 1e-4 relative (max|diff|/max|ref|); most kernels are held to 1e-5."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # north_star: outputs within 1e-4 relative fp32 tolerance
+TIGHT = 2e-5
+
+
+def O():
+    from oracle import gcn_oracle
+    return gcn_oracle
+
+
+def _csr(ctx, hb, weighted):
+    from gcnx import synth
+    from gcnx.device import DeviceCSR
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx) if weighted else None
+    return DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr), vals
+
+
+def _ref_spmm(hb, vals, h, bias=None, relu=False):
+    o = O()
+    out = o.spmm_csr(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64),
+                     None if vals is None else vals.astype(np.float64), h.astype(np.float64))
+    if bias is not None:
+        out = out + bias.astype(np.float64)
+    return np.maximum(out, 0) if relu else out
+
+
+@pytest.mark.parametrize("f", [4, 10, 16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_parity_widths(ctx, f, weighted):
+    from gcnx import device as D, synth
+    hb = synth.ecoli_batch(3, f, seed=f)
+    a, vals = _csr(ctx, hb, weighted)
+    rng = np.random.default_rng(f)
+    bias = rng.standard_normal(f).astype(np.float32)
+    h = ctx.to_device(hb.x)
+    out = ctx.empty((hb.n, f))
+    D.spmm(ctx, a, h, ctx.to_device(bias), out, act="relu")
+    assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x, bias, True)) < TIGHT
+    D.spmm(ctx, a, h, None, out, act=None)
+    assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT
+
+
+def test_spmm_long_rows_overflowing_the_lds_stage(ctx):
+    """config 5 shape: one 4096-entry row next to short rows (chunk > LDS staging capacity)."""
+    from gcnx import device as D, synth
+    hb = synth.power_law_batch(n_graphs=1, graph_size=8192, f=64, seed=3)
+    assert np.diff(hb.rowptr).max() == 4096
+    for weighted in (False, True):
+        a, vals = _csr(ctx, hb, weighted)
+        out = ctx.empty((hb.n, 64))
+        D.spmm(ctx, a, ctx.to_device(hb.x), None, out)
+        assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT
+
+
+def test_spmm_empty_rows_single_nodes_and_strided_views(ctx):
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR
+    # rows 0 and 3 have no entries; row 4 is a lone self-loop
+    rowptr = np.array([0, 0, 2, 3, 3, 4], np.int32)
+    colidx = np.array([0, 2, 1, 4], np.int32)
+    hb = synth.HostBatch(np.arange(40, dtype=np.float32).reshape(5, 8), rowptr, colidx, None, np.array([0, 4, 5], np.int32),
+                         np.eye(2, dtype=np.float32))
+    a = DeviceCSR.from_host_csr(ctx, rowptr, colidx, None, hb.graph_ptr)
+    out = ctx.zeros((5, 8))
+    D.spmm(ctx, a, ctx.to_device(hb.x), None, out)
+    assert np.array_equal(out.numpy(), _ref_spmm(hb, None, hb.x).astype(np.float32))
+    # column-slice views of wider buffers (Spektral's concat-skip written in place)
+    hb2 = synth.ecoli_batch(2, 32, seed=5)
+    a2, vals = _csr(ctx, hb2, True)
+    wide_in = ctx.to_device(np.concatenate([np.zeros_like(hb2.x), hb2.x], 1))       # h = cols 32..64
+    wide_out = ctx.zeros((hb2.n, 96))
+    D.spmm(ctx, a2, wide_in.cols(32, 64), None, wide_out.cols(64, 96))
+    got = wide_out.numpy()
+    assert rel_err(got[:, 64:], _ref_spmm(hb2, vals, hb2.x)) < TIGHT and not got[:, :64].any()
+
+
+def test_spmm_zero_sizes_and_argument_errors(ctx):
+    from gcnx import _lib
+    lib = ctx.lib
+    assert lib.gcnx_spmm_csr(ctx.h, None, None, None, None, 0, None, None, 0, 0, 16, 0, None, 0) == 0
+    buf = ctx.zeros((4, 4))
+    rc = lib.gcnx_spmm_csr(ctx.h, buf.ptr, buf.ptr, None, buf.ptr, 2, None, buf.ptr, 4, 4, 4, 0, None, 0)
+    assert rc == 1 and "leading dimension" in _lib.last_error(ctx.h)          # ldh < f
+    rc = lib.gcnx_spmm_csr(ctx.h, buf.ptr, buf.ptr, None, buf.ptr, 4, None, buf.ptr, 4, 4, 4, 0, None, 0)
+    assert rc == 1 and "in-place" in _lib.last_error(ctx.h)
+
+
+def test_spmm_full_size_properties(ctx):
+    """BASELINE config 3 size (1M nodes / 10M entries, F=256): size-independent properties.
+    A*1 = row degree exactly (small integers are exact in fp32); linearity A(ah1+h2) = aAh1+Ah2."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR
+    hb = synth.block_diag_batch(with_x=False)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
+    n, f = hb.n, 256
+    ones = ctx.to_device(np.ones((n, f), np.float32))
+    out = ctx.empty((n, f))
+    D.spmm(ctx, a, ones, None, out)
+    got = out.numpy()
+    deg = np.diff(hb.rowptr).astype(np.float32)
+    assert np.array_equal(got[:, 0], deg) and np.array_equal(got[:, 255], deg) and np.array_equal(got[::997].T[7], deg[::997])
+    rng = np.random.default_rng(0)
+    h1 = rng.standard_normal((n, f), dtype=np.float32); h2 = rng.standard_normal((n, f), dtype=np.float32)
+    d1, d2 = ctx.to_device(h1), ctx.to_device(h2)
+    o1, o2, o3 = ctx.empty((n, f)), ctx.empty((n, f)), ctx.empty((n, f))
+    D.spmm(ctx, a, d1, None, o1); D.spmm(ctx, a, d2, None, o2)
+    d3 = ctx.to_device(np.float32(0.5) * h1 + h2)
+    D.spmm(ctx, a, d3, None, o3)
+    lin = np.float32(0.5) * o1.numpy() + o2.numpy()
+    assert rel_err(o3.numpy(), lin) < 1e-5
+    # spot-check 2000 random rows against the oracle definition
+    rows = rng.integers(0, n, 2000)
+    ref = np.stack([h1[hb.colidx[hb.rowptr[r]:hb.rowptr[r + 1]]].astype(np.float64).sum(0) for r in rows])
+    assert rel_err(o1.numpy()[rows], ref) < TIGHT
+
+
+@pytest.mark.parametrize("n,fi,fo", [(1000, 128, 128), (77, 10, 6), (4096, 256, 256), (333, 32, 2), (65, 130, 70)])
+def test_gemm_forward_parity(ctx, n, fi, fo):
+    from gcnx import device as D
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, fi), dtype=np.float32); w = rng.standard_normal((fi, fo), dtype=np.float32) / np.sqrt(fi)
+    b = rng.standard_normal(fo).astype(np.float32); al = rng.random(fo).astype(np.float32)
+    dx, dw, db, dal = (ctx.to_device(v) for v in (x, w, b, al))
+    out = ctx.empty((n, fo))
+    z = x.astype(np.float64) @ w.astype(np.float64)
+    D.gemm(ctx, dx, dw, None, out)
+    assert rel_err(out.numpy(), z) < TIGHT
+    D.gemm(ctx, dx, dw, db, out, act="relu")
+    assert rel_err(out.numpy(), np.maximum(z + b, 0)) < TIGHT
+    D.gemm(ctx, dx, dw, db, out, act="prelu", alpha=dal)
+    zb = z + b
+    assert rel_err(out.numpy(), np.maximum(zb, 0) + al * np.minimum(zb, 0)) < TIGHT
+
+
+def test_gemm_backward_parity_and_fusions(ctx):
+    from gcnx import device as D
+    rng = np.random.default_rng(1)
+    for n, fi, fo in ((3000, 128, 128), (50000, 64, 96), (129, 10, 6)):
+        x = rng.standard_normal((n, fi), dtype=np.float32); dh = rng.standard_normal((n, fo), dtype=np.float32)
+        w = rng.standard_normal((fi, fo), dtype=np.float32); ymask = rng.standard_normal((n, fi), dtype=np.float32)
+        d_x, d_dh, d_w, d_m = (ctx.to_device(v) for v in (x, dh, w, ymask))
+        dw = ctx.empty((fi, fo))
+        D.gemm_dw(ctx, d_x, d_dh, dw)                                     # split-K over the N rows
+        assert rel_err(dw.numpy(), x.astype(np.float64).T @ dh.astype(np.float64)) < TIGHT
+        dx = ctx.empty((n, fi)); db = ctx.empty(fi)
+        ref = dh.astype(np.float64) @ w.astype(np.float64).T
+        D.gemm_dx(ctx, d_dh, d_w, dx)
+        assert rel_err(dx.numpy(), ref) < TIGHT
+        D.gemm_dx(ctx, d_dh, d_w, dx, y_mask=d_m, db=db)                  # fused ReLU mask + BiasAddGrad
+        refm = ref * (ymask > 0)
+        assert rel_err(dx.numpy(), refm) < TIGHT and rel_err(db.numpy(), refm.sum(0)) < TIGHT
+        base = rng.standard_normal((n, fi), dtype=np.float32)
+        acc = ctx.to_device(base)
+        D.gemm_dx(ctx, d_dh, d_w, acc, accumulate=True)                   # skip-connection gradient add
+        assert rel_err(acc.numpy(), ref + base) < TIGHT
+    # split-K is deterministic: two runs are bitwise identical
+    a1 = ctx.empty((64, 96)); a2 = ctx.empty((64, 96))
+    D.gemm_dw(ctx, d_x, d_dh, dw)
+    x = rng.standard_normal((50000, 64), dtype=np.float32); dh = rng.standard_normal((50000, 96), dtype=np.float32)
+    d_x, d_dh = ctx.to_device(x), ctx.to_device(dh)
+    D.gemm_dw(ctx, d_x, d_dh, a1); D.gemm_dw(ctx, d_x, d_dh, a2)
+    assert np.array_equal(a1.numpy(), a2.numpy())
+
+
+def test_gemm_unbuilt_precision_fails_loudly(ctx):
+    from gcnx import _lib, device as D
+    x = ctx.zeros((8, 8)); out = ctx.zeros((8, 8))
+    try:
+        D.gemm(ctx, x, x, None, out, prec="bf16x3")
+    except _lib.GcnxError as e:      # allowed until the bf16 kernels land: must not silently fall back
+        assert e.code == 5
+
+
+@pytest.mark.parametrize("mode", ["sum", "avg", "max"])
+def test_segment_pool_forward_backward(ctx, mode):
+    from gcnx import device as D
+    from gcnx.device import Segments
+    o = O()
+    rng = np.random.default_rng(3)
+    sizes = [1, 700, 33, 2, 257]
+    gp = np.concatenate([[0], np.cumsum(sizes)])
+    n, f = int(gp[-1]), 70
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    x[5:9, 3] = x[5:9, 3].max() + 1.0        # a tie inside graph 1: first maximal row must win
+    seg = Segments(ctx, gp)
+    pooled = ctx.empty((5, f)); arg = ctx.empty((5, f), np.int32) if mode == "max" else None
+    D.segment_pool(ctx, seg, ctx.to_device(x), pooled, mode, arg)
+    ref, rarg = o.global_pool_fwd(x.astype(np.float64), gp, mode)
+    assert rel_err(pooled.numpy(), ref) < TIGHT
+    if mode == "max":
+        assert np.array_equal(arg.numpy(), rarg)
+    dp = rng.standard_normal((5, f), dtype=np.float32)
+    y = rng.standard_normal((n, f), dtype=np.float32)
+    dx = ctx.empty((n, f)); db = ctx.empty(f)
+    D.segment_pool_bwd(ctx, seg, ctx.to_device(dp), dx, mode, arg)
+    rdx = o.global_pool_bwd(dp.astype(np.float64), gp, n, mode, rarg)
+    assert rel_err(dx.numpy(), rdx) < TIGHT
+    D.segment_pool_bwd(ctx, seg, ctx.to_device(dp), dx, mode, arg, y=ctx.to_device(y), db=db)   # fused mask + db
+    rm = rdx * (y > 0)
+    assert rel_err(dx.numpy(), rm) < TIGHT and rel_err(db.numpy(), rm.sum(0)) < TIGHT
+
+
+def test_softmax_cce_matches_keras_semantics(ctx):
+    from gcnx import device as D
+    o = O()
+    rng = np.random.default_rng(4)
+    b, c = 1000, 2
+    logits = (4 * rng.standard_normal((b, c))).astype(np.float32)
+    logits[0] = [40.0, -40.0]; logits[1] = [-40.0, 40.0]            # saturated: exercises the clip
+    y = np.eye(c, dtype=np.float32)[rng.integers(0, c, b)]; y[0] = [1, 0]; y[1] = [1, 0]
+    probs = ctx.empty((b, c)); la = ctx.zeros(2); dl = ctx.empty((b, c))
+    D.softmax_cce(ctx, ctx.to_device(logits), ctx.to_device(y), probs, la, dl, denom=b)
+    p = o.softmax(logits.astype(np.float64))
+    assert rel_err(probs.numpy(), p) < TIGHT
+    loss, hits = la.numpy()
+    assert abs(loss - o.cce_loss(y.astype(np.float64), p)) < 1e-5 * max(1, loss)
+    assert hits == round(o.categorical_accuracy(y, p) * b)
+    assert rel_err(dl.numpy(), o.softmax_cce_grad(y.astype(np.float64), p)) < TIGHT
+    # shard semantics: denom = global batch
+    la.fill_zero()
+    D.softmax_cce(ctx, ctx.to_device(logits[:10]), ctx.to_device(y[:10]), ctx.empty((10, c)), la, None, denom=40)
+    assert abs(la.numpy()[0] - o.cce_loss(y[:10].astype(np.float64), p[:10], denom=40)) < 1e-5
+
+
+@pytest.mark.parametrize("act", [None, "relu", "prelu"])
+def test_act_bias_grad(ctx, act):
+    from gcnx import device as D
+    o = O()
+    rng = np.random.default_rng(6)
+    n, f = 5000, 96
+    dy = rng.standard_normal((n, f), dtype=np.float32); y = rng.standard_normal((n, f), dtype=np.float32)
+    al = rng.random(f).astype(np.float32)
+    dz = ctx.empty((n, f)); db = ctx.empty(f); dal = ctx.empty(f)
+    D.act_bias_grad(ctx, ctx.to_device(dy), ctx.to_device(y), dz, act, db=db,
+                    alpha=ctx.to_device(al) if act == "prelu" else None, dalpha=dal if act == "prelu" else None)
+    ref = o.act_bwd(dy.astype(np.float64), y.astype(np.float64), act, al.astype(np.float64))
+    assert rel_err(dz.numpy(), ref) < TIGHT and rel_err(db.numpy(), ref.sum(0)) < TIGHT
+    if act == "prelu":
+        assert rel_err(dal.numpy(), (dy.astype(np.float64) * np.minimum(y, 0)).sum(0)) < TIGHT
+
+
+def test_graph_prep_coo_to_csr_norm_transpose(ctx):
+    from gcnx import _lib, synth
+    from gcnx.device import DeviceCSR
+    o = O()
+    hb = synth.ecoli_batch(3, 4, seed=8)
+    idx = hb.indices()
+    a = DeviceCSR.from_coo(ctx, idx, np.ones(len(idx)), hb.n, graph_ptr=hb.graph_ptr)
+    assert np.array_equal(a.rowptr.numpy(), hb.rowptr) and np.array_equal(a.colidx.numpy()[:hb.nnz], hb.colidx)
+    an = a.unweighted().gcn_norm("spektral")
+    ref = o.gcn_filter_csr(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None, "spektral")
+    assert rel_err(an.vals.numpy()[:hb.nnz], ref) < 1e-6
+    ap = a.unweighted().gcn_norm("pyg")
+    assert rel_err(ap.vals.numpy()[:hb.nnz], o.gcn_filter_csr(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None, "pyg")) < 1e-6
+    # empty rows in the COO (isolated nodes) and an empty matrix
+    idx2 = np.array([[1, 1], [1, 3], [4, 0]], np.int64)
+    a2 = DeviceCSR.from_coo(ctx, idx2, None, 6)
+    assert np.array_equal(a2.rowptr.numpy(), [0, 0, 2, 2, 2, 3, 3])
+    a0 = DeviceCSR.from_coo(ctx, np.zeros((0, 2), np.int64), None, 3)
+    assert np.array_equal(a0.rowptr.numpy(), [0, 0, 0, 0])
+    # unsorted rows / out-of-range indices are rejected (GCNX_ERR_DATA), not mis-converted
+    with pytest.raises(_lib.GcnxError) as e:
+        DeviceCSR.from_coo(ctx, idx2[::-1].copy(), None, 6)
+    assert e.value.code == 6
+    with pytest.raises(_lib.GcnxError):
+        DeviceCSR.from_coo(ctx, np.array([[0, 9]], np.int64), None, 6)
+    with pytest.raises(_lib.GcnxError, match="diagonal"):
+        a2.gcn_norm()
+    # transpose of an asymmetric weighted matrix
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.integers(0, 50, 400)); cols = rng.integers(0, 50, 400)
+    key = np.unique(rows * 50 + cols); rows, cols = key // 50, key % 50
+    vals = rng.random(len(key)).astype(np.float32)
+    rp = np.zeros(51, np.int32); np.cumsum(np.bincount(rows, minlength=50), out=rp[1:])
+    at = DeviceCSR.from_host_csr(ctx, rp, cols.astype(np.int32), vals, symmetric=False).transpose()
+    trp, tci, tv = o.csr_transpose(rp.astype(np.int64), cols, vals)
+    assert np.array_equal(at.rowptr.numpy(), trp) and np.array_equal(at.colidx.numpy(), tci) and np.array_equal(at.vals.numpy(), tv)
+
+
+def test_sgd_and_graph_capture_replay(ctx):
+    from gcnx import device as D
+    rng = np.random.default_rng(2)
+    p = rng.standard_normal(100003).astype(np.float32); g = rng.standard_normal(100003).astype(np.float32)
+    dp, dg = ctx.to_device(p), ctx.to_device(g)
+    D.sgd(ctx, dp, dg, 0.02)
+    assert np.array_equal(dp.numpy(), p - np.float32(0.02) * g)
+    graph = ctx.capture(lambda: D.sgd(ctx, dp, dg, 0.02))      # captured, not yet executed
+    graph.launch(); graph.launch(); ctx.sync()
+    ref = p - np.float32(0.02) * g
+    ref = ref - np.float32(0.02) * g; ref = ref - np.float32(0.02) * g
+    assert np.array_equal(dp.numpy(), ref)
+    graph.destroy()
+    t0, t1 = ctx.event().record(), None
+    D.sgd(ctx, dp, dg, 0.0)
+    t1 = ctx.event().record()
+    assert t1.elapsed_ms_since(t0) >= 0.0
+    info = ctx.info()
+    assert info["arch"].startswith("gfx950") and info["cus"] >= 200

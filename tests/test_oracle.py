@@ -1,0 +1,262 @@
+"""CPU tests of the oracle itself (PARITY UNPINNED -- see oracle/gcn_oracle.py): the numpy
+restatement against scipy / torch-CPU autograd / finite differences, the committed goldens,
+and the C restatement against the numpy one."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_batch, load_golden, rel_err
+from oracle import gcn_oracle as O
+
+
+def _rand_csr(rng, n, p=0.1, self_loops=True, symmetric=True):
+    a = rng.random((n, n)) < p
+    if symmetric:
+        a = np.triu(a, 1); a = a | a.T
+    if self_loops:
+        a = a | np.eye(n, dtype=bool)
+    else:
+        a = a & ~np.eye(n, dtype=bool)
+    rows, cols = np.nonzero(a)
+    rowptr = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+    return rowptr, cols.astype(np.int64)
+
+
+def test_spmm_matches_scipy_weighted_and_unweighted():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    rowptr, colidx = _rand_csr(rng, 120)
+    h = rng.standard_normal((120, 24))
+    vals = rng.random(len(colidx))
+    for v in (None, vals):
+        a = sp.csr_matrix((np.ones(len(colidx)) if v is None else v, colidx, rowptr), shape=(120, 120))
+        assert rel_err(O.spmm_csr(rowptr, colidx, v, h), a @ h) < 1e-13
+        assert rel_err(O.spmm_csr_T(rowptr, colidx, v, h), a.T @ h) < 1e-13
+        tr, tc, tv = O.csr_transpose(rowptr, colidx, v)
+        assert rel_err(O.spmm_csr(tr, tc, tv, h), a.T @ h) < 1e-13
+
+
+def test_gcn_filter_spektral_adds_identity_unconditionally():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1)
+    rowptr, colidx = _rand_csr(rng, 40, 0.2, self_loops=True)
+    v = O.gcn_filter_csr(rowptr, colidx, None, "spektral")
+    a = sp.csr_matrix((np.ones(len(colidx)), colidx, rowptr), shape=(40, 40)).toarray()
+    at = a + np.eye(40)                         # diagonal becomes 2
+    d = at.sum(1) ** -0.5
+    dense = d[:, None] * at * d[None, :]
+    rows = np.repeat(np.arange(40), np.diff(rowptr))
+    assert np.allclose(v, dense[rows, colidx], rtol=1e-13)
+    assert np.allclose(O.gcn_filter_scipy(sp.csr_matrix(a)).toarray(), dense, rtol=1e-13)
+    # PyG flavour keeps existing loops at weight 1
+    vp = O.gcn_filter_csr(rowptr, colidx, None, "pyg")
+    dp = a.sum(1) ** -0.5
+    assert np.allclose(vp, (dp[:, None] * a * dp[None, :])[rows, colidx], rtol=1e-13)
+
+
+def test_disjoint_collate_layout():
+    from gcnx import synth
+    graphs = synth.tiny_graphs(5, 8, seed=3)
+    x, (idx, val, shape), i, y = O.disjoint_collate(graphs)
+    n = sum(g[0].shape[0] for g in graphs)
+    assert x.shape == (n, 8) and shape == (n, n) and y.shape == (5, 2)
+    assert idx.dtype == np.int64 and i.dtype == np.int64
+    key = idx[:, 0] * n + idx[:, 1]
+    assert np.all(np.diff(key) > 0)                                   # row-major, unique
+    assert np.array_equal(i, np.repeat(np.arange(5), [g[0].shape[0] for g in graphs]))
+    assert np.all(i[idx[:, 0]] == i[idx[:, 1]])                       # block diagonal
+    off = 0
+    for g in graphs:                                                  # every block equals its graph
+        m = g[0].shape[0]
+        sel = (idx[:, 0] >= off) & (idx[:, 0] < off + m)
+        dense = np.zeros((m, m)); dense[idx[sel, 0] - off, idx[sel, 1] - off] = val[sel]
+        assert np.array_equal(dense, g[1].toarray())
+        off += m
+
+
+@pytest.mark.parametrize("pool", ["sum", "avg", "max"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gcn2_gradients_match_torch_autograd(pool, weighted):
+    import torch
+    rng = np.random.default_rng(5)
+    sizes = [7, 1, 12, 5]
+    n = sum(sizes)
+    gp = np.concatenate([[0], np.cumsum(sizes)])
+    blocks = []
+    import scipy.sparse as sp
+    for s in sizes:
+        rp, ci = _rand_csr(rng, s, 0.4)
+        blocks.append(sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(s, s)))
+    a = sp.block_diag(blocks).tocsr(); a.sort_indices()
+    rowptr, colidx = a.indptr.astype(np.int64), a.indices.astype(np.int64)
+    vals = O.gcn_filter_csr(rowptr, colidx, None) if weighted else None
+    x = 0.3 * rng.standard_normal((n, 6))
+    y = np.eye(2)[rng.integers(0, 2, len(sizes))]
+    params = O.gcn2_init(rng, 6, 5, 2)
+    for k in ("b1", "b2", "b3"):
+        params[k] = 0.1 * rng.standard_normal(params[k].shape)
+    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, x, (rowptr, colidx, vals), gp, y, pool)
+
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    at = torch.sparse_coo_tensor(np.stack([rows, colidx]),
+                                 torch.tensor(np.ones(len(colidx)) if vals is None else vals), (n, n)).coalesce()
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+    y1 = torch.relu(torch.sparse.mm(at, torch.tensor(x) @ tp["w1"]) + tp["b1"])
+    y2 = torch.relu(torch.sparse.mm(at, y1 @ tp["w2"]) + tp["b2"])
+    segs = [y2[gp[g]:gp[g + 1]] for g in range(len(sizes))]
+    pooled = torch.stack([s.sum(0) if pool == "sum" else s.mean(0) if pool == "avg" else s.max(0).values for s in segs])
+    probs = torch.softmax(pooled @ tp["w3"] + tp["b3"], 1)
+    tl = -(torch.tensor(y) * torch.log(torch.clamp(probs, 1e-7, 1 - 1e-7))).sum(1).mean()
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-12
+    for k in grads:
+        assert rel_err(grads[k], tp[k].grad.numpy()) < 1e-11, k
+    # sharding identity: shard losses/grads normalised by the GLOBAL batch add up
+    tot = {k: 0.0 for k in grads}; ltot = 0.0
+    for g0, g1 in ((0, 2), (2, 4)):
+        r0, r1 = gp[g0], gp[g1]
+        e0, e1 = rowptr[r0], rowptr[r1]
+        csr_s = (rowptr[r0:r1 + 1] - e0, colidx[e0:e1] - r0, None if vals is None else vals[e0:e1])
+        l_s, _, g_s, _ = O.gcn2_loss_and_grads(params, x[r0:r1], csr_s, gp[g0:g1 + 1] - r0, y[g0:g1], pool, denom=len(sizes))
+        ltot += l_s
+        for k in g_s:
+            tot[k] = tot[k] + g_s[k]
+    assert abs(ltot - loss) < 1e-12
+    for k in grads:
+        assert rel_err(tot[k], grads[k]) < 1e-12, k
+
+
+def test_finite_difference_gradcheck_gcnconv():
+    rng = np.random.default_rng(9)
+    rowptr, colidx = _rand_csr(rng, 15, 0.3)
+    vals = O.gcn_filter_csr(rowptr, colidx, None)
+    x = rng.standard_normal((15, 4)); w = rng.standard_normal((4, 3)); b = 0.1 * rng.standard_normal(3)
+    r = rng.standard_normal((15, 3))
+
+    def f(w_, b_, x_):
+        return float((O.gcn_conv_fwd(x_, (rowptr, colidx, vals), w_, b_, "relu")[0] * r).sum())
+    yv, cache = O.gcn_conv_fwd(x, (rowptr, colidx, vals), w, b, "relu")
+    dx, dw, db = O.gcn_conv_bwd(r, cache, (rowptr, colidx, vals), w, "relu")
+    eps = 1e-6
+    for arr, grad, which in ((w, dw, 0), (b, db, 1), (x, dx, 2)):
+        num = np.zeros_like(arr)
+        it = np.nditer(arr, flags=["multi_index"])
+        for _ in it:
+            i = it.multi_index
+            p, m = arr.copy(), arr.copy(); p[i] += eps; m[i] -= eps
+            args = [w, b, x]; args[which] = p; fp = f(*args); args[which] = m; fm = f(*args)
+            num[i] = (fp - fm) / (2 * eps)
+        assert rel_err(grad, num) < 1e-6
+
+
+def test_general_gnn_gradients_match_torch_autograd():
+    """n1 tier (GeneralGNN-complete): BN(train) + PReLU + concat-skip + sum-aggregation."""
+    import torch
+    rng = np.random.default_rng(2)
+    sizes = [6, 9, 4]
+    n = sum(sizes); gp = np.concatenate([[0], np.cumsum(sizes)])
+    import scipy.sparse as sp
+    blocks = []
+    for s in sizes:
+        rp, ci = _rand_csr(rng, s, 0.4)
+        blocks.append(sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(s, s)))
+    a = sp.block_diag(blocks).tocsr(); a.sort_indices()
+    rowptr, colidx = a.indptr.astype(np.int64), a.indices.astype(np.int64)
+    x = rng.standard_normal((n, 5)); y = np.eye(2)[rng.integers(0, 2, 3)]
+    layers = O.general_gnn_init(rng, 5, 2, hidden=8, message_passing=2, pre=2, post=2)
+    for grp in layers.values():
+        for p in grp:
+            if "alpha" in p:
+                p["alpha"] = 0.25 * rng.random(p["alpha"].shape)
+            p["gamma"] = 1 + 0.1 * rng.standard_normal(p["gamma"].shape)
+            p["beta"] = 0.1 * rng.standard_normal(p["beta"].shape)
+            p["bias"] = 0.1 * rng.standard_normal(p["bias"].shape)
+    loss, acc, grads, probs, stats = O.general_gnn_loss_and_grads(layers, x, (rowptr, colidx, None), gp, y)
+
+    T = lambda v: torch.tensor(v, requires_grad=True)
+    tl = {g: [{k: T(v) for k, v in p.items() if not k.startswith("moving")} for p in ps] for g, ps in layers.items()}
+    at = torch.tensor(a.toarray())
+
+    def block(h, p, final=False):
+        z = h @ p["kernel"] + p["bias"]
+        mu, var = z.mean(0), z.var(0, unbiased=False)
+        zb = p["gamma"] * (z - mu) / torch.sqrt(var + 1e-3) + p["beta"]
+        if final:
+            return torch.softmax(zb, 1)
+        return torch.relu(zb) + p["alpha"] * torch.minimum(zb, torch.zeros_like(zb))
+    out = torch.tensor(x)
+    for p in tl["pre"]:
+        out = block(out, p)
+    for p in tl["gnn"]:
+        out = torch.cat([at @ block(out, p), out], 1)
+    out = torch.stack([out[gp[g]:gp[g + 1]].sum(0) for g in range(3)])
+    out = block(out, tl["post"][0]); pr = block(out, tl["post"][1], final=True)
+    tloss = -(torch.tensor(y) * torch.log(torch.clamp(pr, 1e-7, 1 - 1e-7))).sum(1).mean()
+    tloss.backward()
+    assert abs(loss - tloss.item()) < 1e-12 and rel_err(probs, pr.detach().numpy()) < 1e-12
+    for grp in grads:
+        for k, g in enumerate(grads[grp]):
+            for name, val in g.items():
+                ref = tl[grp][k][name].grad.numpy()   # Dense bias under BN has an exactly-zero gradient
+                assert np.allclose(val, ref, rtol=1e-9, atol=1e-13), (grp, k, name)
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_numpy_oracle_reproduces_goldens(name):
+    g = load_golden(name)
+    hb = golden_batch(g)
+    params = {k: g["p_" + k].astype(np.float64) for k in O.GCN2_PARAM_ORDER}
+    vals = None if hb.vals is None else hb.vals.astype(np.float64)
+    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, hb.x.astype(np.float64),
+                                                    (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals),
+                                                    hb.graph_ptr, hb.y.astype(np.float64), str(g["pool"]))
+    assert abs(loss - float(g["loss"])) < 1e-12 * max(1.0, abs(loss))
+    assert acc == float(g["acc"])
+    assert rel_err(cache["probs"], g["probs"]) < 1e-12
+    assert rel_err(cache["y2"], g["y2"]) < 1e-6          # goldens store activations in fp32
+    for k in O.GCN2_PARAM_ORDER:
+        assert rel_err(grads[k], g["g_" + k]) < 1e-6, k
+
+
+@pytest.mark.parametrize("name", [n for n in GOLDEN if "max" not in n and "avg" not in n])
+def test_c_oracle_matches_goldens_fp32(name):
+    """The fp32 C restatement (sum pool, symmetric adjacency) against the fp64 goldens at the
+    1e-4 bar the GPU path is held to."""
+    from oracle import c_oracle
+    g = load_golden(name)
+    hb = golden_batch(g)
+    flat = np.concatenate([g["p_" + k].ravel() for k in O.GCN2_PARAM_ORDER]).astype(np.float32)
+    m = c_oracle.Gcn2Cpu(hb, g["p_w1"].shape[1], 2, flat)
+    loss, acc = m.step(lr=0.0)
+    assert abs(loss - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert acc == pytest.approx(float(g["acc"]))
+    off = 0
+    for k in O.GCN2_PARAM_ORDER:
+        n = g["g_" + k].size
+        assert rel_err(m.grads[off:off + n].reshape(g["g_" + k].shape), g["g_" + k]) < 1e-4, k
+        off += n
+    # SGD apply (gcn.py:338)
+    m2 = c_oracle.Gcn2Cpu(hb, g["p_w1"].shape[1], 2, flat)
+    m2.step(lr=float(g["lr"]))
+    assert np.allclose(m2.params, flat - float(g["lr"]) * m2.grads, rtol=0, atol=1e-7)
+
+
+def test_c_oracle_kernels_match_numpy():
+    from oracle import c_oracle
+    rng = np.random.default_rng(4)
+    rowptr, colidx = _rand_csr(rng, 200, 0.05)
+    vals = O.gcn_filter_csr(rowptr, colidx, None).astype(np.float32)
+    h = rng.standard_normal((200, 20)).astype(np.float32)
+    b = rng.standard_normal(20).astype(np.float32)
+    ref = np.maximum(O.spmm_csr(rowptr, colidx, vals.astype(np.float64), h.astype(np.float64)) + b, 0)
+    out = c_oracle.spmm_csr(rowptr.astype(np.int32), colidx.astype(np.int32), vals, h, b, relu=True)
+    assert rel_err(out, ref) < 1e-6
+    w = rng.standard_normal((20, 12)).astype(np.float32)
+    assert rel_err(c_oracle.gemm(h, w), h.astype(np.float64) @ w.astype(np.float64)) < 1e-6
+
+
+def test_lr_schedule_and_losses():
+    # PiecewiseConstantDecay indexed by optimizer step, epochs=5 -> boundaries [0, 1] (gcn.py:321-324)
+    assert [O.piecewise_lr(s, 5) for s in (0, 1, 2, 100)] == [0.02, 0.002, 0.0002, 0.0002]
+    p = np.array([[1.0, 0.0], [0.5, 0.5]]); y = np.array([[1.0, 0.0], [0.0, 1.0]])
+    assert np.isclose(O.cce_loss(y, p), (-np.log(1 - 1e-7) - np.log(0.5)) / 2)      # clip at 1-1e-7
+    assert O.categorical_accuracy(y, np.array([[0.9, 0.1], [0.8, 0.2]])) == 0.5
