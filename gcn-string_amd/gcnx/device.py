@@ -280,14 +280,20 @@ class Segments:
 # ------------------------------------------------------------------------------------------- #
 
 def _p(a):
-    return None if a is None else a.ptr
+    """Device pointer of an fp32 operand (or None).  A float64 upload would be silently
+    reinterpreted by the kernels, so the dtype is checked here, at the boundary."""
+    if a is None:
+        return None
+    if a.dtype != np.float32 and a.dtype != np.int32:
+        raise TypeError(f"libgcnx operands are float32/int32, got {a.dtype}")
+    return a.ptr
 
 
 def gemm(ctx, x, w, bias, out, act=None, prec="f32", alpha=None):
     n, fi = x.shape
     fo = w.shape[1]
     assert w.shape[0] == fi and out.shape == (n, fo)
-    ctx._ck(ctx.lib.gcnx_gemm(ctx.h, x.ptr, x.ld, w.ptr, _p(bias), out.ptr, out.ld, n, fi, fo, L.PRECS[prec],
+    ctx._ck(ctx.lib.gcnx_gemm(ctx.h, _p(x), x.ld, _p(w), _p(bias), _p(out), out.ld, n, fi, fo, L.PRECS[prec],
                               L.ACTS[act], _p(alpha)))
     return out
 
@@ -295,33 +301,33 @@ def gemm(ctx, x, w, bias, out, act=None, prec="f32", alpha=None):
 def spmm(ctx, a, h, bias, out, act=None):
     n, f = h.shape
     assert a.n == n and out.shape == (n, f)
-    ctx._ck(ctx.lib.gcnx_spmm_csr(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), h.ptr, h.ld, _p(bias), out.ptr,
+    ctx._ck(ctx.lib.gcnx_spmm_csr(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(h), h.ld, _p(bias), _p(out),
                                   out.ld, n, f, L.ACTS[act], _p(a.block_ptr), a.n_blocks))
     return out
 
 
 def segment_pool(ctx, seg, x, pooled, mode="sum", argmax=None):
-    ctx._ck(ctx.lib.gcnx_segment_pool(ctx.h, seg.dev.ptr, x.ptr, x.ld, pooled.ptr, seg.n_graphs, x.shape[1],
+    ctx._ck(ctx.lib.gcnx_segment_pool(ctx.h, seg.dev.ptr, _p(x), x.ld, _p(pooled), seg.n_graphs, x.shape[1],
                                       L.POOLS[mode], _p(argmax)))
     return pooled
 
 
 def segment_pool_bwd(ctx, seg, dpooled, dx, mode="sum", argmax=None, y=None, db=None):
     n, f = dx.shape
-    ctx._ck(ctx.lib.gcnx_segment_pool_bwd(ctx.h, seg.dev.ptr, dpooled.ptr, dx.ptr, dx.ld, n, seg.n_graphs, f,
+    ctx._ck(ctx.lib.gcnx_segment_pool_bwd(ctx.h, seg.dev.ptr, _p(dpooled), _p(dx), dx.ld, n, seg.n_graphs, f,
                                           L.POOLS[mode], _p(argmax), _p(y), y.ld if y is not None else 0, _p(db)))
     return dx
 
 
 def softmax_cce(ctx, logits, y, probs, loss_acc, dlogits=None, denom=None):
     b, c = logits.shape
-    ctx._ck(ctx.lib.gcnx_softmax_cce(ctx.h, logits.ptr, y.ptr, b, c, float(denom if denom else b), probs.ptr,
-                                     loss_acc.ptr, _p(dlogits)))
+    ctx._ck(ctx.lib.gcnx_softmax_cce(ctx.h, _p(logits), _p(y), b, c, float(denom if denom else b), _p(probs),
+                                     _p(loss_acc), _p(dlogits)))
 
 
 def act_bias_grad(ctx, dy, y, dz, act, db=None, alpha=None, dalpha=None):
     n, f = dy.shape
-    ctx._ck(ctx.lib.gcnx_act_bias_grad(ctx.h, dy.ptr, dy.ld, _p(y), y.ld if y is not None else 0, dz.ptr, dz.ld, n,
+    ctx._ck(ctx.lib.gcnx_act_bias_grad(ctx.h, _p(dy), dy.ld, _p(y), y.ld if y is not None else 0, _p(dz), dz.ld, n,
                                        f, L.ACTS[act], _p(alpha), _p(db), _p(dalpha)))
     return dz
 
@@ -330,7 +336,7 @@ def gemm_dw(ctx, x, dh, dw, prec="f32"):
     n, fi = x.shape
     fo = dh.shape[1]
     assert dh.shape[0] == n and dw.shape == (fi, fo) and dw.contiguous
-    ctx._ck(ctx.lib.gcnx_gemm_dw(ctx.h, x.ptr, x.ld, dh.ptr, dh.ld, dw.ptr, n, fi, fo, L.PRECS[prec]))
+    ctx._ck(ctx.lib.gcnx_gemm_dw(ctx.h, _p(x), x.ld, _p(dh), dh.ld, _p(dw), n, fi, fo, L.PRECS[prec]))
     return dw
 
 
@@ -338,10 +344,10 @@ def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
     n, fo = dh.shape
     fi = w.shape[0]
     assert w.shape[1] == fo and dx.shape == (n, fi)
-    ctx._ck(ctx.lib.gcnx_gemm_dx(ctx.h, dh.ptr, dh.ld, w.ptr, dx.ptr, dx.ld, n, fi, fo, L.PRECS[prec],
+    ctx._ck(ctx.lib.gcnx_gemm_dx(ctx.h, _p(dh), dh.ld, _p(w), _p(dx), dx.ld, n, fi, fo, L.PRECS[prec],
                                  1 if accumulate else 0, _p(y_mask), y_mask.ld if y_mask is not None else 0, _p(db)))
     return dx
 
 
 def sgd(ctx, params, grads, lr):
-    ctx._ck(ctx.lib.gcnx_sgd(ctx.h, params.ptr, grads.ptr, params.size, float(lr)))
+    ctx._ck(ctx.lib.gcnx_sgd(ctx.h, _p(params), _p(grads), params.size, float(lr)))

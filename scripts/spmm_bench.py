@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""SpMM-only microbenchmark (tuning aid): one process, interleaved variants, HIP-event timing.
+    python scripts/spmm_bench.py [--workload block1m|ecoli|powerlaw] [--iters 20] [--slabs 256,128,64]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gcn-string_amd"))
+import numpy as np
+import gcnx
+from gcnx import device as D, synth
+from gcnx.device import DeviceCSR
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="block1m")
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--slabs", default="0")
+ap.add_argument("--unweighted", action="store_true")
+args = ap.parse_args()
+if args.workload == "block1m":
+    hb = synth.block_diag_batch(with_x=False); f = 256
+elif args.workload == "ecoli":
+    hb = synth.ecoli_batch(); f = 128
+else:
+    hb = synth.power_law_batch(with_x=False); f = 256
+vals = None if args.unweighted else synth.gcn_norm_host(hb.rowptr, hb.colidx)
+ctx = gcnx.Context(0)
+a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+h = ctx.to_device(np.random.default_rng(0).standard_normal((hb.n, f), dtype=np.float32))
+out = ctx.empty((hb.n, f)); bias = ctx.zeros(f)
+alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, f, vals is not None)
+print(f"N={hb.n} nnz={hb.nnz} F={f} alg={alg/1e6:.1f} MB")
+for rnd in range(args.rounds):
+    for slab in args.slabs.split(","):
+        for k_ in ("GCNX_SPMM_SLAB", "GCNX_SPMM_KERNEL", "GCNX_SPMM_THREADS", "GCNX_SPMM_LDS_KB", "GCNX_SPMM_ABLATE"): os.environ.pop(k_, None)
+        if slab.startswith("t"):      # e.g. t1024 or t512k64 : block kernel, threads [, LDS KiB]
+            body_, _, ab_ = slab[1:].partition("a")
+            if ab_: os.environ["GCNX_SPMM_ABLATE"] = ab_
+            t_, _, kb_ = body_.partition("k")
+            os.environ["GCNX_SPMM_THREADS"] = t_
+            if kb_: os.environ["GCNX_SPMM_LDS_KB"] = kb_
+            slab_ = "0"
+        else:
+            slab_ = slab
+        if slab_ == "rows": os.environ["GCNX_SPMM_KERNEL"] = "rows"
+        elif slab_ != "0": os.environ["GCNX_SPMM_SLAB"] = slab_; os.environ["GCNX_SPMM_KERNEL"] = "rows"
+        for _ in range(3): D.spmm(ctx, a, h, bias, out, act="relu")
+        e0 = ctx.event().record()
+        for _ in range(args.iters): D.spmm(ctx, a, h, bias, out, act="relu")
+        e1 = ctx.event().record()
+        ms = e1.elapsed_ms_since(e0) / args.iters
+        print(f"round {rnd} slab {slab:>8}: {ms*1e3:9.1f} us  {alg/ms/1e6:8.1f} GB/s  frac {alg/ms/1e6/8000:.3f}", flush=True)
+ctx.close()
