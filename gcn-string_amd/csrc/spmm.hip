@@ -28,13 +28,17 @@
 // __shfl_xor at the end.  Chunk ids are remapped so each XCD (private 4 MiB L2) walks one
 // contiguous range of rows: in a disjoint (block-diagonal) batch the rows a chunk gathers lie
 // in the same graph, hence in the same L2.
+#include <algorithm>
 #include <cstdlib>
+#include <new>
+#include <vector>
 
 #include "common.h"
 
 namespace {
 
-constexpr int kRowsPerChunk = 32;    // rows per workgroup
+constexpr int kRowsPerChunk = 32;    // rows per workgroup (large inputs; plan chunks)
+constexpr int kRowsPerChunkSmall = 8;   // small inputs: more, shorter workgroups (launch-latency regime)
 constexpr int kStageCap = 2048;      // CSR entries staged in LDS per chunk (overflow -> global)
 
 __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
@@ -43,22 +47,23 @@ __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
 }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-template <int LPR, bool WEIGHTED>
+template <int LPR, bool WEIGHTED, int RPC>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx,
                                                         const float* __restrict__ vals,
                                                         const float* __restrict__ h, int64_t ldh,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int64_t ldo, int32_t n, int32_t f, int32_t col0, int act,
-                                                        int nchunks) {
+                                                        int nchunks, const int2* __restrict__ chunk_list) {
   constexpr int G = 64 / LPR;  // neighbour groups per wave
   __shared__ int32_t s_col[kStageCap];
   __shared__ float s_val[WEIGHTED ? kStageCap : 1];
-  __shared__ int32_t s_rp[kRowsPerChunk + 1];
+  __shared__ int32_t s_rp[RPC + 1];
 
   const int chunk = gcnx_xcd_remap(blockIdx.x, nchunks);
-  const int r0 = chunk * kRowsPerChunk;
-  const int r1 = min(n, r0 + kRowsPerChunk);
+  int r0 = chunk * RPC;
+  int r1 = min(n, r0 + RPC);
+  if (chunk_list) { r0 = chunk_list[chunk].x; r1 = chunk_list[chunk].y; }   // row ranges picked by a plan
   const int tid = threadIdx.x;
   if (tid <= r1 - r0) s_rp[tid] = rowptr[r0 + tid];
   const int e0 = rowptr[r0];
@@ -114,11 +119,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
 }
 
 
-// ----------------------------------------------------------------------------------------------
-// Block kernel
-// ----------------------------------------------------------------------------------------------
-constexpr int kBlkLdsBytes = 80 * 1024;   // 2 workgroups per CU (160 KiB LDS)
-constexpr int kSlab = 32;                 // columns per work item
+constexpr int kSlab = 32;                 // widest column slab of the tile kernel
 
 // Broadcast of lane J's value to the lanes of its row group as a DPP quad_perm move (VALU; no
 // LDS traffic).  LPR >= 4: every lane of the quad reads lane J.  LPR == 2: two rows share a
@@ -141,6 +142,7 @@ __device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx
                                               int e0, int slot, int b, int row0, int pad, int last4, int (&mc)[4],
                                               float (&mv)[4]) {
   const int e = e0 + 4 * slot;
+  if (b < 0) { for (int i = 0; i < 4; ++i) { mc[i] = pad; mv[i] = 0.f; } return; }
   int c0 = pad, c1 = pad, c2 = pad, c3 = pad;
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   if (e < b) {
@@ -159,148 +161,209 @@ __device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx
   mc[3] = e + 3 < b ? c3 - row0 : pad;  mv[3] = e + 3 < b ? v3 : 0.f;
 }
 
-// One pass over FT = 4*LPR columns [c0, c0+FT) of block rows [row0, row0+ng).
+// ----------------------------------------------------------------------------------------------
+// Tile kernel: persistent, double-buffered version of the block kernel.
 //
-// The tile holds ng feature rows plus one all-zero row at index ng: CSR slots past the end of a
-// row point there (value 0), so the inner loop is branch-free per group of 4 entries and adds
-// exact zeros for the padding (no 0*inf hazards).  Each LPR-lane group owns one output row.  The
-// per-(row, slab) index traffic is what limits this kernel (8 slabs re-read the CSR), so it is
-// kept to 4 vector-memory instructions per 8 rows: one dwordx2 for the row pointers, one
-// dwordx4 each for 16 column indices and 16 values (fetch_entries), one store.  Entries reach
-// the lanes of the group through DPP quad broadcasts.  Index traffic is software-pipelined two
-// row groups ahead: while group i is reduced, the entries of group i+1 and the row pointers of
-// group i+2 are in flight.
-template <int THREADS, int LPR, bool WEIGHTED, bool FROM_LDS>
-__device__ __forceinline__ void block_pass(float* __restrict__ tile, const int32_t* __restrict__ rowptr,
-                                           const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-                                           const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias,
-                                           float* __restrict__ out, int64_t ldo, int row0, int ng, int c0, int act,
-                                           int last4, int ablate) {
-  constexpr int FT = LPR * 4;
-  constexpr int RPW = 64 / LPR;           // rows per wave iteration (one row per LPR-lane group)
-  constexpr int QL = LPR >= 4 ? 4 : 2;    // lanes of a row that fetch entries (4 entries each)
-  constexpr int EPB = 4 * QL;             // CSR entries fetched per row per batch
-  constexpr int STRIDE = (THREADS / 64) * RPW;
+// One 1024-thread workgroup per CU owns all 160 KiB of LDS as two tile buffers and pulls
+// (graph, 32-column slab) items from a device work queue.  While item k is reduced out of
+// buffer k&1, the feature tile of item k+1 streams into the other buffer by LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, nothing to wait for until the next barrier), so HBM reads,
+// LDS gathers and output stores of neighbouring items overlap inside one CU.  All CSR data an
+// item needs (row pointers + the first 16 entries of each of the wave's rows) is fetched into
+// registers as ONE burst after the previous item's reduction, never inside the reduction:
+// vector-memory returns are in order, and a late index load would otherwise have to wait for the
+// whole in-flight tile.  One barrier per item.
+// ----------------------------------------------------------------------------------------------
+constexpr int kPT = 1024;                         // threads per persistent workgroup
+constexpr int kPWaves = kPT / 64;
+constexpr int kTilePieces = 5056;                 // float4 pieces per tile buffer = 79 wave-instructions
+constexpr int kTileFloats = kTilePieces * 4;      // zero row starts here (same byte offset for every tier)
+constexpr int kBufFloats = 80 * 1024 / 4;         // one buffer; 2 buffers = all 160 KiB of a CU
+constexpr int kCtrlFloat = kTileFloats + 64;      // two int slots for queue hand-off, inside buffer 0's tail
+constexpr int kCap32 = kTilePieces / 8;           // 632 rows at FT = 32
+constexpr int kSpan = kPWaves * 16;               // rows a workgroup covers per wave iteration (16 rows per wave)
+
+template <int PPR>   // float4 pieces per tile row
+__device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h, int64_t ldh, int row0, int ng, int c0) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int grp = lane / LPR, sub = lane % LPR;
-  const int slot = sub % QL;
-  const int pad = FROM_LDS ? ng : 0;      // local row used by padding slots
-
-  // ---- stage the feature tile: every load is in flight before the first LDS write
-  if (FROM_LDS && !(ablate & 1)) {
-    constexpr int U = 5 * 1024 / THREADS;  // ceil((rows that fit) * LPR / THREADS)
-    const int total = ng * LPR;
-    float4 v[U];
+  const int total = ng * PPR;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = min(tid + u * THREADS, total - 1);   // clamped: branch-free
-      v[u] = *reinterpret_cast<const float4*>(h + (int64_t)(row0 + i / LPR) * ldh + c0 + (i % LPR) * 4);
+  for (int u = 0; u < (kTilePieces + kPT - 1) / kPT; ++u) {
+    const int i = tid + u * kPT;
+    if (i < total) {
+      const float* src = h + (int64_t)(row0 + i / PPR) * ldh + c0 + (i % PPR) * 4;
+      float* dst = buf + (u * kPT + (tid & ~63)) * 4;   // wave-uniform base; the DMA adds lane*16 bytes
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = tid + u * THREADS;
-      if (i < total) *reinterpret_cast<float4*>(tile + i * 4) = v[u];   // tile[r][q*4..]: r*FT + q*4 == i*4
-    }
-    if (tid < LPR) *reinterpret_cast<float4*>(tile + ng * FT + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-
-  // ---- pipeline prologue: row pointers of this wave's first two row groups, entries of the first
-  int r = wave * RPW + grp;
-  int a = 0, b = 0, a1 = 0, b1 = 0;
-  if (r < ng) { const I2u p = *reinterpret_cast<const I2u*>(rowptr + row0 + r); a = p.x; b = p.y; }
-  if (r + STRIDE < ng) { const I2u p = *reinterpret_cast<const I2u*>(rowptr + row0 + r + STRIDE); a1 = p.x; b1 = p.y; }
-  int mc[4];
-  float mv[4];
-  fetch_entries<WEIGHTED>(colidx, vals, a, slot, b, row0, pad, last4, mc, mv);
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bv = *reinterpret_cast<const float4*>(bias + c0 + sub * 4);
-  const float* hcol = h + c0 + sub * 4;
-  const float* trow = tile + sub * 4;
-  if (FROM_LDS) __syncthreads();
-
-  for (int rb = wave * RPW; rb < ng; rb += STRIDE) {
-    r = rb + grp;
-    // prefetch: entries of the next row group, row pointers of the one after
-    int mc_n[4];
-    float mv_n[4];
-    fetch_entries<WEIGHTED>(colidx, vals, a1, slot, b1, row0, pad, last4, mc_n, mv_n);
-    int a2 = 0, b2 = 0;
-    if (r + 2 * STRIDE < ng) { const I2u p = *reinterpret_cast<const I2u*>(rowptr + row0 + r + 2 * STRIDE); a2 = p.x; b2 = p.y; }
-
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int base = a;
-    while (!(ablate & 2)) {   // one batch of EPB entries per trip; trip count uniform inside a lane group
-#define GCNX_STEP4(J)                                                                                          \
-      if ((J) == 0 || __builtin_amdgcn_ballot_w64(base + 4 * (J) < b) != 0) {   /* wave-uniform skip */            \
-        int c[4];                                                                                              \
-        float w[4];                                                                                            \
-        float4 hv[4];                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-          c[i] = quad_bcast<LPR, (J)>(mc[i]);                                                                    \
-          if (WEIGHTED) w[i] = __int_as_float(quad_bcast<LPR, (J)>(__float_as_int(mv[i])));                      \
-        }                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-          if (FROM_LDS) {                                                                                      \
-            hv[i] = *reinterpret_cast<const float4*>(trow + c[i] * FT);                                        \
-          } else {                                                                                             \
-            hv[i] = *reinterpret_cast<const float4*>(hcol + (int64_t)(row0 + c[i]) * ldh);                     \
-            if (base + 4 * (J) + i >= b) hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                \
-          }                                                                                                    \
-        }                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc = WEIGHTED ? f4_fma(w[i], hv[i], acc) : f4_add(acc, hv[i]); \
-      }
-      GCNX_STEP4(0)
-      GCNX_STEP4(1)
-      if (QL == 4) {
-        GCNX_STEP4(2 % QL)
-        GCNX_STEP4(3 % QL)
-      }
-#undef GCNX_STEP4
-      base += EPB;
-      if (base >= b) break;
-      fetch_entries<WEIGHTED>(colidx, vals, base, slot, b, row0, pad, last4, mc, mv);   // rows longer than EPB
-    }
-    if (r < ng) {
-      acc = f4_add(acc, bv);
-      if (act == GCNX_ACT_RELU) {
-        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-      }
-      *reinterpret_cast<float4*>(out + (int64_t)(row0 + r) * ldo + c0 + sub * 4) = acc;
-    }
-    a = a1; b = b1; a1 = a2; b1 = b2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { mc[q] = mc_n[q]; mv[q] = mv_n[q]; }
-  }
-  if (FROM_LDS) __syncthreads();  // the next pass overwrites the tile
 }
 
-template <int THREADS, bool WEIGHTED>
-__global__ __launch_bounds__(THREADS, THREADS / 128) void spmm_block_kernel(
+// Index burst of an item, part 1: row pointers of every row this quad owns (NI wave iterations),
+// branch-free so that all loads are in flight at once.
+template <int NI>
+__device__ __forceinline__ void tile_load_rowptr(const int32_t* __restrict__ rowptr, int row0, int ng, int (&a)[NI],
+                                                 int (&b)[NI]) {
+  const int rbase = (threadIdx.x >> 6) * 16 + ((threadIdx.x & 63) >> 2);
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    const int r = rbase + t * kSpan;
+    const I2u p = *reinterpret_cast<const I2u*>(rowptr + row0 + min(r, ng - 1));   // clamped: always in bounds
+    a[t] = p.x;
+    b[t] = r < ng ? p.y : p.x;   // rows past the block end become empty
+  }
+}
+
+// Part 2: the first 16 entries of each of those rows.
+template <int NI, bool WEIGHTED>
+__device__ __forceinline__ void tile_load_entries(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+                                                  int row0, int pad, int last4, const int (&a)[NI], const int (&b)[NI],
+                                                  int (&mc)[NI][4], float (&mv)[NI][4]) {
+#pragma unroll
+  for (int t = 0; t < NI; ++t)
+    fetch_entries<WEIGHTED>(colidx, vals, a[t], threadIdx.x & 3, b[t], row0, pad, last4, mc[t], mv[t]);
+}
+
+// Reduction of one item out of its LDS tile (indices already in registers).  One quad per row,
+// CPL float4 column chunks per lane.  KEEP: leave mc/mv holding each row's FIRST 16 entries on
+// return (the next pass over the sibling columns reuses them).
+template <int NI, int CPL, bool WEIGHTED, bool KEEP>
+__device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, const int32_t* __restrict__ colidx,
+                                            const float* __restrict__ vals, const float4 (&bv)[CPL],
+                                            float* __restrict__ out, int64_t ldo, int row0, int ng, int c0, int act,
+                                            int pad, int last4, const int (&a)[NI], const int (&b)[NI],
+                                            int (&mc)[NI][4], float (&mv)[NI][4]) {
+  constexpr int FT = 16 * CPL;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 3;
+  const int rbase = (threadIdx.x >> 6) * 16 + (lane >> 2);
+  const float* trow = tile + sub * 4;
+#pragma unroll
+  for (int t = 0; t < NI; ++t) if (t * kSpan < ng) {
+    const int r = rbase + t * kSpan;
+    float4 acc[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int base = a[t];
+    const int bb = b[t];
+    while (true) {
+#define GCNX_TSTEP4(J)                                                                                         \
+      if ((J) == 0 || __builtin_amdgcn_ballot_w64(base + 4 * (J) < bb) != 0) {                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+          const int c = quad_bcast<4, (J)>(mc[t][i]);                                                          \
+          float w = 0.f;                                                                                       \
+          if (WEIGHTED) w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(mv[t][i])));                     \
+          _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                    \
+            const float4 hv = *reinterpret_cast<const float4*>(trow + c * FT + 16 * j);                        \
+            acc[j] = WEIGHTED ? f4_fma(w, hv, acc[j]) : f4_add(acc[j], hv);                                    \
+          }                                                                                                    \
+        }                                                                                                      \
+      }
+      GCNX_TSTEP4(0)
+      GCNX_TSTEP4(1)
+      GCNX_TSTEP4(2)
+      GCNX_TSTEP4(3)
+#undef GCNX_TSTEP4
+      base += 16;
+      if (base >= bb) break;
+      // rows longer than 16 entries (rare in contact graphs): fetched on demand
+      fetch_entries<WEIGHTED>(colidx, vals, base, sub, bb, row0, pad, last4, mc[t], mv[t]);
+    }
+    if (KEEP && __builtin_amdgcn_ballot_w64(bb - a[t] > 16) != 0)   // a long row overwrote its first batch
+      fetch_entries<WEIGHTED>(colidx, vals, a[t], sub, bb, row0, pad, last4, mc[t], mv[t]);
+    if (r < ng) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        float4 o = f4_add(acc[j], bv[j]);
+        if (act == GCNX_ACT_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(out + (int64_t)(row0 + r) * ldo + c0 + (sub + 4 * j) * 4) = o;
+      }
+    }
+  }
+}
+
+// Items of one tier: (graph of the tier's list) x (slab of FT*NPASS columns), each done in NPASS
+// steps of FT columns that share one index burst (tier 1: FT = 32; tier 2: FT = 16).
+// NI = wave iterations that cover the largest graph of the tier.
+template <int NI, int FT, int NPASS, bool WEIGHTED>
+__global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
     const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-    const int32_t* __restrict__ block_ptr, int nslabs, int act, int nwork, int cap32, int n, int ablate) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int w = gcnx_xcd_remap(blockIdx.x, nwork);  // slabs of one graph stay on one XCD, adjacent in time
-  const int g = w / nslabs, s = w % nslabs;
-  const int row0 = block_ptr[g];
-  const int ng = block_ptr[g + 1] - row0;
-  if (ng <= 0) return;
-  const int c0 = s * kSlab;
-  const int last4 = rowptr[n] - 4;   // last entry index from which a 4-entry vector load stays in bounds
-  // cap32 = rows that fit (plus the zero row) with a 32-column tile
-  if (ng <= cap32) {
-    block_pass<THREADS, 8, WEIGHTED, true>(tile, rowptr, colidx, vals, h, ldh, bias, out, ldo, row0, ng, c0, act, last4, ablate);
-  } else if (ng <= 2 * cap32) {
-#pragma unroll 1
-    for (int p = 0; p < 2; ++p)
-      block_pass<THREADS, 4, WEIGHTED, true>(tile, rowptr, colidx, vals, h, ldh, bias, out, ldo, row0, ng, c0 + 16 * p, act, last4, ablate);
-  } else if (ng <= 4 * cap32) {
-#pragma unroll 1
-    for (int p = 0; p < 4; ++p)
-      block_pass<THREADS, 2, WEIGHTED, true>(tile, rowptr, colidx, vals, h, ldh, bias, out, ldo, row0, ng, c0 + 8 * p, act, last4, ablate);
-  } else {
-    block_pass<THREADS, 8, WEIGHTED, false>(tile, rowptr, colidx, vals, h, ldh, bias, out, ldo, row0, ng, c0, act, last4, ablate);
+    const int2* __restrict__ graphs /* (row0, ng), largest first */, int nslabs, int act, int nwork, int n,
+    int* __restrict__ queue) {
+  constexpr int ITEM_COLS = FT * NPASS;     // columns per work item
+  constexpr int CPL = FT / 16;
+  constexpr int PAD = kTileFloats / FT;      // index of the all-zero row
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* ctrl = reinterpret_cast<int*>(lds + kCtrlFloat);
+  const int tid = threadIdx.x;
+  if (tid == 0) { ctrl[0] = atomicAdd(queue, 1); ctrl[1] = atomicAdd(queue, 1); }
+  if (tid < 32) lds[kTileFloats + tid] = 0.f;                 // zero rows of both buffers
+  else if (tid < 64) lds[kBufFloats + kTileFloats + tid - 32] = 0.f;
+  __syncthreads();
+  int item = ctrl[0], nxt_item = ctrl[1];
+  if (item >= nwork) return;                                  // every workgroup reaches an exit: the queue is finite
+  const int last4 = rowptr[n] - 4;
+  const int sub = tid & 3;
+
+  int a[NI], b[NI], mc[NI][4];
+  float mv[NI][4];
+  int2 g = graphs[item / nslabs];
+  int c0 = (item % nslabs) * ITEM_COLS;
+  int pass = 0;
+  tile_load_rowptr<NI>(rowptr, g.x, g.y, a, b);
+  tile_load_entries<NI, WEIGHTED>(colidx, vals, g.x, PAD, last4, a, b, mc, mv);
+  tile_dma<FT / 4>(lds, h, ldh, g.x, g.y, c0);
+
+  for (int k = 0;; ++k) {
+    __syncthreads();   // tile k has landed (hipcc drains vmcnt before the barrier); reduction k-1 is over everywhere
+    // ---- step k+1: sibling columns of the same item, or the look-ahead item
+    const bool same = pass + 1 < NPASS;
+    if (!same && k >= NPASS) nxt_item = ctrl[((k / NPASS) - 1) & 1];   // popped by thread 0 one item ago
+    const int n_item = same ? item : nxt_item;
+    const bool n_valid = n_item < nwork;
+    int2 ng2 = g;
+    int nc0 = c0 + FT;
+    int popped = 0;
+    int a_n[NI], b_n[NI];
+    if (n_valid) {
+      if (!same) {
+        if (tid == 0) popped = atomicAdd(queue, 1);           // look-ahead pop; its latency hides behind the reduction
+        ng2 = graphs[n_item / nslabs];
+        nc0 = (n_item % nslabs) * ITEM_COLS;
+      }
+      tile_dma<FT / 4>(lds + ((k + 1) & 1) * kBufFloats, h, ldh, ng2.x, ng2.y, nc0);   // streams in during the reduction
+      if (!same && NPASS == 1) tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a_n, b_n);   // early: hides one round trip
+    }
+    // ---- reduce step k
+    float4 bv[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bv[j] = *reinterpret_cast<const float4*>(bias + c0 + (sub + 4 * j) * 4);
+    }
+    tile_reduce<NI, CPL, WEIGHTED, (NPASS > 1)>(lds + (k & 1) * kBufFloats, colidx, vals, bv, out, ldo, g.x, g.y, c0, act,
+                                                PAD, last4, a, b, mc, mv);
+    if (!n_valid) break;
+    if (!same) {
+      // ---- rest of the index burst of the next item (the registers of this item are dead now)
+      if (tid == 0) ctrl[(k / NPASS) & 1] = popped;
+      if (NPASS == 1) {
+#pragma unroll
+        for (int t = 0; t < NI; ++t) { a[t] = a_n[t]; b[t] = b_n[t]; }
+      } else {
+        tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a, b);     // register budget: no early prefetch in the 2-pass tier
+      }
+      tile_load_entries<NI, WEIGHTED>(colidx, vals, ng2.x, PAD, last4, a, b, mc, mv);
+      item = n_item;
+      pass = 0;
+    } else {
+      ++pass;
+    }
+    g = ng2;
+    c0 = nc0;
   }
 }
 
@@ -329,26 +392,142 @@ __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restr
 
 template <int LPR>
 void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
-                 int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act) {
-  const int nchunks = gcnx_cdiv(n, kRowsPerChunk);
+                 int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                 const int2* chunk_list = nullptr, int list_len = 0) {
+  const bool small = !chunk_list && n < 16 * 1024 * kRowsPerChunk / 4;   // < 128k rows
+  const int nchunks = chunk_list ? list_len : gcnx_cdiv(n, small ? kRowsPerChunkSmall : kRowsPerChunk);
   const int span = LPR * 4;
   for (int col0 = 0; col0 < f; col0 += span) {
-    if (vals)
-      hipLaunchKernelGGL((spmm_rows_kernel<LPR, true>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx,
-                         vals, h, ldh, bias, out, ldo, n, f, col0, act, nchunks);
-    else
-      hipLaunchKernelGGL((spmm_rows_kernel<LPR, false>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx,
-                         vals, h, ldh, bias, out, ldo, n, f, col0, act, nchunks);
+#define GCNX_ROWS(W, R)                                                                                              \
+    hipLaunchKernelGGL((spmm_rows_kernel<LPR, W, R>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx, vals, h, \
+                       ldh, bias, out, ldo, n, f, col0, act, nchunks, chunk_list)
+    if (small) { if (vals) GCNX_ROWS(true, kRowsPerChunkSmall); else GCNX_ROWS(false, kRowsPerChunkSmall); }
+    else { if (vals) GCNX_ROWS(true, kRowsPerChunk); else GCNX_ROWS(false, kRowsPerChunk); }
+#undef GCNX_ROWS
   }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                   int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                   const int2* chunk_list, int list_len) {
+  int lanes = f / 4;
+  // Tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in floats
+  // forces the lanes-per-row split of the rows kernel; results are identical.
+  if (const char* e = getenv("GCNX_SPMM_SLAB")) {
+    const int slab = atoi(e);
+    if (slab >= 16 && slab / 4 < lanes) lanes = slab / 4;
+  }
+  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
+  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
+  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
+  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
+  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
+}
+
+template <int NI, int FT, int NPASS>
+int launch_tiles(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                 int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                 const int2* graphs, int ngraphs, int* queue) {
+  constexpr int lds_bytes = 2 * kBufFloats * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<NI, FT, NPASS, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<NI, FT, NPASS, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  const int nslabs = f / (FT * NPASS);
+  const long long nwork = (long long)ngraphs * nslabs;
+  if (nwork >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many (graph, slab) work items");
+  const int grid = (int)(nwork < ctx->num_cus ? nwork : ctx->num_cus);   // one persistent workgroup per CU
+  if (vals)
+    hipLaunchKernelGGL((spmm_tile_kernel<NI, FT, NPASS, true>), dim3(grid), dim3(kPT), lds_bytes, ctx->stream, rowptr, colidx,
+                       vals, h, ldh, bias, out, ldo, graphs, nslabs, act, (int)nwork, n, queue);
+  else
+    hipLaunchKernelGGL((spmm_tile_kernel<NI, FT, NPASS, false>), dim3(grid), dim3(kPT), lds_bytes, ctx->stream, rowptr, colidx,
+                       vals, h, ldh, bias, out, ldo, graphs, nslabs, act, (int)nwork, n, queue);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
 }  // namespace
 
-extern "C" int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
-                             const float* h, int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n,
-                             int32_t f, int act, const int32_t* block_ptr, int32_t nblocks) {
+// What the diagonal-block structure of a disjoint batch buys: which graphs fit an LDS tile (and
+// at which slab width), largest first so the work queue ends on small items; 32-row chunks of
+// the graphs that do not, for the rows kernel.  Built once per batch; owned by the caller.
+struct gcnx_spmm_plan {
+  int nblocks = 0;
+  int n1 = 0, n2 = 0, nchunks = 0;      // tier-1 graphs, tier-2 graphs, row chunks of larger graphs
+  long long tile_rows = 0;
+  int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
+};
+
+extern "C" {
+
+int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nblocks, gcnx_spmm_plan** out) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, out != nullptr, "gcnx_spmm_plan_create: out is NULL");
+  *out = nullptr;
+  GCNX_REQUIRE(ctx, nblocks >= 0 && (nblocks == 0 || block_ptr), "gcnx_spmm_plan_create: bad block list");
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_spmm_plan_create synchronises and cannot be captured");
+  try {
+    std::vector<int32_t> bp((size_t)nblocks + 1, 0);
+    if (nblocks > 0) {
+      GCNX_HIP(ctx, hipMemcpyAsync(bp.data(), block_ptr, bp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<int2> t1, t2, ch;
+    long long tile_rows = 0;
+    for (int g = 0; g < nblocks; ++g) {
+      const int r0 = bp[g], ng = bp[g + 1] - bp[g];
+      if (ng < 0) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g);
+      if (ng == 0) continue;
+      if (ng <= kCap32) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; }
+      else if (ng <= 2 * kCap32) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; }
+      else for (int r = r0; r < r0 + ng; r += kRowsPerChunk) ch.push_back(make_int2(r, std::min(r + kRowsPerChunk, r0 + ng)));
+    }
+    auto by_size = [](const int2& x, const int2& y) { return x.y != y.y ? x.y > y.y : x.x < y.x; };
+    std::sort(t1.begin(), t1.end(), by_size);
+    std::sort(t2.begin(), t2.end(), by_size);
+    gcnx_spmm_plan* p = new gcnx_spmm_plan();
+    p->nblocks = nblocks;
+    p->n1 = (int)t1.size(); p->n2 = (int)t2.size(); p->nchunks = (int)ch.size();
+    p->tile_rows = tile_rows;
+    const size_t total = t1.size() + t2.size() + ch.size();
+    if (total) {
+      std::vector<int2> all;
+      all.reserve(total);
+      all.insert(all.end(), t1.begin(), t1.end());
+      all.insert(all.end(), t2.begin(), t2.end());
+      all.insert(all.end(), ch.begin(), ch.end());
+      hipError_t e = hipMalloc((void**)&p->dev, total * sizeof(int2));
+      if (e != hipSuccess) { delete p; return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_create: hipMalloc: %s", hipGetErrorString(e)); }
+      e = hipMemcpyAsync(p->dev, all.data(), total * sizeof(int2), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
+    }
+    *out = p;
+  } catch (const std::bad_alloc&) {
+    return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_create: out of host memory");
+  }
+  return GCNX_OK;
+}
+
+int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
+  GCNX_CHECK_CTX(ctx);
+  if (!plan) return GCNX_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (plan->dev) (void)hipFree(plan->dev);
+  delete plan;
+  return GCNX_OK;
+}
+
+int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                  const gcnx_spmm_plan* plan) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr: negative size");
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_spmm_csr: activation %d not supported here", act);
@@ -364,52 +543,34 @@ extern "C" int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  const char* force = getenv("GCNX_SPMM_KERNEL");  // tuning knob: "rows" disables the block kernel
-  if (block_ptr && nblocks > 0 && f % kSlab == 0 && !(force && force[0] == 'r')) {
-    int lds_bytes = kBlkLdsBytes, threads = 512;
-    if (const char* e = getenv("GCNX_SPMM_LDS_KB")) {   // tuning knobs
-      const int kb = atoi(e);
-      if (kb >= 8 && kb * 1024 <= kBlkLdsBytes) lds_bytes = kb * 1024;
-    }
-    int ablate = 0;  // timing-only ablation (wrong results): 1 = skip tile load, 2 = skip reduction
-    if (const char* e = getenv("GCNX_SPMM_ABLATE")) ablate = atoi(e);
-    if (const char* e = getenv("GCNX_SPMM_THREADS")) threads = atoi(e) == 1024 ? 1024 : 512;
-    const int cap32 = lds_bytes / (kSlab * 4) - 1;
-    const int nslabs = f / kSlab;
-    const long long nwork = (long long)nblocks * nslabs;
-    GCNX_REQUIRE(ctx, nwork < 2147483647LL, "gcnx_spmm_csr: too many (block, slab) work items");
-#define GCNX_LAUNCH_BLOCK(T, W)                                                                                   \
-  do {                                                                                                            \
-    static bool attr_set = false;                                                                                 \
-    if (!attr_set) {                                                                                              \
-      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_block_kernel<T, W>),                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kBlkLdsBytes));               \
-      attr_set = true;                                                                                            \
-    }                                                                                                             \
-    hipLaunchKernelGGL((spmm_block_kernel<T, W>), dim3((unsigned)nwork), dim3(T), lds_bytes, ctx->stream, rowptr, \
-                       colidx, vals, h, ldh, bias, out, ldo, block_ptr, nslabs, act, (int)nwork, cap32, n, ablate); \
-  } while (0)
-    if (threads == 1024) {
-      if (vals) GCNX_LAUNCH_BLOCK(1024, true); else GCNX_LAUNCH_BLOCK(1024, false);
-    } else {
-      if (vals) GCNX_LAUNCH_BLOCK(512, true); else GCNX_LAUNCH_BLOCK(512, false);
-    }
-#undef GCNX_LAUNCH_BLOCK
+  const char* force = getenv("GCNX_SPMM_KERNEL");  // tuning knob: "rows" disables the tile kernel, "tile" forces it
+  // The tile kernel is a throughput design (one item per CU at a time): it needs a few items
+  // per CU to fill the chip, otherwise the rows kernel's finer decomposition wins.
+  bool tiles = plan && f % kSlab == 0 && (long long)(plan->n1 + 2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
+  if (force && force[0] == 'r') tiles = false;
+  if (force && force[0] == 't' && plan && f % kSlab == 0) tiles = true;
+  if (!tiles) {
+    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0);
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  int lanes = f / 4;
-  // Debug/tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in
-  // floats (64/128/256) forces the lanes-per-row split; results are identical.
-  if (const char* e = getenv("GCNX_SPMM_SLAB")) {
-    const int slab = atoi(e);
-    if (slab >= 16 && slab / 4 < lanes) lanes = slab / 4;
+  int* queues = ctx->flag + 1;
+  GCNX_HIP(ctx, hipMemsetAsync(queues, 0, 2 * sizeof(int), ctx->stream));
+  if (plan->n1 > 0) {
+    int rc = launch_tiles<3, 32, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, queues);
+    if (rc) return rc;
   }
-  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
-  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
-  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
-  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
-  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
-  GCNX_LAUNCH_OK(ctx);
+  if (plan->n2 > 0) {
+    int rc = launch_tiles<5, 16, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
+                                plan->n2, queues + 1);
+    if (rc) return rc;
+  }
+  if (plan->nchunks > 0) {
+    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
+                  plan->nchunks);
+    GCNX_LAUNCH_OK(ctx);
+  }
   return GCNX_OK;
 }
+
+}  // extern "C"

@@ -55,7 +55,9 @@ SIGNATURES = {
     "gcnx_gcn_norm": [_vp, _vp, _vp, _vp, _i32, _int, _vp],
     "gcnx_csr_transpose": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gcnx_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp],
-    "gcnx_spmm_csr": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp, _i32],
+    "gcnx_spmm_plan_create": [_vp, _vp, _i32, C.POINTER(_vp)],
+    "gcnx_spmm_plan_destroy": [_vp, _vp],
+    "gcnx_spmm_csr": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp],
     "gcnx_segment_pool": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _int, _vp],
     "gcnx_softmax_cce": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
     "gcnx_act_bias_grad": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp],

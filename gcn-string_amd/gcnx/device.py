@@ -109,12 +109,13 @@ class Graph:
 class DeviceArray:
     """Row-major device buffer (1-D or 2-D) or a column-slice view of one (ld = row stride)."""
 
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "ld", "_base", "_owner")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "ld", "_base", "_owner", "_spmm_plan")
 
     def __init__(self, ctx, ptr, shape, dtype, ld=None, base=None, owner=False):
         self.ctx, self.ptr, self.shape, self.dtype = ctx, ptr, tuple(int(s) for s in shape), np.dtype(dtype)
         self.ld = int(ld) if ld is not None else (self.shape[-1] if self.shape else 1)
         self._base, self._owner = base, owner
+        self._spmm_plan = None
 
     @classmethod
     def alloc(cls, ctx, shape, dtype):
@@ -198,7 +199,23 @@ class DeviceCSR:
         self.block_ptr, self.n_blocks = block_ptr, int(n_blocks)
         self.symmetric = symmetric
         self._t = None
+        self._plan = None
         self.dense_shape = (self.n, self.n)
+
+    @property
+    def plan(self):
+        """gcnx_spmm_plan of this batch's block structure (built on first use, shared by every
+        CSR that shares block_ptr: normalised / unweighted / transposed views)."""
+        if self.block_ptr is None or self.n_blocks == 0:
+            return None
+        holder = self.block_ptr
+        p = getattr(holder, "_spmm_plan", None)
+        if p is None:
+            h = C.c_void_p()
+            self.ctx._ck(self.ctx.lib.gcnx_spmm_plan_create(self.ctx.h, holder.ptr, self.n_blocks, C.byref(h)))
+            p = _Plan(self.ctx, h)
+            holder._spmm_plan = p
+        return p.h
 
     @classmethod
     def from_host_csr(cls, ctx, rowptr, colidx, vals=None, graph_ptr=None, symmetric=True):
@@ -254,6 +271,18 @@ class DeviceCSR:
                          self.symmetric)
 
 
+class _Plan:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx._live:
+                self.ctx.lib.gcnx_spmm_plan_destroy(self.ctx.h, self.h)
+        except Exception:
+            pass
+
+
 class Segments:
     """Graph membership of the rows of a disjoint batch: graph_ptr int32[B+1] on the device
     (the sorted id vector ``i`` of DisjointLoader, run-length encoded)."""
@@ -302,7 +331,7 @@ def spmm(ctx, a, h, bias, out, act=None):
     n, f = h.shape
     assert a.n == n and out.shape == (n, f)
     ctx._ck(ctx.lib.gcnx_spmm_csr(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(h), h.ld, _p(bias), _p(out),
-                                  out.ld, n, f, L.ACTS[act], _p(a.block_ptr), a.n_blocks))
+                                  out.ld, n, f, L.ACTS[act], a.plan))
     return out
 
 

@@ -42,6 +42,7 @@ typedef struct gcnx_ctx gcnx_ctx;
 typedef struct gcnx_comm gcnx_comm;
 typedef struct gcnx_graph gcnx_graph;
 typedef struct gcnx_event gcnx_event;
+typedef struct gcnx_spmm_plan gcnx_spmm_plan;
 
 typedef enum {
   GCNX_OK = 0,
@@ -120,16 +121,21 @@ GCNX_API int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int3
 GCNX_API int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias,
               float* out, int64_t ldo, int64_t n, int32_t fi, int32_t fo, int prec, int act,
               const float* alpha);
+/* The block-diagonal structure of a DisjointLoader batch (sp.block_diag) as a
+ * scheduling plan: block_ptr int32[nblocks+1] on the device (= graph_ptr) says that rows
+ * [block_ptr[g], block_ptr[g+1]) reference only columns of that same range.  Built once per
+ * batch (synchronises), owned by the caller, read-only afterwards; it must describe the CSR it
+ * is later used with.  It only changes how gcnx_spmm_csr schedules work, never its result. */
+GCNX_API int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nblocks,
+                                   gcnx_spmm_plan** out);
+GCNX_API int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan);
 /* K2/K3 SparseTensorDenseMatMul / gather+unsorted_segment_sum:
  * out[t,:] = act( sum_e vals[e] * h[colidx[e],:] + bias ), e over row t.
  * GCNConv.call (bias AFTER aggregation) and GeneralConv.propagate (vals NULL).
- * block_ptr (int32[nblocks+1], may be NULL) lists diagonal blocks of the disjoint batch
- * (= graph_ptr): rows [block_ptr[g], block_ptr[g+1]) reference only columns of that range.
- * It is a scheduling hint that enables the LDS-resident-tile kernel; results are identical. */
+ * plan (may be NULL) enables the LDS-resident tile kernel for graphs that fit one. */
 GCNX_API int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx,
                   const float* vals, const float* h, int64_t ldh, const float* bias, float* out,
-                  int64_t ldo, int32_t n, int32_t f, int act, const int32_t* block_ptr,
-                  int32_t nblocks);
+                  int64_t ldo, int32_t n, int32_t f, int act, const gcnx_spmm_plan* plan);
 /* K4 SegmentSum / mean / max over sorted graph ids (GlobalSumPool, gcn.py:320 pool="sum";
  * max variant: gcn_utills.py:842).  graph_ptr int32[B+1].  argmax int32[B*F] (row index of
  * the maximum; required for MAX, else NULL). */

@@ -31,18 +31,9 @@ alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, f, vals is not None)
 print(f"N={hb.n} nnz={hb.nnz} F={f} alg={alg/1e6:.1f} MB")
 for rnd in range(args.rounds):
     for slab in args.slabs.split(","):
-        for k_ in ("GCNX_SPMM_SLAB", "GCNX_SPMM_KERNEL", "GCNX_SPMM_THREADS", "GCNX_SPMM_LDS_KB", "GCNX_SPMM_ABLATE"): os.environ.pop(k_, None)
-        if slab.startswith("t"):      # e.g. t1024 or t512k64 : block kernel, threads [, LDS KiB]
-            body_, _, ab_ = slab[1:].partition("a")
-            if ab_: os.environ["GCNX_SPMM_ABLATE"] = ab_
-            t_, _, kb_ = body_.partition("k")
-            os.environ["GCNX_SPMM_THREADS"] = t_
-            if kb_: os.environ["GCNX_SPMM_LDS_KB"] = kb_
-            slab_ = "0"
-        else:
-            slab_ = slab
-        if slab_ == "rows": os.environ["GCNX_SPMM_KERNEL"] = "rows"
-        elif slab_ != "0": os.environ["GCNX_SPMM_SLAB"] = slab_; os.environ["GCNX_SPMM_KERNEL"] = "rows"
+        for k_ in ("GCNX_SPMM_SLAB", "GCNX_SPMM_KERNEL"): os.environ.pop(k_, None)
+        if slab in ("rows", "tile"): os.environ["GCNX_SPMM_KERNEL"] = slab
+        elif slab != "0": os.environ["GCNX_SPMM_SLAB"] = slab; os.environ["GCNX_SPMM_KERNEL"] = "rows"
         for _ in range(3): D.spmm(ctx, a, h, bias, out, act="relu")
         e0 = ctx.event().record()
         for _ in range(args.iters): D.spmm(ctx, a, h, bias, out, act="relu")

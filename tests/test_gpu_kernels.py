@@ -61,6 +61,37 @@ def test_spmm_long_rows_overflowing_the_lds_stage(ctx):
         assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
+    """The persistent LDS-tile kernel on a batch that holds every scheduling class: graphs of
+    <= 632 rows (32-column tile), <= 1264 rows (two 16-column passes), larger ones (row chunks
+    for the rows kernel), a single-node graph, rows with > 16 entries (on-demand index fetch)."""
+    from gcnx import device as D, synth
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    sizes = [1, 40, 632, 633, 1264, 1265, 300, 2000, 7]
+    blocks = []
+    for i, m in enumerate(sizes):
+        dens = 0.5 if m == 40 else min(1.0, 9.0 / m)          # the 40-node graph has ~20-entry rows
+        a = sp.random(m, m, density=dens, random_state=i, format="csr")
+        a = ((a + a.T) > 0).astype(np.float32) + sp.identity(m, dtype=np.float32, format="csr")
+        blocks.append((a > 0).astype(np.float32))
+    a = sp.block_diag(blocks).tocsr(); a.sort_indices()
+    n = a.shape[0]
+    gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    hb = synth.HostBatch(rng.standard_normal((n, 64), dtype=np.float32), a.indptr.astype(np.int32), a.indices.astype(np.int32),
+                         None, gp, np.zeros((len(sizes), 2), np.float32))
+    csr, vals = _csr(ctx, hb, weighted)
+    bias = rng.standard_normal(64).astype(np.float32)
+    ref = _ref_spmm(hb, vals, hb.x, bias, True)
+    out = ctx.zeros((n, 64))
+    for kernel in ("tile", "rows"):
+        monkeypatch.setenv("GCNX_SPMM_KERNEL", kernel)
+        out.fill_zero()
+        D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out, act="relu")
+        assert rel_err(out.numpy(), ref) < TIGHT, kernel
+
+
 def test_spmm_empty_rows_single_nodes_and_strided_views(ctx):
     from gcnx import device as D, synth
     from gcnx.device import DeviceCSR
@@ -86,11 +117,11 @@ def test_spmm_empty_rows_single_nodes_and_strided_views(ctx):
 def test_spmm_zero_sizes_and_argument_errors(ctx):
     from gcnx import _lib
     lib = ctx.lib
-    assert lib.gcnx_spmm_csr(ctx.h, None, None, None, None, 0, None, None, 0, 0, 16, 0, None, 0) == 0
+    assert lib.gcnx_spmm_csr(ctx.h, None, None, None, None, 0, None, None, 0, 0, 16, 0, None) == 0
     buf = ctx.zeros((4, 4))
-    rc = lib.gcnx_spmm_csr(ctx.h, buf.ptr, buf.ptr, None, buf.ptr, 2, None, buf.ptr, 4, 4, 4, 0, None, 0)
+    rc = lib.gcnx_spmm_csr(ctx.h, buf.ptr, buf.ptr, None, buf.ptr, 2, None, buf.ptr, 4, 4, 4, 0, None)
     assert rc == 1 and "leading dimension" in _lib.last_error(ctx.h)          # ldh < f
-    rc = lib.gcnx_spmm_csr(ctx.h, buf.ptr, buf.ptr, None, buf.ptr, 4, None, buf.ptr, 4, 4, 4, 0, None, 0)
+    rc = lib.gcnx_spmm_csr(ctx.h, buf.ptr, buf.ptr, None, buf.ptr, 4, None, buf.ptr, 4, 4, 4, 0, None)
     assert rc == 1 and "in-place" in _lib.last_error(ctx.h)
 
 
