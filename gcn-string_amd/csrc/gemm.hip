@@ -125,14 +125,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
-// Second stage of the deterministic split-K: out[i] = sum_s part[s][i], s ascending.
+// Second stage of the deterministic split-K: out[i] = sum_s part[s][i].  Block = 64 outputs x 4
+// split groups; each group sums its splits in ascending order, the 4 group sums are combined in
+// a fixed order -- the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int64_t slab,
                                                             int nsplit, float* __restrict__ out, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += part[(int64_t)z * slab + i];
-  out[i] = s;
+  __shared__ float s[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + el;
+  float acc = 0.f;
+  if (i < total) {
+    const int per = (nsplit + 3) / 4;
+    const int z0 = grp * per, z1 = min(nsplit, z0 + per);
+#pragma unroll 4
+    for (int z = z0; z < z1; ++z) acc += part[(int64_t)z * slab + i];
+  }
+  s[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0 && i < total) out[i] = (s[0][el] + s[1][el]) + (s[2][el] + s[3][el]);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -203,7 +213,7 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo, "gcnx_gemm_dw: leading dimension too small");
   // dW[i, o] = sum_n X[n, i] * dH[n, o]: A[i][k=n] = X[n*ldx + i], B[k=n][o] = dH[n*lddh + o].
   const int tiles = gcnx_cdiv(fi, BM) * gcnx_cdiv(fo, BN);
-  int nsplit = (int)((4LL * ctx->num_cus + tiles - 1) / tiles);
+  int nsplit = (int)((2LL * ctx->num_cus + tiles - 1) / tiles);   // ~2 workgroups per CU
   const int64_t ksteps = (n + BK - 1) / BK;
   if (nsplit > ksteps) nsplit = (int)ksteps;
   if (nsplit < 1) nsplit = 1;
@@ -223,7 +233,7 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   GCNX_LAUNCH_OK(ctx);
   if (nsplit > 1) {
     const int64_t total = (int64_t)fi * fo;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(total, 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(total, 64)), dim3(256), 0, ctx->stream,
                        (const float*)ctx->ws, total, nsplit, dw, total);
     GCNX_LAUNCH_OK(ctx);
   }

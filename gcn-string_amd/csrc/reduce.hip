@@ -6,92 +6,141 @@
 
 namespace {
 
-constexpr int kColsumRows = 512;  // rows per first-stage workgroup
+constexpr int kColsumRows = 256;  // rows per first-stage workgroup
 
-// Column sums of x[n, f] -> part[chunk][f].  Block = 64 column lanes x 4 row groups.
+__device__ __forceinline__ float4 ld4(const float* p, bool vec, int valid) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) v.x = p[0];
+  if (valid > 1) v.y = p[1];
+  if (valid > 2) v.z = p[2];
+  if (valid > 3) v.w = p[3];
+  return v;
+}
+__device__ __forceinline__ void st4(float* p, float4 v, bool vec, int valid) {
+  if (vec) { *reinterpret_cast<float4*>(p) = v; return; }
+  if (valid > 0) p[0] = v.x;
+  if (valid > 1) p[1] = v.y;
+  if (valid > 2) p[2] = v.z;
+  if (valid > 3) p[3] = v.w;
+}
+
+// Column sums of x[n, f] -> part[chunk][f].  Block = 16 float4 column lanes (64 columns) x 16 row
+// groups; the 16 partial rows are combined through LDS in a fixed order (deterministic).
 // Optional fused activation gradient: dz = dy * act'(y) is written and summed instead of x.
 template <bool FUSE_ACT>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int32_t f,
                                                      int64_t rows_per_chunk, float* __restrict__ part,
                                                      const float* __restrict__ y, int64_t ldy, float* __restrict__ dz,
                                                      int64_t lddz, int act, const float* __restrict__ alpha,
-                                                     float* __restrict__ part_alpha) {
-  __shared__ float s[4][64];
-  __shared__ float s2[4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+                                                     float* __restrict__ part_alpha, int vec) {
+  __shared__ float4 s[16][16];
+  __shared__ float4 s2[16][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cl * 4;
+  const int valid = f - c;                       // columns this lane really owns (<= 0: none)
+  const bool v4 = vec && valid >= 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
   const int64_t r1 = min(n, r0 + rows_per_chunk);
-  float acc = 0.f, acc_a = 0.f;
-  if (c < f) {
-    const float al = (FUSE_ACT && act == GCNX_ACT_PRELU) ? alpha[c] : 0.f;
-    for (int64_t r = r0 + rg; r < r1; r += 4) {
-      float v = x[r * ldx + c];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc_a = acc;
+  if (valid > 0) {
+    float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FUSE_ACT && act == GCNX_ACT_PRELU) al = ld4(alpha + c, false, valid);
+#pragma unroll 4
+    for (int64_t r = r0 + rg; r < r1; r += 16) {
+      float4 v = ld4(x + r * ldx + c, v4, valid);
       if (FUSE_ACT) {
-        const float yy = y[r * ldy + c];
-        if (act == GCNX_ACT_RELU) v = yy > 0.f ? v : 0.f;
-        else if (act == GCNX_ACT_PRELU) {
-          acc_a += v * fminf(yy, 0.f);
-          v = yy > 0.f ? v : al * v;
+        const float4 yy = ld4(y + r * ldy + c, v4, valid);
+        if (act == GCNX_ACT_RELU) {
+          v.x = yy.x > 0.f ? v.x : 0.f; v.y = yy.y > 0.f ? v.y : 0.f; v.z = yy.z > 0.f ? v.z : 0.f; v.w = yy.w > 0.f ? v.w : 0.f;
+        } else if (act == GCNX_ACT_PRELU) {
+          acc_a.x += v.x * fminf(yy.x, 0.f); acc_a.y += v.y * fminf(yy.y, 0.f);
+          acc_a.z += v.z * fminf(yy.z, 0.f); acc_a.w += v.w * fminf(yy.w, 0.f);
+          v.x = yy.x > 0.f ? v.x : al.x * v.x; v.y = yy.y > 0.f ? v.y : al.y * v.y;
+          v.z = yy.z > 0.f ? v.z : al.z * v.z; v.w = yy.w > 0.f ? v.w : al.w * v.w;
         }
-        dz[r * lddz + c] = v;
+        st4(dz + r * lddz + c, v, v4, valid);
       }
-      acc += v;
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
   s[rg][cl] = acc;
   if (FUSE_ACT) s2[rg][cl] = acc_a;
   __syncthreads();
-  if (rg == 0 && c < f) {
-    if (part) part[(int64_t)blockIdx.y * f + c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
-    if (FUSE_ACT && part_alpha) part_alpha[(int64_t)blockIdx.y * f + c] = (s2[0][cl] + s2[1][cl]) + (s2[2][cl] + s2[3][cl]);
+  if (rg == 0 && valid > 0) {
+    float4 t = s[0][cl], ta = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 1; q < 16; ++q) { t.x += s[q][cl].x; t.y += s[q][cl].y; t.z += s[q][cl].z; t.w += s[q][cl].w; }
+    if (part) st4(part + (int64_t)blockIdx.y * f + c, t, false, valid);
+    if (FUSE_ACT && part_alpha) {
+      ta = s2[0][cl];
+      for (int q = 1; q < 16; ++q) { ta.x += s2[q][cl].x; ta.y += s2[q][cl].y; ta.z += s2[q][cl].z; ta.w += s2[q][cl].w; }
+      st4(part_alpha + (int64_t)blockIdx.y * f + c, ta, false, valid);
+    }
   }
 }
 
-// Pool forward: block = (column tile of 64, graph).  Rows of the graph are split over 4 groups.
+// Pool forward: block = (column tile of 64, graph); 16 float4 column lanes x 16 row groups.
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict__ gp, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ pooled, int32_t f, int mode,
-                                                       int32_t* __restrict__ argmax) {
-  __shared__ float s[4][64];
-  __shared__ int si[4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+                                                       int32_t* __restrict__ argmax, int vec) {
+  __shared__ float4 s[16][16];
+  __shared__ int4 si[16][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cl * 4;
+  const int valid = f - c;
+  const bool v4 = vec && valid >= 4;
   const int g = blockIdx.y;
   const int lo = gp[g], hi = gp[g + 1];
-  float acc = (mode == GCNX_POOL_MAX) ? -INFINITY : 0.f;
-  int arg = lo;
-  if (c < f) {
-    for (int r = lo + rg; r < hi; r += 4) {
-      const float v = x[(int64_t)r * ldx + c];
+  const float init = (mode == GCNX_POOL_MAX) ? -INFINITY : 0.f;
+  float4 acc = make_float4(init, init, init, init);
+  int4 arg = make_int4(lo, lo, lo, lo);
+  if (valid > 0) {
+#pragma unroll 4
+    for (int r = lo + rg; r < hi; r += 16) {
+      const float4 v = ld4(x + (int64_t)r * ldx + c, v4, valid);
       if (mode == GCNX_POOL_MAX) {
-        if (v > acc) { acc = v; arg = r; }
+        if (v.x > acc.x) { acc.x = v.x; arg.x = r; }
+        if (v.y > acc.y) { acc.y = v.y; arg.y = r; }
+        if (v.z > acc.z) { acc.z = v.z; arg.z = r; }
+        if (v.w > acc.w) { acc.w = v.w; arg.w = r; }
       } else {
-        acc += v;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
   }
   s[rg][cl] = acc;
   si[rg][cl] = arg;
   __syncthreads();
-  if (rg == 0 && c < f) {
-    float out;
+  if (rg == 0 && valid > 0) {
+    float4 o = s[0][cl];
+    int4 a = si[0][cl];
     if (mode == GCNX_POOL_MAX) {
-      out = s[0][cl];
-      int a = si[0][cl];
-      // first maximal row wins (matches argmax of the oracle): strict > over ascending row groups
-      // is not enough because groups interleave rows, so break ties on the smaller row index.
-      for (int q = 1; q < 4; ++q) {
-        const float v = s[q][cl];
-        const int ai = si[q][cl];
-        if (v > out || (v == out && ai < a)) { out = v; a = ai; }
+      // first maximal row wins (argmax of the oracle): row groups interleave rows, so ties break
+      // on the smaller row index.
+      for (int q = 1; q < 16; ++q) {
+        const float4 v = s[q][cl];
+        const int4 ai = si[q][cl];
+        if (v.x > o.x || (v.x == o.x && ai.x < a.x)) { o.x = v.x; a.x = ai.x; }
+        if (v.y > o.y || (v.y == o.y && ai.y < a.y)) { o.y = v.y; a.y = ai.y; }
+        if (v.z > o.z || (v.z == o.z && ai.z < a.z)) { o.z = v.z; a.z = ai.z; }
+        if (v.w > o.w || (v.w == o.w && ai.w < a.w)) { o.w = v.w; a.w = ai.w; }
       }
-      if (hi == lo) { out = 0.f; a = lo; }
-      if (argmax) argmax[(int64_t)g * f + c] = a;
+      if (hi == lo) { o = make_float4(0.f, 0.f, 0.f, 0.f); a = make_int4(lo, lo, lo, lo); }
+      if (argmax) {
+        int32_t* ap = argmax + (int64_t)g * f + c;
+        if (valid > 0) ap[0] = a.x;
+        if (valid > 1) ap[1] = a.y;
+        if (valid > 2) ap[2] = a.z;
+        if (valid > 3) ap[3] = a.w;
+      }
     } else {
-      out = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
-      if (mode == GCNX_POOL_AVG && hi > lo) out /= (float)(hi - lo);
+      for (int q = 1; q < 16; ++q) { o.x += s[q][cl].x; o.y += s[q][cl].y; o.z += s[q][cl].z; o.w += s[q][cl].w; }
+      if (mode == GCNX_POOL_AVG && hi > lo) {
+        const float inv = (float)(hi - lo);
+        o.x /= inv; o.y /= inv; o.z /= inv; o.w /= inv;
+      }
     }
-    pooled[(int64_t)g * f + c] = out;
+    st4(pooled + (int64_t)g * f + c, o, false, valid);
   }
 }
 
@@ -181,6 +230,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float* out, const float* y,
                 int64_t ldy, float* dz, int64_t lddz, int act, const float* alpha, float* out_alpha) {
   const bool fuse = (dz != nullptr);
+  auto al = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  const int vec = al(x) && ldx % 4 == 0 && (!fuse || (al(y) && ldy % 4 == 0 && al(dz) && lddz % 4 == 0));
   const int nchunks = gcnx_cdiv(n, kColsumRows);
   const bool want_alpha = fuse && act == GCNX_ACT_PRELU && out_alpha;
   const size_t need = (size_t)nchunks * f * sizeof(float) * (want_alpha ? 2 : 1);
@@ -200,23 +251,24 @@ int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f
   dim3 grid(gcnx_cdiv(f, 64), nchunks);
   if (fuse)
     hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, ctx->stream, x, ldx, n, f, (int64_t)kColsumRows,
-                       part, y, ldy, dz, lddz, act, alpha, part_a);
+                       part, y, ldy, dz, lddz, act, alpha, part_a, vec);
   else
     hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, ctx->stream, x, ldx, n, f, (int64_t)kColsumRows,
-                       part, nullptr, (int64_t)0, nullptr, (int64_t)0, 0, nullptr, nullptr);
+                       part, nullptr, (int64_t)0, nullptr, (int64_t)0, 0, nullptr, nullptr, vec);
   GCNX_LAUNCH_OK(ctx);
   if (nchunks > 1) {
+    const int vec2 = f % 4 == 0;   // the partials live in the 256-B aligned workspace with row stride f
     dim3 g2(gcnx_cdiv(f, 64), 1);
     if (out) {
       hipLaunchKernelGGL((colsum_kernel<false>), g2, dim3(256), 0, ctx->stream, (const float*)part, (int64_t)f,
                          (int64_t)nchunks, f, (int64_t)nchunks, out, nullptr, (int64_t)0, nullptr, (int64_t)0, 0,
-                         nullptr, nullptr);
+                         nullptr, nullptr, vec2);
       GCNX_LAUNCH_OK(ctx);
     }
     if (want_alpha) {
       hipLaunchKernelGGL((colsum_kernel<false>), g2, dim3(256), 0, ctx->stream, (const float*)part_a, (int64_t)f,
                          (int64_t)nchunks, f, (int64_t)nchunks, out_alpha, nullptr, (int64_t)0, nullptr, (int64_t)0,
-                         0, nullptr, nullptr);
+                         0, nullptr, nullptr, vec2);
       GCNX_LAUNCH_OK(ctx);
     }
   }
@@ -259,7 +311,8 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
   GCNX_REQUIRE(ctx, ldx >= f, "gcnx_segment_pool: leading dimension too small");
   GCNX_REQUIRE(ctx, mode != GCNX_POOL_MAX || argmax, "gcnx_segment_pool: MAX needs an argmax buffer");
   dim3 grid(gcnx_cdiv(f, 64), b);
-  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax);
+  const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
+  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
     const int2* __restrict__ graphs /* (row0, ng), largest first */, int nslabs, int act, int nwork, int n,
     int* __restrict__ queue) {
   constexpr int ITEM_COLS = FT * NPASS;     // columns per work item
+  constexpr bool EARLY_RP = NPASS == 1 && NI <= 3;   // early row-pointer prefetch only where registers allow
   constexpr int CPL = FT / 16;
   constexpr int PAD = kTileFloats / FT;      // index of the all-zero row
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
         nc0 = (n_item % nslabs) * ITEM_COLS;
       }
       tile_dma<FT / 4>(lds + ((k + 1) & 1) * kBufFloats, h, ldh, ng2.x, ng2.y, nc0);   // streams in during the reduction
-      if (!same && NPASS == 1) tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a_n, b_n);   // early: hides one round trip
+      if (!same && EARLY_RP) tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a_n, b_n);   // early: hides one round trip
     }
     // ---- reduce step k
     float4 bv[CPL];
@@ -350,11 +351,11 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
     if (!same) {
       // ---- rest of the index burst of the next item (the registers of this item are dead now)
       if (tid == 0) ctrl[(k / NPASS) & 1] = popped;
-      if (NPASS == 1) {
+      if (EARLY_RP) {
 #pragma unroll
         for (int t = 0; t < NI; ++t) { a[t] = a_n[t]; b[t] = b_n[t]; }
       } else {
-        tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a, b);     // register budget: no early prefetch in the 2-pass tier
+        tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a, b);     // register budget: no early prefetch in this tier
       }
       tile_load_entries<NI, WEIGHTED>(colidx, vals, ng2.x, PAD, last4, a, b, mc, mv);
       item = n_item;

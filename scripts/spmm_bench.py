@@ -31,8 +31,9 @@ alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, f, vals is not None)
 print(f"N={hb.n} nnz={hb.nnz} F={f} alg={alg/1e6:.1f} MB")
 for rnd in range(args.rounds):
     for slab in args.slabs.split(","):
-        for k_ in ("GCNX_SPMM_SLAB", "GCNX_SPMM_KERNEL"): os.environ.pop(k_, None)
-        if slab in ("rows", "tile"): os.environ["GCNX_SPMM_KERNEL"] = slab
+        for k_ in ("GCNX_SPMM_SLAB", "GCNX_SPMM_KERNEL", "GCNX_SPMM_ABLATE"): os.environ.pop(k_, None)
+        if slab.startswith("tile") and slab != "tile": os.environ["GCNX_SPMM_ABLATE"] = slab[4:]; os.environ["GCNX_SPMM_KERNEL"] = "tile"
+        elif slab in ("rows", "tile"): os.environ["GCNX_SPMM_KERNEL"] = slab
         elif slab != "0": os.environ["GCNX_SPMM_SLAB"] = slab; os.environ["GCNX_SPMM_KERNEL"] = "rows"
         for _ in range(3): D.spmm(ctx, a, h, bias, out, act="relu")
         e0 = ctx.event().record()
