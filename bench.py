@@ -52,6 +52,27 @@ def make_global_batch(workload, world, scaling):
     return hb, hidden
 
 
+def pmc_traffic(workload):
+    """HBM bytes per SpMM call from the committed rocprofv3 PMC passes (profiles/rNN/spmm_pmc.json, collected in
+    separate --pmc runs as MI355X_MICROARCH.md prescribes): 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
+    at half its bytes) + WRITE_SIZE, KiB -> bytes, summed over the kernels of one gcnx_spmm_csr call."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "spmm_pmc.json")))
+    if not files:
+        return None
+    try:
+        tab = json.load(open(files[-1])).get(workload)
+        if not tab:
+            return None
+        tot = 0.0
+        for counters in tab.values():
+            tot += 2.0 * counters.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0)
+            tot += counters.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0)
+        return tot * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(hb, hidden, params_flat, budget_s):
     """Rank 0, N=1 only: the fp32 C restatement (oracle/gcn_oracle.c, OpenMP) of the same step on
     the same batch, on this box's host cores, for about budget_s seconds."""
@@ -159,7 +180,7 @@ def main():
         alg3 = synth.spmm_algorithmic_bytes(hb3.n, hb3.nnz, 256, weighted=True)
         big = {"workload": "config3: N=1,000,000 nnz=10,000,000 F=256 fp32, weighted, bias+relu", "bound": "hbm",
                "achieved": alg3 / (ms3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg3, "avg_launch_us": 1e3 * ms3,
+               "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("block1m"), "algorithmic_bytes": alg3, "avg_launch_us": 1e3 * ms3,
                "launches": 20, "kernels": "spmm_tile_kernel x2 + spmm_rows_kernel (one gcnx_spmm_csr call)"}
         for t in (a3, h3, o3):
             pass
@@ -183,7 +204,7 @@ def main():
             "roofline": {"kernel": ("spmm_rows_kernel" if small else "spmm_tile_kernel(+rows)") +
                                    " (GCNConv aggregation, weighted, bias+relu fused)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": alg, "avg_launch_us": 1e3 * spmm_ms, "launches": iters},
+                         "traffic": pmc_traffic(args.workload), "algorithmic_bytes": alg, "avg_launch_us": 1e3 * spmm_ms, "launches": iters},
         }
         if big is not None:
             rec["roofline_config3"] = big

@@ -27,46 +27,61 @@ struct Epilogue {
   int accumulate;       // C += result
 };
 
-// Loads one 64x32 (or 32x64) operand tile into a k-major LDS image s[k][LD].
+// One 64x32 (or 32x64) operand tile, global -> registers (2 float4 per thread), then registers
+// -> the k-major LDS image s[k][LD].  Splitting the two lets the loads of tile t+1 fly during
+// the MFMAs of tile t.
 //   KCONTIG:  element(i,k) = p[i*ld + k]   (row index is the M/N index; k contiguous)
 //   !KCONTIG: element(i,k) = p[k*ld + i]   (k is the row index; M/N contiguous)
 template <bool KCONTIG>
-__device__ __forceinline__ void load_tile(const float* __restrict__ p, int64_t ld, int64_t i0, int64_t i_end,
-                                          int64_t k0, int64_t k_end, float (*s)[LD], int tid, bool vec_ok) {
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ p, int64_t ld, int64_t i0, int64_t i_end,
+                                           int64_t k0, int64_t k_end, int tid, bool vec_ok, float4 (&v)[2]) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int idx = tid + 256 * q;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KCONTIG) {
       const int i = idx >> 3, k = (idx & 7) * 4;
       const int64_t gi = i0 + i, gk = k0 + k;
       if (gi < i_end) {
         const float* src = p + gi * ld + gk;
         if (vec_ok && gk + 3 < k_end) {
-          v = *reinterpret_cast<const float4*>(src);
+          v[q] = *reinterpret_cast<const float4*>(src);
         } else {
-          if (gk + 0 < k_end) v.x = src[0];
-          if (gk + 1 < k_end) v.y = src[1];
-          if (gk + 2 < k_end) v.z = src[2];
-          if (gk + 3 < k_end) v.w = src[3];
+          if (gk + 0 < k_end) v[q].x = src[0];
+          if (gk + 1 < k_end) v[q].y = src[1];
+          if (gk + 2 < k_end) v[q].z = src[2];
+          if (gk + 3 < k_end) v[q].w = src[3];
         }
       }
-      s[k + 0][i] = v.x; s[k + 1][i] = v.y; s[k + 2][i] = v.z; s[k + 3][i] = v.w;
     } else {
       const int k = idx >> 4, i = (idx & 15) * 4;
       const int64_t gi = i0 + i, gk = k0 + k;
       if (gk < k_end) {
         const float* src = p + gk * ld + gi;
         if (vec_ok && gi + 3 < i_end) {
-          v = *reinterpret_cast<const float4*>(src);
+          v[q] = *reinterpret_cast<const float4*>(src);
         } else {
-          if (gi + 0 < i_end) v.x = src[0];
-          if (gi + 1 < i_end) v.y = src[1];
-          if (gi + 2 < i_end) v.z = src[2];
-          if (gi + 3 < i_end) v.w = src[3];
+          if (gi + 0 < i_end) v[q].x = src[0];
+          if (gi + 1 < i_end) v[q].y = src[1];
+          if (gi + 2 < i_end) v[q].z = src[2];
+          if (gi + 3 < i_end) v[q].w = src[3];
         }
       }
-      *reinterpret_cast<float4*>(&s[k][i]) = v;
+    }
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(float (*s)[LD], int tid, const float4 (&v)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q;
+    if (KCONTIG) {
+      const int i = idx >> 3, k = (idx & 7) * 4;
+      s[k + 0][i] = v[q].x; s[k + 1][i] = v[q].y; s[k + 2][i] = v[q].z; s[k + 3][i] = v[q].w;
+    } else {
+      const int k = idx >> 4, i = (idx & 15) * 4;
+      *reinterpret_cast<float4*>(&s[k][i]) = v[q];
     }
   }
 }
@@ -92,10 +107,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
+  float4 ra[2], rb[2];
+  if (kbeg < kend) {
+    fetch_tile<A_KCONTIG>(a, lda, m0, M, kbeg, kend, tid, vec_a, ra);
+    fetch_tile<B_KCONTIG>(b, ldb, n0, Nc, kbeg, kend, tid, vec_b, rb);
+  }
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    load_tile<A_KCONTIG>(a, lda, m0, M, k0, kend, As, tid, vec_a);
-    load_tile<B_KCONTIG>(b, ldb, n0, Nc, k0, kend, Bs, tid, vec_b);
+    store_tile<A_KCONTIG>(As, tid, ra);
+    store_tile<B_KCONTIG>(Bs, tid, rb);
     __syncthreads();
+    if (k0 + BK < kend) {   // next tile's loads are in flight during this tile's MFMAs
+      fetch_tile<A_KCONTIG>(a, lda, m0, M, k0 + BK, kend, tid, vec_a, ra);
+      fetch_tile<B_KCONTIG>(b, ldb, n0, Nc, k0 + BK, kend, tid, vec_b, rb);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const float av = As[2 * kk + fk][wm * 32 + fr];
@@ -145,11 +169,229 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if (grp == 0 && i < total) out[i] = (s[0][el] + s[1][el]) + (s[2][el] + s[3][el]);
 }
 
+// ----------------------------------------------------------------------------------------------
+// bf16 MFMA path (GCNX_PREC_BF16, GCNX_PREC_BF16X3): v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//
+// BF16X3 splits every fp32 operand into hi = bf16(x), lo = bf16(x - hi) and accumulates
+// hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-18 relative): fp32-grade results at three
+// MFMA passes, still far below the HBM time of these shapes (F <= a few hundred: AI 64-128
+// flop/B against a bf16 machine balance of ~300).  128x128 block tile, 4 waves of 64x64
+// (4x4 MFMA tiles, 64 accumulator registers), K steps of 32.  LDS images are [row][k] bf16 with
+// an 80-byte row stride: the operand read -- lane l takes the 16 bytes k = 8*(l>>4).. of row
+// l&15 -- is one ds_read_b128 per 16x32 fragment, bank-conflict-free.
+// The streamed operand is converted in registers on its way to LDS; the small weight operand is
+// converted (and transposed for X*W) once per call into a [col][k] bf16 image in the workspace.
+// X^T*dH (K = the N rows) transposes both operands 4x4 in registers.
+// ----------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HM = 128, HN = 128, HK = 32, HLD = 40;   // HLD bf16 elements = 80 B row stride
+
+__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// Weight operand -> [col][kpad] bf16 hi/lo images.  TRANSPOSE: out[o][i] = W[i][o] (X*W);
+// otherwise out[i][o] = W[i][o] (dH*W^T).  Columns k >= K are zero.
+__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, int fi, int fo, int transpose,
+                                                    int kpad, __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)ncol * kpad) return;
+  const int col = (int)(idx / kpad), k = (int)(idx % kpad);
+  float v = 0.f;
+  if (k < K) v = transpose ? w[(int64_t)k * fo + col] : w[(int64_t)col * fo + k];
+  const __bf16 h = (__bf16)v;
+  hi[idx] = h;
+  lo[idx] = (__bf16)(v - (float)h);
+}
+
+// MODE 0: C = A(fp32 [M,K], k contiguous) * B(bf16 image [Nc][kpad])           (X*W and dH*W^T)
+// MODE 1: C = A^T * B with A = fp32 [K,M] rows, B = fp32 [K,Nc] rows, split-K   (X^T*dH)
+template <int MODE, bool X3>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict__ a, int64_t lda,
+                                                        const float* __restrict__ bf, int64_t ldb,
+                                                        const __bf16* __restrict__ bhi, const __bf16* __restrict__ blo,
+                                                        int kpad, float* __restrict__ c, int64_t ldc, int64_t M,
+                                                        int32_t Nc, int64_t K, int64_t kchunk, Epilogue ep, int vec_a,
+                                                        int vec_b) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[X3 ? 2 : 1][HM][HLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[X3 ? 2 : 1][HN][HLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * HM;
+  const int64_t n0 = (int64_t)blockIdx.x * HN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = min(K, kbeg + kchunk);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += HK) {
+    if (MODE == 0) {
+      // A tile 128 rows x 32 k (fp32): thread -> rows (tid>>3) + 32*q, k = (tid&7)*4
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = (tid >> 3) + 32 * q, k = (tid & 7) * 4;
+        const int64_t gr = m0 + r, gk = k0 + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < M) {
+          const float* src = a + gr * lda + gk;
+          if (vec_a && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk + 0 < kend) v.x = src[0];
+            if (gk + 1 < kend) v.y = src[1];
+            if (gk + 2 < kend) v.z = src[2];
+            if (gk + 3 < kend) v.w = src[3];
+          }
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(&As[0][r][k]) = hi;
+        if (X3) *reinterpret_cast<bf16x4*>(&As[X3 ? 1 : 0][r][k]) = lo;
+      }
+      // B tile 128 cols x 32 k from the bf16 images: thread -> col (tid>>2) + 64*q, k = (tid&3)*8
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int col = (tid >> 2) + 64 * q, k = (tid & 3) * 8;
+        const int64_t gc = n0 + col;
+        bf16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+        if (gc < Nc) {   // kpad is a multiple of 32 and zero padded: no k guard
+          h = *reinterpret_cast<const bf16x8*>(bhi + gc * kpad + k0 + k);
+          if (X3) l = *reinterpret_cast<const bf16x8*>(blo + gc * kpad + k0 + k);
+        }
+        *reinterpret_cast<bf16x8*>(&Bs[0][col][k]) = h;
+        if (X3) *reinterpret_cast<bf16x8*>(&Bs[X3 ? 1 : 0][col][k]) = l;
+      }
+    } else {
+      // both operands are [k][m] fp32 rows: 4 k-rows x 4 columns per thread, transposed in registers
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float* p = which == 0 ? a : bf;
+        const int64_t ld = which == 0 ? lda : ldb;
+        const int64_t i0 = which == 0 ? m0 : n0, iend = which == 0 ? M : (int64_t)Nc;
+        const bool vec = which == 0 ? vec_a : vec_b;
+        const int kq = (tid >> 5) * 4, i = (tid & 31) * 4;
+        float4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gk = k0 + kq + r, gi = i0 + i;
+          v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gk < kend) {
+            const float* src = p + gk * ld + gi;
+            if (vec && gi + 3 < iend) v[r] = *reinterpret_cast<const float4*>(src);
+            else {
+              if (gi + 0 < iend) v[r].x = src[0];
+              if (gi + 1 < iend) v[r].y = src[1];
+              if (gi + 2 < iend) v[r].z = src[2];
+              if (gi + 3 < iend) v[r].w = src[3];
+            }
+          }
+        }
+        const float4 t0 = make_float4(v[0].x, v[1].x, v[2].x, v[3].x), t1 = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+        const float4 t2 = make_float4(v[0].z, v[1].z, v[2].z, v[3].z), t3 = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        const float4 tt[4] = {t0, t1, t2, t3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x4 hi, lo;
+          split4(tt[j], hi, lo);
+          __bf16(*dst)[HM][HLD] = which == 0 ? As : Bs;
+          *reinterpret_cast<bf16x4*>(&dst[0][i + j][kq]) = hi;
+          if (X3) *reinterpret_cast<bf16x4*>(&dst[X3 ? 1 : 0][i + j][kq]) = lo;
+        }
+      }
+    }
+    __syncthreads();
+    bf16x8 ah[4], bh[4], al[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][wm * 64 + i * 16 + fr][fq * 8]);
+      bh[i] = *reinterpret_cast<const bf16x8*>(&Bs[0][wn * 64 + i * 16 + fr][fq * 8]);
+      if (X3) {
+        al[i] = *reinterpret_cast<const bf16x8*>(&As[X3 ? 1 : 0][wm * 64 + i * 16 + fr][fq * 8]);
+        bl[i] = *reinterpret_cast<const bf16x8*>(&Bs[X3 ? 1 : 0][wn * 64 + i * 16 + fr][fq * 8]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (X3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  // C/D map of a 16x16 tile: col = lane & 15, row = (lane >> 4)*4 + reg.
+  float* cz = c + (gridDim.z > 1 ? (int64_t)blockIdx.z * M * ldc : 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t col = n0 + wn * 64 + j * 16 + fr;
+    if (col >= Nc) continue;
+    const float bias = (ep.bias ? ep.bias[col] : 0.f);
+    const float alpha = (ep.alpha ? ep.alpha[col] : 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (row >= M) continue;
+        float v = acc[i][j][r] + bias;
+        if (ep.act == GCNX_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (ep.act == GCNX_ACT_PRELU) v = v > 0.f ? v : alpha * v;
+        if (ep.mask) v = ep.mask[row * ep.ldmask + col] > 0.f ? v : 0.f;
+        float* dst = cz + row * ldc + col;
+        if (ep.accumulate) v += *dst;
+        *dst = v;
+      }
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
 int gcnx_colsum(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float* out);  // reduce.hip
+
+namespace {
+
+// X*W (transpose = 1) and dH*W^T (transpose = 0) on the bf16 MFMA path.
+int launch_bf16_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose,
+                   float* c, int64_t ldc, int64_t m, int prec, const Epilogue& ep) {
+  const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
+  const int kpad = ((K + HK - 1) / HK) * HK;
+  const size_t img = (size_t)ncol * kpad;   // elements per image
+  int rc = gcnx_ws_reserve(ctx, 2 * img * sizeof(__bf16) + 256);
+  if (rc) return rc;
+  __bf16* hi = (__bf16*)ctx->ws;
+  __bf16* lo = hi + ((img + 127) / 128) * 128;
+  hipLaunchKernelGGL(wprep_kernel, dim3(gcnx_cdiv((long long)img, 256)), dim3(256), 0, ctx->stream, w, fi, fo, transpose,
+                     kpad, hi, lo);
+  GCNX_LAUNCH_OK(ctx);
+  dim3 grid(gcnx_cdiv(ncol, HN), gcnx_cdiv(m, HM), 1);
+  const int va = al16(a) && lda % 4 == 0;
+  if (prec == GCNX_PREC_BF16X3)
+    hipLaunchKernelGGL((gemm_bf16_kernel<0, true>), grid, dim3(256), 0, ctx->stream, a, lda, (const float*)nullptr,
+                       (int64_t)0, hi, lo, kpad, c, ldc, m, ncol, (int64_t)K, (int64_t)kpad + HK, ep, va, 0);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<0, false>), grid, dim3(256), 0, ctx->stream, a, lda, (const float*)nullptr,
+                       (int64_t)0, hi, lo, kpad, c, ldc, m, ncol, (int64_t)K, (int64_t)kpad + HK, ep, va, 0);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -159,12 +401,12 @@ int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const 
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm: negative size");
   GCNX_REQUIRE(ctx, act >= GCNX_ACT_NONE && act <= GCNX_ACT_PRELU, "gcnx_gemm: unknown activation %d", act);
   GCNX_REQUIRE(ctx, act != GCNX_ACT_PRELU || alpha, "gcnx_gemm: PReLU needs alpha");
-  if (prec != GCNX_PREC_F32)
-    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm: precision %d not built yet (only GCNX_PREC_F32)", prec);
+  GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm: unknown precision %d", prec);
   if (n == 0 || fo == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, x && w && out, "gcnx_gemm: NULL pointer");
   GCNX_REQUIRE(ctx, ldx >= fi && ldo >= fo, "gcnx_gemm: leading dimension too small");
   Epilogue ep{bias, act == GCNX_ACT_PRELU ? alpha : nullptr, nullptr, 0, act, 0};
+  if (prec != GCNX_PREC_F32) return launch_bf16_nn(ctx, x, ldx, w, fi, fo, 1, out, ldo, n, prec, ep);
   dim3 grid(gcnx_cdiv(fo, BN), gcnx_cdiv(n, BM), 1);
   const int va = al16(x) && ldx % 4 == 0, vb = al16(w) && fo % 4 == 0;
   hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, ctx->stream, x, ldx, w, (int64_t)fo, out,
@@ -177,8 +419,7 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
                  int32_t fi, int32_t fo, int prec, int accumulate, const float* y_mask, int64_t ldy, float* db) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dx: negative size");
-  if (prec != GCNX_PREC_F32)
-    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm_dx: precision %d not built yet (only GCNX_PREC_F32)", prec);
+  GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dx: unknown precision %d", prec);
   GCNX_REQUIRE(ctx, !(accumulate && (y_mask || db)), "gcnx_gemm_dx: accumulate cannot be combined with mask/db");
   if (n == 0 || fi == 0) {
     if (db && fi > 0) GCNX_HIP(ctx, hipMemsetAsync(db, 0, (size_t)fi * 4, ctx->stream));
@@ -188,6 +429,12 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
   GCNX_REQUIRE(ctx, lddh >= fo && lddx >= fi && (!y_mask || ldy >= fi), "gcnx_gemm_dx: leading dimension too small");
   // dX[n, i] = sum_o dH[n, o] * W[i, o]:  A = dH (k contiguous), B[k=o][j=i] = W[i*fo + o] (k contiguous).
   Epilogue ep{nullptr, nullptr, y_mask, ldy, GCNX_ACT_NONE, accumulate};
+  if (prec != GCNX_PREC_F32) {
+    int rc = launch_bf16_nn(ctx, dh, lddh, w, fi, fo, 0, dx, lddx, n, prec, ep);
+    if (rc) return rc;
+    if (db) return gcnx_colsum(ctx, dx, lddx, n, fi, db);
+    return GCNX_OK;
+  }
   dim3 grid(gcnx_cdiv(fi, BN), gcnx_cdiv(n, BM), 1);
   const int va = al16(dh) && lddh % 4 == 0, vb = al16(w) && fo % 4 == 0;
   hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, ctx->stream, dh, lddh, w, (int64_t)fo, dx,
@@ -201,8 +448,7 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
                  int32_t fi, int32_t fo, int prec) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dw: negative size");
-  if (prec != GCNX_PREC_F32)
-    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm_dw: precision %d not built yet (only GCNX_PREC_F32)", prec);
+  GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dw: unknown precision %d", prec);
   if (fi == 0 || fo == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, dw != nullptr, "gcnx_gemm_dw: dw is NULL");
   if (n == 0) {
@@ -212,8 +458,42 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   GCNX_REQUIRE(ctx, x && dh, "gcnx_gemm_dw: NULL pointer");
   GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo, "gcnx_gemm_dw: leading dimension too small");
   // dW[i, o] = sum_n X[n, i] * dH[n, o]: A[i][k=n] = X[n*ldx + i], B[k=n][o] = dH[n*lddh + o].
+  if (prec != GCNX_PREC_F32) {
+    const int tiles_h = gcnx_cdiv(fi, HM) * gcnx_cdiv(fo, HN);
+    int ns = (int)((4LL * ctx->num_cus + tiles_h - 1) / tiles_h);
+    const int64_t ksteps_h = (n + HK - 1) / HK;
+    if (ns > ksteps_h) ns = (int)ksteps_h;
+    if (ns < 1) ns = 1;
+    const int64_t kchunk_h = ((ksteps_h + ns - 1) / ns) * HK;
+    ns = (int)((n + kchunk_h - 1) / kchunk_h);
+    Epilogue eph{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0};
+    float* tgt = dw;
+    if (ns > 1) {
+      int rc = gcnx_ws_reserve(ctx, (size_t)ns * fi * fo * sizeof(float));
+      if (rc) return rc;
+      tgt = (float*)ctx->ws;
+    }
+    dim3 gridh(gcnx_cdiv(fo, HN), gcnx_cdiv(fi, HM), ns);
+    const int vah = al16(x) && ldx % 4 == 0, vbh = al16(dh) && lddh % 4 == 0;
+    if (prec == GCNX_PREC_BF16X3)
+      hipLaunchKernelGGL((gemm_bf16_kernel<1, true>), gridh, dim3(256), 0, ctx->stream, x, ldx, dh, lddh,
+                         (const __bf16*)nullptr, (const __bf16*)nullptr, 0, tgt, (int64_t)fo, (int64_t)fi, fo, n, kchunk_h,
+                         eph, vah, vbh);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<1, false>), gridh, dim3(256), 0, ctx->stream, x, ldx, dh, lddh,
+                         (const __bf16*)nullptr, (const __bf16*)nullptr, 0, tgt, (int64_t)fo, (int64_t)fi, fo, n, kchunk_h,
+                         eph, vah, vbh);
+    GCNX_LAUNCH_OK(ctx);
+    if (ns > 1) {
+      const int64_t total = (int64_t)fi * fo;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(total, 64)), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
+                         total, ns, dw, total);
+      GCNX_LAUNCH_OK(ctx);
+    }
+    return GCNX_OK;
+  }
   const int tiles = gcnx_cdiv(fi, BM) * gcnx_cdiv(fo, BN);
-  int nsplit = (int)((2LL * ctx->num_cus + tiles - 1) / tiles);   // ~2 workgroups per CU
+  int nsplit = (int)((4LL * ctx->num_cus + tiles - 1) / tiles);   // ~4 workgroups per CU
   const int64_t ksteps = (n + BK - 1) / BK;
   if (nsplit > ksteps) nsplit = (int)ksteps;
   if (nsplit < 1) nsplit = 1;

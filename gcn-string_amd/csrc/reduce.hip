@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // Pool forward: block = (column tile of 64, graph); 16 float4 column lanes x 16 row groups.
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict__ gp, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ pooled, int32_t f, int mode,
-                                                       int32_t* __restrict__ argmax, int vec) {
+                                                       int32_t* __restrict__ argmax, int vec, int nsplit) {
+  // nsplit > 1 (sum/avg only): blockIdx.z owns a slice of the graph's rows and writes a partial
+  // row sum to pooled + z*B*f (the caller's workspace); pool_combine_kernel adds them in order.
   __shared__ float4 s[16][16];
   __shared__ int4 si[16][16];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
@@ -90,7 +92,14 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
   const int valid = f - c;
   const bool v4 = vec && valid >= 4;
   const int g = blockIdx.y;
-  const int lo = gp[g], hi = gp[g + 1];
+  int lo = gp[g], hi = gp[g + 1];
+  const int glo = lo, ghi = hi;
+  if (nsplit > 1) {
+    const int per = (hi - lo + nsplit - 1) / nsplit;
+    lo = min(hi, lo + (int)blockIdx.z * per);
+    hi = min(hi, lo + per);
+    pooled += (int64_t)blockIdx.z * gridDim.y * f;
+  }
   const float init = (mode == GCNX_POOL_MAX) ? -INFINITY : 0.f;
   float4 acc = make_float4(init, init, init, init);
   int4 arg = make_int4(lo, lo, lo, lo);
@@ -135,8 +144,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
       }
     } else {
       for (int q = 1; q < 16; ++q) { o.x += s[q][cl].x; o.y += s[q][cl].y; o.z += s[q][cl].z; o.w += s[q][cl].w; }
-      if (mode == GCNX_POOL_AVG && hi > lo) {
-        const float inv = (float)(hi - lo);
+      if (mode == GCNX_POOL_AVG && ghi > glo && nsplit <= 1) {
+        const float inv = (float)(ghi - glo);
         o.x /= inv; o.y /= inv; o.z /= inv; o.w /= inv;
       }
     }
@@ -144,13 +153,30 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
   }
 }
 
+// Second stage of the split pool: pooled[g][c] = sum_z part[z][g][c] (z ascending), / n_g for AVG.
+__global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restrict__ part, const int32_t* __restrict__ gp,
+                                                           float* __restrict__ pooled, int32_t b, int32_t f, int nsplit,
+                                                           int mode) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)b * f) return;
+  float acc = 0.f;
+  for (int z = 0; z < nsplit; ++z) acc += part[(int64_t)z * b * f + i];
+  if (mode == GCNX_POOL_AVG) {
+    const int g = (int)(i / f);
+    const int cnt = gp[g + 1] - gp[g];
+    if (cnt > 0) acc /= (float)cnt;
+  }
+  pooled[i] = acc;
+}
+
 // Pool backward (+ optional fused ReLU mask of the layer that produced the pooled tensor).
-// One wave per row; the row's graph is found by binary search in graph_ptr.
+// One wave per row (64 float4 lanes cover 256 columns per pass); the row's graph is found by
+// binary search in graph_ptr.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const int32_t* __restrict__ gp, int32_t b,
                                                        const float* __restrict__ dp, float* __restrict__ dx,
                                                        int64_t lddx, int32_t n, int32_t f, int mode,
                                                        const int32_t* __restrict__ argmax, const float* __restrict__ y,
-                                                       int64_t ldy) {
+                                                       int64_t ldy, int vec) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
@@ -161,11 +187,26 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const int32_t* __restrict
   }
   const int g = lo;
   const float scale = (mode == GCNX_POOL_AVG) ? 1.0f / (float)(gp[g + 1] - gp[g]) : 1.0f;
-  for (int c = lane; c < f; c += 64) {
-    float v = dp[(int64_t)g * f + c] * scale;
-    if (mode == GCNX_POOL_MAX && argmax[(int64_t)g * f + c] != r) v = 0.f;
-    if (y && !(y[(int64_t)r * ldy + c] > 0.f)) v = 0.f;
-    dx[(int64_t)r * lddx + c] = v;
+  for (int c = lane * 4; c < f; c += 256) {
+    const int valid = f - c;
+    const bool v4 = vec && valid >= 4;
+    float4 v = ld4(dp + (int64_t)g * f + c, vec && f % 4 == 0 && valid >= 4, valid);
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    if (mode == GCNX_POOL_MAX) {
+      const int32_t* ap = argmax + (int64_t)g * f + c;
+      if (ap[0] != r) v.x = 0.f;
+      if (valid > 1 && ap[1] != r) v.y = 0.f;
+      if (valid > 2 && ap[2] != r) v.z = 0.f;
+      if (valid > 3 && ap[3] != r) v.w = 0.f;
+    }
+    if (y) {
+      const float4 yy = ld4(y + (int64_t)r * ldy + c, v4, valid);
+      if (!(yy.x > 0.f)) v.x = 0.f;
+      if (!(yy.y > 0.f)) v.y = 0.f;
+      if (!(yy.z > 0.f)) v.z = 0.f;
+      if (!(yy.w > 0.f)) v.w = 0.f;
+    }
+    st4(dx + (int64_t)r * lddx + c, v, v4, valid);
   }
 }
 
@@ -310,9 +351,29 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
   GCNX_REQUIRE(ctx, graph_ptr && x && pooled, "gcnx_segment_pool: NULL pointer");
   GCNX_REQUIRE(ctx, ldx >= f, "gcnx_segment_pool: leading dimension too small");
   GCNX_REQUIRE(ctx, mode != GCNX_POOL_MAX || argmax, "gcnx_segment_pool: MAX needs an argmax buffer");
-  dim3 grid(gcnx_cdiv(f, 64), b);
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
-  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec);
+  // Few graphs (an E. coli batch has 32) cannot fill 256 CUs with one workgroup per (graph, column
+  // tile): slice each graph's rows over blockIdx.z and combine the partial sums in a second launch.
+  const int base_wgs = gcnx_cdiv(f, 64) * b;
+  int nsplit = 1;
+  if (mode != GCNX_POOL_MAX && base_wgs < 2 * ctx->num_cus) {
+    nsplit = (2 * ctx->num_cus + base_wgs - 1) / base_wgs;
+    if (nsplit > 16) nsplit = 16;
+  }
+  if (nsplit > 1) {
+    int rc = gcnx_ws_reserve(ctx, (size_t)nsplit * b * f * sizeof(float));
+    if (rc) return rc;
+    dim3 grid(gcnx_cdiv(f, 64), b, nsplit);
+    hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, (float*)ctx->ws, f, mode,
+                       argmax, vec, nsplit);
+    GCNX_LAUNCH_OK(ctx);
+    hipLaunchKernelGGL(pool_combine_kernel, dim3(gcnx_cdiv((int64_t)b * f, 256)), dim3(256), 0, ctx->stream,
+                       (const float*)ctx->ws, graph_ptr, pooled, b, f, nsplit, mode);
+    GCNX_LAUNCH_OK(ctx);
+    return GCNX_OK;
+  }
+  dim3 grid(gcnx_cdiv(f, 64), b);
+  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec, 1);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -331,8 +392,10 @@ int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* 
   GCNX_REQUIRE(ctx, graph_ptr && dpooled && dx, "gcnx_segment_pool_bwd: NULL pointer");
   GCNX_REQUIRE(ctx, lddx >= f && (!y || ldy >= f), "gcnx_segment_pool_bwd: leading dimension too small");
   GCNX_REQUIRE(ctx, mode != GCNX_POOL_MAX || argmax, "gcnx_segment_pool_bwd: MAX needs the argmax buffer");
+  auto al = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  const int vec = al(dx) && lddx % 4 == 0 && al(dpooled) && (!y || (al(y) && ldy % 4 == 0));
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, graph_ptr, b, dpooled, dx,
-                     lddx, n, f, mode, argmax, y, ldy);
+                     lddx, n, f, mode, argmax, y, ldy, vec);
   GCNX_LAUNCH_OK(ctx);
   if (db) return gcnx_colsum(ctx, dx, lddx, n, f, db);
   return GCNX_OK;

@@ -39,6 +39,7 @@ namespace {
 
 constexpr int kRowsPerChunk = 32;    // rows per workgroup (large inputs; plan chunks)
 constexpr int kRowsPerChunkSmall = 8;   // small inputs: more, shorter workgroups (launch-latency regime)
+constexpr int kSlab = 32;             // widest column slab of the tile kernel
 constexpr int kStageCap = 2048;      // CSR entries staged in LDS per chunk (overflow -> global)
 
 __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
@@ -82,25 +83,19 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && col_ok) bv = *reinterpret_cast<const float4*>(bias + c);
 
-  for (int r = r0 + wave; r < r1; r += 4) {
-    const int a = s_rp[r - r0] - e0, b = s_rp[r - r0 + 1] - e0;  // chunk-relative entry range
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col_ok) {
-#pragma unroll 4
-      for (int e = a + g; e < b; e += G) {
-        int cidx;
-        float v = 1.0f;
-        if (e < kStageCap) {
-          cidx = s_col[e];
-          if (WEIGHTED) v = s_val[e];
-        } else {
-          cidx = colidx[e0 + e];
-          if (WEIGHTED) v = vals[e0 + e];
-        }
-        const float4 hv = *reinterpret_cast<const float4*>(h + (int64_t)cidx * ldh + c);
-        acc = WEIGHTED ? f4_fma(v, hv, acc) : f4_add(acc, hv);
-      }
+  // Two rows per trip: their gathers are independent, so both sets of loads are in flight
+  // before either is accumulated (the per-row dependent latency is what bounds small inputs).
+  auto entry = [&](int e, int& cidx, float& v) {
+    v = 1.0f;
+    if (e < kStageCap) {
+      cidx = s_col[e];
+      if (WEIGHTED) v = s_val[e];
+    } else {
+      cidx = colidx[e0 + e];
+      if (WEIGHTED) v = vals[e0 + e];
     }
+  };
+  auto finish = [&](float4 acc, int r) {
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
       acc.x += __shfl_xor(acc.x, off);
@@ -108,18 +103,45 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
       acc.z += __shfl_xor(acc.z, off);
       acc.w += __shfl_xor(acc.w, off);
     }
-    if (g == 0 && col_ok) {
+    if (g == 0 && col_ok && r < r1) {
       acc = f4_add(acc, bv);
       if (act == GCNX_ACT_RELU) {
         acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
       }
       *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
     }
+  };
+  for (int r = r0 + wave; r < r1; r += 8) {
+    const int rB = r + 4;                                          // second row of this trip (may be past the chunk)
+    const int aA = s_rp[r - r0] - e0, bA = s_rp[r - r0 + 1] - e0;  // chunk-relative entry ranges
+    const int aB = rB < r1 ? s_rp[rB - r0] - e0 : 0, bB = rB < r1 ? s_rp[rB - r0 + 1] - e0 : 0;
+    float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+    if (col_ok) {
+      int eA = aA + g, eB = aB + g;
+      while (eA < bA || eB < bB) {                                 // wave-divergent only in the tails
+        float4 hA[2], hB[2];
+        float vA[2], vB[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          int cA = 0, cB = 0;
+          vA[u] = vB[u] = 0.f;
+          hA[u] = hB[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (eA + u * G < bA) { entry(eA + u * G, cA, vA[u]); hA[u] = *reinterpret_cast<const float4*>(h + (int64_t)cA * ldh + c); }
+          if (eB + u * G < bB) { entry(eB + u * G, cB, vB[u]); hB[u] = *reinterpret_cast<const float4*>(h + (int64_t)cB * ldh + c); }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (eA + u * G < bA) accA = WEIGHTED ? f4_fma(vA[u], hA[u], accA) : f4_add(accA, hA[u]);
+          if (eB + u * G < bB) accB = WEIGHTED ? f4_fma(vB[u], hB[u], accB) : f4_add(accB, hB[u]);
+        }
+        eA += 2 * G;
+        eB += 2 * G;
+      }
+    }
+    finish(accA, r);
+    finish(accB, rB);
   }
 }
-
-
-constexpr int kSlab = 32;                 // widest column slab of the tile kernel
 
 // Broadcast of lane J's value to the lanes of its row group as a DPP quad_perm move (VALU; no
 // LDS traffic).  LPR >= 4: every lane of the quad reads lane J.  LPR == 2: two rows share a

@@ -202,13 +202,37 @@ def test_gemm_backward_parity_and_fusions(ctx):
     assert np.array_equal(a1.numpy(), a2.numpy())
 
 
-def test_gemm_unbuilt_precision_fails_loudly(ctx):
-    from gcnx import _lib, device as D
-    x = ctx.zeros((8, 8)); out = ctx.zeros((8, 8))
-    try:
-        D.gemm(ctx, x, x, None, out, prec="bf16x3")
-    except _lib.GcnxError as e:      # allowed until the bf16 kernels land: must not silently fall back
-        assert e.code == 5
+def _bf16_round(x):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 on the host (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+@pytest.mark.parametrize("n,fi,fo", [(1000, 128, 128), (77, 10, 6), (4096, 256, 256), (333, 32, 2), (300, 130, 70)])
+def test_gemm_bf16_mfma_paths(ctx, n, fi, fo):
+    """The bf16 MFMA weight GEMM of north_star.  bf16x3 (hi/lo split, 3 passes) is held to the
+    1e-4 fp32 bar; plain bf16 is exact against an oracle fed bf16-rounded operands (the products
+    are exact in fp32, only the accumulation order differs) and within 2e-2 of the fp32 result."""
+    from gcnx import device as D
+    rng = np.random.default_rng(n + fi)
+    x = rng.standard_normal((n, fi), dtype=np.float32); w = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
+    dh = rng.standard_normal((n, fo), dtype=np.float32); b = rng.standard_normal(fo).astype(np.float32)
+    ym = rng.standard_normal((n, fi), dtype=np.float32)
+    d_x, d_w, d_dh, d_b, d_ym = (ctx.to_device(v) for v in (x, w, dh, b, ym))
+    x64, w64, dh64 = x.astype(np.float64), w.astype(np.float64), dh.astype(np.float64)
+    xb, wb, dhb = (_bf16_round(v).astype(np.float64) for v in (x, w, dh))
+    out = ctx.empty((n, fo)); dx = ctx.empty((n, fi)); dw = ctx.empty((fi, fo)); db = ctx.empty(fi)
+    for prec, tol, (ax, aw, adh) in (("bf16x3", TOL, (x64, w64, dh64)), ("bf16", 2e-5, (xb, wb, dhb))):
+        D.gemm(ctx, d_x, d_w, d_b, out, act="relu", prec=prec)
+        assert rel_err(out.numpy(), np.maximum(ax @ aw + b, 0)) < tol, prec
+        D.gemm_dx(ctx, d_dh, d_w, dx, prec=prec, y_mask=d_ym, db=db)
+        ref = (adh @ aw.T) * (ym > 0)
+        assert rel_err(dx.numpy(), ref) < tol and rel_err(db.numpy(), ref.sum(0)) < max(tol, 1e-5), prec
+        D.gemm_dw(ctx, d_x, d_dh, dw, prec=prec)
+        assert rel_err(dw.numpy(), ax.T @ adh) < tol, prec
+    D.gemm(ctx, d_x, d_w, None, out, prec="bf16")
+    assert rel_err(out.numpy(), x64 @ w64) < 2e-2
 
 
 @pytest.mark.parametrize("mode", ["sum", "avg", "max"])

@@ -46,6 +46,20 @@ def test_gcn2_matches_golden_vectors(ctx, name):
     assert rel_err(m(batch, training=False), g["probs"]) < TOL
 
 
+@pytest.mark.parametrize("name", [n for n in GOLDEN if "tiny_weighted" in n or "f128" in n or "ecoli" in n])
+def test_gcn2_bf16x3_gemm_meets_the_fp32_bar(ctx, name):
+    """Whole step with the bf16x3 MFMA GEMMs against the fp64 golden vectors at the same 1e-4."""
+    g = load_golden(name)
+    m, batch, hb = _model_from_golden(ctx, g)
+    m.prec = "bf16x3"
+    m.loss_and_grads(batch, None)
+    loss, acc = m.fetch_metrics(hb.n_graphs)
+    assert abs(loss - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
+    assert rel_err(m._bufs["probs"].numpy(), g["probs"]) < TOL
+    for k, gk in m.gradients().items():
+        assert rel_err(gk, g["g_" + k]) < TOL, k
+
+
 def test_disjoint_loader_to_model_end_to_end(ctx):
     """config 1 plumbing: Graph objects -> DisjointLoader -> ((x, a, i), y) -> device COO->CSR ->
     device gcn_filter -> model, vs the oracle fed by its own collate."""
