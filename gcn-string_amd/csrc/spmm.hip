@@ -205,6 +205,17 @@ constexpr int kCtrlFloat = kTileFloats + 64;      // two int slots for queue han
 constexpr int kCap32 = kTilePieces / 8;           // 632 rows at FT = 32
 constexpr int kSpan = kPWaves * 16;               // rows a workgroup covers per wave iteration (16 rows per wave)
 
+// Tile rows are gathered at random, so a ds_read_b128 pass (16 lanes = 4 quads = 4 rows x 64 B)
+// collides whenever two of its rows start in the same bank quarter.  With plain 128-B rows only
+// the row parity picks the quarter pair (2.75x the ideal LDS cycles, simulated and consistent
+// with SQ_LDS_BANK_CONFLICT); XOR-ing the 16-byte chunk index with bits of the row index spreads
+// rows over all four quarters (2.1x).  LDS-DMA writes linearly, so the swizzle is applied to the
+// SOURCE address of each piece and, as the same involution, to the read.
+template <int PPR>
+__device__ __forceinline__ int tile_swz(int row) {
+  return PPR == 8 ? ((row >> 1) & 7) : PPR == 4 ? ((row >> 2) & 3) : 0;
+}
+
 template <int PPR>   // float4 pieces per tile row
 __device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h, int64_t ldh, int row0, int ng, int c0) {
   const int tid = threadIdx.x;
@@ -213,7 +224,8 @@ __device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h
   for (int u = 0; u < (kTilePieces + kPT - 1) / kPT; ++u) {
     const int i = tid + u * kPT;
     if (i < total) {
-      const float* src = h + (int64_t)(row0 + i / PPR) * ldh + c0 + (i % PPR) * 4;
+      const int r = i / PPR;
+      const float* src = h + (int64_t)(row0 + r) * ldh + c0 + (((i % PPR) ^ tile_swz<PPR>(r)) * 4);
       float* dst = buf + (u * kPT + (tid & ~63)) * 4;   // wave-uniform base; the DMA adds lane*16 bytes
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -225,14 +237,15 @@ __device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h
 // branch-free so that all loads are in flight at once.
 template <int NI>
 __device__ __forceinline__ void tile_load_rowptr(const int32_t* __restrict__ rowptr, int row0, int ng, int (&a)[NI],
-                                                 int (&b)[NI]) {
-  const int rbase = (threadIdx.x >> 6) * 16 + ((threadIdx.x & 63) >> 2);
+                                                 int (&b)[NI], int rlo = 0) {
+  // rows [rlo, ng) of the block; ng doubles as the (exclusive) end of the row range
+  const int rbase = rlo + (threadIdx.x >> 6) * 16 + ((threadIdx.x & 63) >> 2);
 #pragma unroll
   for (int t = 0; t < NI; ++t) {
     const int r = rbase + t * kSpan;
     const I2u p = *reinterpret_cast<const I2u*>(rowptr + row0 + min(r, ng - 1));   // clamped: always in bounds
     a[t] = p.x;
-    b[t] = r < ng ? p.y : p.x;   // rows past the block end become empty
+    b[t] = r < ng ? p.y : p.x;   // rows past the range end become empty
   }
 }
 
@@ -254,14 +267,14 @@ __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, cons
                                             const float* __restrict__ vals, const float4 (&bv)[CPL],
                                             float* __restrict__ out, int64_t ldo, int row0, int ng, int c0, int act,
                                             int pad, int last4, const int (&a)[NI], const int (&b)[NI],
-                                            int (&mc)[NI][4], float (&mv)[NI][4]) {
+                                            int (&mc)[NI][4], float (&mv)[NI][4], int rlo = 0) {
+  // output rows [rlo, ng) of the block (ng = exclusive end of the row range)
   constexpr int FT = 16 * CPL;
   const int lane = threadIdx.x & 63;
   const int sub = lane & 3;
-  const int rbase = (threadIdx.x >> 6) * 16 + (lane >> 2);
-  const float* trow = tile + sub * 4;
+  const int rbase = rlo + (threadIdx.x >> 6) * 16 + (lane >> 2);
 #pragma unroll
-  for (int t = 0; t < NI; ++t) if (t * kSpan < ng) {
+  for (int t = 0; t < NI; ++t) if (rlo + t * kSpan < ng) {
     const int r = rbase + t * kSpan;
     float4 acc[CPL];
 #pragma unroll
@@ -276,7 +289,7 @@ __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, cons
           float w = 0.f;                                                                                       \
           if (WEIGHTED) w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(mv[t][i])));                     \
           _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                    \
-            const float4 hv = *reinterpret_cast<const float4*>(trow + c * FT + 16 * j);                        \
+            const float4 hv = *reinterpret_cast<const float4*>(tile + c * FT + (((sub + 4 * j) ^ tile_swz<FT / 4>(c)) * 4)); \
             acc[j] = WEIGHTED ? f4_fma(w, hv, acc[j]) : f4_add(acc[j], hv);                                    \
           }                                                                                                    \
         }                                                                                                      \
@@ -579,13 +592,15 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
   }
   int* queues = ctx->flag + 1;
   GCNX_HIP(ctx, hipMemsetAsync(queues, 0, 2 * sizeof(int), ctx->stream));
+  // One column pass per work item: sharing an index burst between 2 or 4 passes (NPASS > 1) measured 3-10 % slower
+  // on config 3 (the items get longer and the work queue coarser), so only NPASS = 1 is instantiated.
   if (plan->n1 > 0) {
     int rc = launch_tiles<3, 32, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, queues);
     if (rc) return rc;
   }
   if (plan->n2 > 0) {
     int rc = launch_tiles<5, 16, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                plan->n2, queues + 1);
+                                    plan->n2, queues + 1);
     if (rc) return rc;
   }
   if (plan->nchunks > 0) {
