@@ -9,7 +9,7 @@ from . import _lib
 from .loader import Dataset, DisjointLoader, Graph, ListDataset, SparseTensor
 
 __all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "SparseTensor", "Context", "GCNConv",
-           "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "DeviceBatch"]
+           "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch"]
 
 
 def __getattr__(name):  # device-side names load libgcnx lazily, host-only use needs no .so
@@ -19,7 +19,7 @@ def __getattr__(name):  # device-side names load libgcnx lazily, host-only use n
     if name in ("GCNConv", "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense"):
         from . import layers
         return getattr(layers, name)
-    if name in ("GCN2", "DeviceBatch"):
+    if name in ("GCN2", "GeneralGNN", "DeviceBatch", "evaluate"):
         from . import models
         return getattr(models, name)
     raise AttributeError(name)

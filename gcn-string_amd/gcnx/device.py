@@ -380,3 +380,41 @@ def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
 
 def sgd(ctx, params, grads, lr):
     ctx._ck(ctx.lib.gcnx_sgd(ctx.h, _p(params), _p(grads), params.size, float(lr)))
+
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99     # Keras BatchNormalization defaults
+
+
+def bn_stats(ctx, z, sums, shift=None):
+    n, f = z.shape
+    ctx._ck(ctx.lib.gcnx_bn_stats(ctx.h, _p(z), z.ld, n, f, _p(shift), _p(sums)))
+
+
+def bn_finalize(ctx, sums, count, mean, inv, moving_mean=None, moving_var=None, shift=None, momentum=BN_MOMENTUM, eps=BN_EPS):
+    ctx._ck(ctx.lib.gcnx_bn_finalize(ctx.h, _p(sums), float(count), mean.size, momentum, eps, _p(shift), _p(mean), _p(inv),
+                                     _p(moving_mean), _p(moving_var)))
+
+
+def bn_moments(ctx, z, sums, mean, inv, moving_mean=None, moving_var=None):
+    """Batch mean / biased variance the way tf.nn.moments takes them (variance of the centred data): a first
+    pass for the mean, a second one centred on it."""
+    bn_stats(ctx, z, sums)
+    bn_finalize(ctx, sums, z.shape[0], mean, inv)
+    bn_stats(ctx, z, sums, shift=mean)
+    bn_finalize(ctx, sums, z.shape[0], mean, inv, moving_mean, moving_var, shift=mean)
+
+
+def bn_act(ctx, z, mean, inv, gamma, beta, y, act=None, alpha=None):
+    n, f = z.shape
+    ctx._ck(ctx.lib.gcnx_bn_act(ctx.h, _p(z), z.ld, n, f, _p(mean), _p(inv), _p(gamma), _p(beta), L.ACTS[act], _p(alpha),
+                                _p(y), y.ld))
+    return y
+
+
+def bn_act_bwd(ctx, dy, z, mean, inv, gamma, beta, dz, scratch, act=None, alpha=None, training=True, dgamma=None, dbeta=None,
+               dalpha=None):
+    n, f = z.shape
+    ctx._ck(ctx.lib.gcnx_bn_act_bwd(ctx.h, _p(dy), dy.ld, _p(z), z.ld, n, f, _p(mean), _p(inv), _p(gamma), _p(beta),
+                                    L.ACTS[act], _p(alpha), 1 if training else 0, _p(dz), dz.ld, _p(dgamma), _p(dbeta),
+                                    _p(dalpha), _p(scratch)))
+    return dz

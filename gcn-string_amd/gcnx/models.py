@@ -248,3 +248,258 @@ class GCN2:
 
     def gradients(self):
         return {k: self.g[k].numpy() for k in self.PARAM_ORDER}
+
+
+def evaluate(model, loader, normalize=None):
+    """The reference's evaluate(loader) (src/scripts/gcn.py:342-362): one pass of
+    loader.steps_per_epoch batches, eager forward with training=False, per-batch loss and accuracy
+    averaged with the batch sizes as weights.  Returns ((loss, acc), [pred per batch])."""
+    output, preds = [], []
+    step = 0
+    while step < loader.steps_per_epoch:
+        step += 1
+        inputs, target = loader.__next__()
+        batch = DeviceBatch.from_host(model.ctx, inputs, target, normalize=normalize)
+        loss, acc, pred = model.evaluate_batch(batch, None)
+        preds.append(pred)
+        output.append((loss, acc, len(target)))
+    output = np.array(output)
+    return tuple(np.average(output[:, :-1], 0, weights=output[:, -1])), preds
+
+
+class GeneralGNN:
+    """spektral.models.GeneralGNN -- the model the reference trains (src/scripts/gcn.py:320:
+    ``GeneralGNN(dataset.n_labels, activation="softmax")``), SURVEY 8.A.3:
+
+        pre-MLP(2) -> 4 x [z = GeneralConv(out); out = concat([z, out])] -> GlobalSumPool -> post-MLP(2)
+
+    MLP layer = Dense -> BatchNormalization -> Dropout(0) -> PReLU (last post layer: softmax);
+    GeneralConv = Dense -> BN -> PReLU -> sum-aggregation over a.indices (values ignored).
+    Same constructor signature; only the defaults the reference uses are implemented (anything
+    else raises).  The skip concatenation is never materialised: every layer reads / writes a
+    column slice of one [N, hidden*(message_passing+1)] buffer through leading-dimension views.
+    Weights are exposed in Keras order per layer: kernel, bias, gamma, beta, moving_mean,
+    moving_variance, alpha.  Single-GPU only this round (sync-BN is the SURVEY 8(e) follow-up).
+    """
+
+    def __init__(self, ctx, output, activation=None, hidden=256, message_passing=4, pre_process=2, post_process=2,
+                 connectivity="cat", batch_norm=True, dropout=0.0, aggregate="sum", hidden_activation="prelu", pool="sum",
+                 prec="f32", seed=0):
+        unsupported = {"connectivity": (connectivity, "cat"), "batch_norm": (batch_norm, True), "dropout": (dropout, 0.0),
+                       "aggregate": (aggregate, "sum"), "hidden_activation": (hidden_activation, "prelu"),
+                       "pool": (pool, "sum"), "activation": (activation, "softmax")}
+        for k, (got, want) in unsupported.items():
+            if got != want:
+                raise NotImplementedError(f"GeneralGNN({k}={got!r}): only {want!r} (what gcn.py:320 uses) is built")
+        self.ctx, self.output, self.hidden, self.mp = ctx, int(output), int(hidden), int(message_passing)
+        self.n_pre, self.n_post, self.prec = int(pre_process), int(post_process), prec
+        self._rng = np.random.default_rng(seed)
+        self.built = False
+        self._bufs = None
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def build(self, f_in):
+        h, mp = self.hidden, self.mp
+        dims = []                                         # (group, fan_in, fan_out, has_prelu)
+        w = f_in
+        for _ in range(self.n_pre):
+            dims.append(("pre", w, h, True)); w = h
+        for k in range(mp):
+            dims.append(("gnn", h * (k + 1), h, True))
+        w = h * (mp + 1)
+        for k in range(self.n_post):
+            last = k == self.n_post - 1
+            dims.append(("post", w, self.output if last else h, not last)); w = h
+        n_train = sum(fi * fo + 3 * fo + (fo if pr else 0) for _, fi, fo, pr in dims)
+        n_state = sum(2 * fo for _, _, fo, _ in dims)
+        self.n_params = n_train
+        ctx = self.ctx
+        self.flat_p, self.flat_g = ctx.zeros(n_train), ctx.zeros(n_train + 2)
+        self.flat_s = ctx.zeros(n_state)                  # moving_mean | moving_var per layer
+        self.loss_acc = self.flat_g.flat(n_train, 2)
+        self.layers = []
+        off = soff = 0
+        for grp, fi, fo, pr in dims:
+            L = {"group": grp, "fi": fi, "fo": fo, "act": "prelu" if pr else None}
+            for name, shape in (("kernel", (fi, fo)), ("bias", (fo,)), ("gamma", (fo,)), ("beta", (fo,))) + \
+                    ((("alpha", (fo,)),) if pr else ()):
+                n = int(np.prod(shape))
+                L[name] = self.flat_p.flat(off, n, shape)
+                L["g_" + name] = self.flat_g.flat(off, n, shape)
+                off += n
+            L["moving_mean"] = self.flat_s.flat(soff, fo); L["moving_var"] = self.flat_s.flat(soff + fo, fo); soff += 2 * fo
+            L["mean"], L["inv"] = ctx.zeros(fo), ctx.zeros(fo)
+            L["sums"], L["scratch"] = ctx.zeros(2 * fo), ctx.zeros(3 * fo)
+            from .layers import glorot_uniform
+            L["kernel"].copy_from_host(glorot_uniform(self._rng, fi, fo))
+            L["gamma"].copy_from_host(np.ones(fo, np.float32))
+            L["moving_var"].copy_from_host(np.ones(fo, np.float32))
+            self.layers.append(L)
+        self.f_in, self.built = f_in, True
+
+    WEIGHT_ORDER = ("kernel", "bias", "gamma", "beta", "moving_mean", "moving_var", "alpha")
+
+    def get_weights(self):
+        return [L[k].numpy() for L in self.layers for k in self.WEIGHT_ORDER if k in L]
+
+    def set_weights(self, weights):
+        it = iter(weights)
+        for L in self.layers:
+            for k in self.WEIGHT_ORDER:
+                if k in L:
+                    L[k].copy_from_host(np.asarray(next(it), np.float32).reshape(L[k].shape))
+
+    @property
+    def trainable_variables(self):
+        return [L[k] for L in self.layers for k in ("kernel", "bias", "gamma", "beta", "alpha") if k in L]
+
+    @property
+    def losses(self):
+        return []
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def _ensure(self, batch):
+        if not self.built:
+            self.build(batch.f)
+        key = (batch.n, batch.n_graphs)
+        if self._bufs is not None and self._bufs["key"] == key:
+            return self._bufs
+        ctx, n, b, h = self.ctx, batch.n, batch.n_graphs, self.hidden
+        wcat = h * (self.mp + 1)
+        bufs = {"key": key, "cat": ctx.empty((n, wcat)), "dcat": ctx.empty((n, wcat)), "h": ctx.empty((n, h)),
+                "dh": ctx.empty((n, h)), "pooled": ctx.empty((b, wcat)), "dpooled": ctx.empty((b, wcat)),
+                "probs": ctx.empty((b, self.output)), "dlogits": ctx.empty((b, self.output)), "zy": ctx.zeros((b, self.output))}
+        for i, L in enumerate(self.layers):
+            rows = b if L["group"] == "post" else n
+            bufs[f"z{i}"] = ctx.empty((rows, L["fo"]))           # Dense output (pre-BN), kept for the backward pass
+            bufs[f"y{i}"] = ctx.empty((rows, L["fo"]))           # layer output where it is not a slice of `cat`
+        self._bufs = bufs
+        return bufs
+
+    def _dense_bn(self, L, x, z, y, training):
+        ctx = self.ctx
+        D.gemm(ctx, x, L["kernel"], L["bias"], z, prec=self.prec)
+        if training:
+            D.bn_moments(ctx, z, L["sums"], L["mean"], L["inv"], L["moving_mean"], L["moving_var"])
+        else:
+            D.bn_finalize(ctx, None, 1, L["mean"], L["inv"], L["moving_mean"], L["moving_var"])
+        D.bn_act(ctx, z, L["mean"], L["inv"], L["gamma"], L["beta"], y, act=L["act"], alpha=L.get("alpha"))
+
+    def _forward(self, batch, bufs, training):
+        h, mp = self.hidden, self.mp
+        cat = bufs["cat"]
+        a = batch.a.unweighted()                          # GeneralConv ignores adjacency values (8.A.4)
+        x = batch.x
+        li = 0
+        for k in range(self.n_pre):
+            L = self.layers[li]
+            y = cat.cols(mp * h, (mp + 1) * h) if k == self.n_pre - 1 else bufs[f"y{li}"]
+            self._dense_bn(L, x, bufs[f"z{li}"], y, training)
+            x = y; li += 1
+        for k in range(mp):
+            L = self.layers[li]
+            inp = cat.cols((mp - k) * h, (mp + 1) * h)
+            self._dense_bn(L, inp, bufs[f"z{li}"], bufs["h"], training)
+            D.spmm(self.ctx, a, bufs["h"], None, cat.cols((mp - k - 1) * h, (mp - k) * h))
+            li += 1
+        D.segment_pool(self.ctx, batch.seg, cat, bufs["pooled"], "sum")
+        x = bufs["pooled"]
+        for k in range(self.n_post):
+            L = self.layers[li]
+            self._dense_bn(L, x, bufs[f"z{li}"], bufs[f"y{li}"], training)
+            x = bufs[f"y{li}"]; li += 1
+        return x                                          # [B, output]: BN output = the softmax logits
+
+    def _bwd_dense_bn(self, L, dy, x, z, dx, training, accumulate=False):
+        ctx = self.ctx
+        dz = dy                                            # in place
+        D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
+                     alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
+                     dalpha=L.get("g_alpha"))
+        D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=self.prec)
+        D.act_bias_grad(ctx, dz, None, dz, None, db=L["g_bias"])
+        if dx is not None:
+            D.gemm_dx(ctx, dz, L["kernel"], dx, prec=self.prec, accumulate=accumulate)
+
+    def _backward(self, batch, bufs, training=True):
+        h, mp = self.hidden, self.mp
+        cat, dcat = bufs["cat"], bufs["dcat"]
+        at = batch.a.unweighted().transpose()
+        n_layers = len(self.layers)
+        li = n_layers - 1
+        d = bufs["dlogits"]                               # d(BN output of the last layer) from softmax+CCE
+        for k in reversed(range(self.n_post)):
+            L = self.layers[li]
+            x = bufs["pooled"] if k == 0 else bufs[f"y{li - 1}"]
+            dx = bufs["dpooled"] if k == 0 else bufs[f"y{li - 1}"]     # y of the previous layer is dead: reuse as its dY
+            if k > 0:
+                dx = self._tmp(bufs, f"dy{li - 1}", x.shape)
+            self._bwd_dense_bn(L, d, x, bufs[f"z{li}"], dx, training)
+            d = dx; li -= 1
+        D.segment_pool_bwd(self.ctx, batch.seg, bufs["dpooled"], dcat, "sum")
+        for k in reversed(range(mp)):
+            L = self.layers[li]
+            D.spmm(self.ctx, at, dcat.cols((mp - k - 1) * h, (mp - k) * h), None, bufs["dh"])
+            inp = cat.cols((mp - k) * h, (mp + 1) * h)
+            self._bwd_dense_bn(L, bufs["dh"], inp, bufs[f"z{li}"], dcat.cols((mp - k) * h, (mp + 1) * h), training,
+                               accumulate=True)
+            li -= 1
+        d = dcat.cols(mp * h, (mp + 1) * h)
+        for k in reversed(range(self.n_pre)):
+            L = self.layers[li]
+            x = batch.x if k == 0 else bufs[f"y{li - 1}"]
+            dx = None if k == 0 else self._tmp(bufs, f"dy{li - 1}", x.shape)
+            self._bwd_dense_bn(L, d, x, bufs[f"z{li}"], dx, training)
+            d = dx; li -= 1
+
+    def _tmp(self, bufs, key, shape):
+        if key not in bufs or bufs[key].shape != tuple(shape):
+            bufs[key] = self.ctx.empty(shape)
+        return bufs[key]
+
+    # ---- public surface ----------------------------------------------------------------------------
+    def _as_batch(self, inputs, target=None):
+        if isinstance(inputs, DeviceBatch):
+            if target is not None and inputs.y is None:
+                inputs.y = self.ctx.to_device(target, np.float32)
+            return inputs
+        return DeviceBatch.from_host(self.ctx, inputs, target, weighted=False)
+
+    def __call__(self, inputs, training=False):
+        batch = self._as_batch(inputs)
+        bufs = self._ensure(batch)
+        logits = self._forward(batch, bufs, training)
+        la = self._tmp(bufs, "la_scratch", (2,))
+        la.fill_zero()
+        D.softmax_cce(self.ctx, logits, bufs["zy"], bufs["probs"], la, None, None)
+        return bufs["probs"].numpy()
+
+    def loss_and_grads(self, inputs, target=None):
+        batch = self._as_batch(inputs, target)
+        bufs = self._ensure(batch)
+        logits = self._forward(batch, bufs, True)
+        self.loss_acc.fill_zero()
+        D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], batch.n_graphs)
+        self._backward(batch, bufs, True)
+        return batch
+
+    def train_step(self, inputs, target=None, lr=0.02, fetch=True):
+        """gcn.py:330-340 for the live model: forward(training=True), CCE, gradients, SGD, accuracy."""
+        batch = self.loss_and_grads(inputs, target)
+        D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr)
+        if not fetch:
+            return None
+        la = self.loss_acc.numpy()
+        return float(la[0]), float(la[1]) / batch.n_graphs
+
+    def evaluate_batch(self, inputs, target):
+        batch = self._as_batch(inputs, target)
+        bufs = self._ensure(batch)
+        logits = self._forward(batch, bufs, False)
+        self.loss_acc.fill_zero()
+        D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, None, batch.n_graphs)
+        la = self.loss_acc.numpy()
+        return float(la[0]), float(la[1]) / batch.n_graphs, bufs["probs"].numpy()
+
+    def gradients(self):
+        return [{k[2:]: L[k].numpy() for k in L if k.startswith("g_")} for L in self.layers]

@@ -174,6 +174,33 @@ GCNX_API int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, cons
                           float* dx, int64_t lddx, int32_t n, int32_t b, int32_t f, int mode,
                           const int32_t* argmax, const float* y, int64_t ldy, float* db);
 
+/* ---- Keras BatchNormalization + PReLU around Dense (MLP / GeneralConv of GeneralGNN, gcn.py:320;
+ *      axis -1, momentum 0.99, eps 1e-3, biased batch variance) ------------------- */
+/* sums[0:f] = column sums of (z - shift), sums[f:2f] = column sums of (z - shift)^2 (device float[2f]);
+ * shift (device float[f], may be NULL = 0).  tf.nn.moments takes the variance of the CENTRED data; to match it
+ * in fp32 call twice: shift = NULL gives the mean, shift = mean gives a cancellation-free variance.  A sharded
+ * caller all-reduces `sums` (and the row count) between gcnx_bn_stats and gcnx_bn_finalize for sync-BN. */
+GCNX_API int gcnx_bn_stats(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f, const float* shift,
+                           float* sums);
+/* Training (sums != NULL): d = sums/count, mean = shift + d, var = sums2/count - d^2 (biased),
+ * inv = 1/sqrt(var+eps); the moving statistics (may be NULL) are updated: m <- momentum*m + (1-momentum)*batch.
+ * mean may alias shift.  Inference (sums == NULL): mean/inv come from the moving statistics. */
+GCNX_API int gcnx_bn_finalize(gcnx_ctx* ctx, const float* sums, float count, int32_t f, float momentum,
+                              float eps, const float* shift, float* mean, float* inv, float* moving_mean,
+                              float* moving_var);
+/* y = act(gamma * (z - mean) * inv + beta); act NONE / RELU / PRELU(alpha[f]). */
+GCNX_API int gcnx_bn_act(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f, const float* mean,
+                         const float* inv, const float* gamma, const float* beta, int act, const float* alpha,
+                         float* y, int64_t ldy);
+/* Backward of gcnx_bn_act given dY and the saved z, mean, inv: dzb = dY*act'(zb);
+ * training: dZ = gamma*inv*(dzb - mean_rows(dzb) - xhat*mean_rows(dzb*xhat)); inference: gamma*inv*dzb.
+ * dgamma = sum dzb*xhat, dbeta = sum dzb, dalpha = sum dY*min(zb,0) (each may be NULL).
+ * sums_scratch: device float[3f].  dz may alias dy. */
+GCNX_API int gcnx_bn_act_bwd(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n,
+                             int32_t f, const float* mean, const float* inv, const float* gamma, const float* beta,
+                             int act, const float* alpha, int training, float* dz, int64_t lddz, float* dgamma,
+                             float* dbeta, float* dalpha, float* sums_scratch);
+
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);
