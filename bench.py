@@ -93,6 +93,34 @@ def cpu_baseline(hb, hidden, params_flat, budget_s):
                       f"F={hb.f}) in {el:.1f} s; C/OpenMP fp32 restatement, not Spektral/TF (absent)"}
 
 
+def bench_generalgnn(ctx, args):
+    """Secondary line: the reference's live model (GeneralGNN defaults, NetSurfP-width inputs F_in = 16,
+    gcn_utills.py:293-300) on the E. coli-shaped batch; forward + CCE + all gradients + SGD, eager launches."""
+    from gcnx import synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GeneralGNN
+    assert args.gpus == 1, "GeneralGNN is single-GPU this round (sync-BN not built)"
+    hb = synth.ecoli_batch(32, 16, seed=1) if args.workload == "ecoli" else synth.block_diag_batch(1_000_000, 10_000_000, 16, seed=2)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+    model = GeneralGNN(ctx, 2, activation="softmax", prec=args.prec)
+    for _ in range(max(args.warmup, 2)):
+        model.train_step(batch, None, lr=0.0002, fetch=False)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(batch, None, lr=0.0002, fetch=False)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": "graphs/sec (fwd+bwd) GeneralGNN (gcn.py:320 defaults)", "value": hb.n_graphs * args.steps / el,
+                      "unit": "graphs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": args.prec, "data": "synthetic",
+                      "config": {"workload": f"GeneralGNN(hidden=256, 4 x GeneralConv, BN, PReLU, cat) on {args.workload}: "
+                                             f"B={hb.n_graphs}, N={hb.n}, nnz={hb.nnz}, F_in=16", "params": model.n_params}}), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +129,9 @@ def main():
     ap.add_argument("--workload", default="ecoli", choices=["ecoli", "block1m", "powerlaw"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--prec", default="f32", choices=["f32", "bf16", "bf16x3"])
+    ap.add_argument("--model", default="gcn2", choices=["gcn2", "generalgnn"],
+                    help="gcn2 = the BN-free 2-layer GCNConv model of BASELINE.md (default, the metric's model); "
+                         "generalgnn = the reference's live model gcn.py:320 (F_in=16, hidden=256; single GPU, eager)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-config3", action="store_true", help="skip the extra config-3 SpMM roofline reading")
@@ -118,6 +149,8 @@ def main():
     scaling = args.scaling or ("weak" if args.workload == "ecoli" else "strong")
 
     ctx = gcnx.Context(local_rank)
+    if args.model == "generalgnn":
+        return bench_generalgnn(ctx, args)
     comm = gcomm.Communicator(ctx, rank, world)
     hb_global, hidden = make_global_batch(args.workload, world, scaling)
     hb, global_graphs = shard.shard_batch(hb_global, rank, world) if world > 1 else (hb_global, hb_global.n_graphs)

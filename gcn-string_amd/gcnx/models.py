@@ -55,7 +55,45 @@ class DeviceBatch:
         return cls(ctx, dx, csr, seg, dy)
 
 
-class GCN2:
+class _GraphRunner:
+    """Runs a fixed call sequence eagerly once (sizes the workspace), captures it into a HIP graph on the second
+    use and replays it afterwards -- the role tf.function plays at gcn.py:328.  Graphs hold the pointers of one
+    batch and are dropped when the batch changes."""
+
+    use_graph = True
+
+    def _bind(self, batch):
+        """Captured graphs hold the pointers of one batch: drop them when the batch changes."""
+        if getattr(self, "_bound_uid", None) != batch.uid:
+            for tag in [t for t in self._graphs if t[0] != "sgd"]:
+                g = self._graphs.pop(tag)
+                if not isinstance(g, str):
+                    g.destroy()
+            self._bound_uid = batch.uid
+
+    def _run(self, tag, fn):
+        """Run fn eagerly the first time (sizes the workspace), then capture + replay."""
+        if not self.use_graph:
+            fn()
+            return
+        st = self._graphs.get(tag)
+        if st is None:
+            fn()
+            self._graphs[tag] = "warm"
+        elif st == "warm":
+            self._graphs[tag] = self.ctx.capture(fn)
+            self._graphs[tag].launch()
+        else:
+            st.launch()
+
+    def _drop_graphs(self):
+        for g in getattr(self, "_graphs", {}).values():
+            if not isinstance(g, str):
+                g.destroy()
+        self._graphs = {}
+
+
+class GCN2(_GraphRunner):
     PARAM_ORDER = ("w1", "b1", "w2", "b2", "w3", "b3")
 
     def __init__(self, ctx, n_labels=2, hidden=None, pool="sum", prec="f32", seed=0, comm=None, use_graph=True):
@@ -125,12 +163,6 @@ class GCN2:
         }
         return self._bufs
 
-    def _drop_graphs(self):
-        for g in self._graphs.values():
-            if not isinstance(g, str):
-                g.destroy()
-        self._graphs = {}
-
     # ---- the call sequences --------------------------------------------------------------------
     def _forward(self, batch, bufs, with_loss, denom):
         ctx, p, prec = self.ctx, self.p, self.prec
@@ -160,30 +192,6 @@ class GCN2:
 
     def _world(self):
         return self.comm.world_size if self.comm is not None else 1
-
-    def _bind(self, batch):
-        """Captured graphs hold the pointers of one batch: drop them when the batch changes."""
-        if getattr(self, "_bound_uid", None) != batch.uid:
-            for tag in [t for t in self._graphs if t[0] != "sgd"]:
-                g = self._graphs.pop(tag)
-                if not isinstance(g, str):
-                    g.destroy()
-            self._bound_uid = batch.uid
-
-    def _run(self, tag, fn):
-        """Run fn eagerly the first time (sizes the workspace), then capture + replay."""
-        if not self.use_graph:
-            fn()
-            return
-        st = self._graphs.get(tag)
-        if st is None:
-            fn()
-            self._graphs[tag] = "warm"
-        elif st == "warm":
-            self._graphs[tag] = self.ctx.capture(fn)
-            self._graphs[tag].launch()
-        else:
-            st.launch()
 
     # ---- public surface: model(inputs, training=...) and train_step ------------------------
     def _as_batch(self, inputs, target=None):
@@ -267,7 +275,7 @@ def evaluate(model, loader, normalize=None):
     return tuple(np.average(output[:, :-1], 0, weights=output[:, -1])), preds
 
 
-class GeneralGNN:
+class GeneralGNN(_GraphRunner):
     """spektral.models.GeneralGNN -- the model the reference trains (src/scripts/gcn.py:320:
     ``GeneralGNN(dataset.n_labels, activation="softmax")``), SURVEY 8.A.3:
 
@@ -284,7 +292,8 @@ class GeneralGNN:
 
     def __init__(self, ctx, output, activation=None, hidden=256, message_passing=4, pre_process=2, post_process=2,
                  connectivity="cat", batch_norm=True, dropout=0.0, aggregate="sum", hidden_activation="prelu", pool="sum",
-                 prec="f32", seed=0):
+                 prec="f32", seed=0, use_graph=True):
+        self.use_graph, self._graphs = use_graph, {}
         unsupported = {"connectivity": (connectivity, "cat"), "batch_norm": (batch_norm, True), "dropout": (dropout, 0.0),
                        "aggregate": (aggregate, "sum"), "hidden_activation": (hidden_activation, "prelu"),
                        "pool": (pool, "sum"), "activation": (activation, "softmax")}
@@ -365,6 +374,7 @@ class GeneralGNN:
         if self._bufs is not None and self._bufs["key"] == key:
             return self._bufs
         ctx, n, b, h = self.ctx, batch.n, batch.n_graphs, self.hidden
+        self._drop_graphs()
         wcat = h * (self.mp + 1)
         bufs = {"key": key, "cat": ctx.empty((n, wcat)), "dcat": ctx.empty((n, wcat)), "h": ctx.empty((n, h)),
                 "dh": ctx.empty((n, h)), "pooled": ctx.empty((b, wcat)), "dpooled": ctx.empty((b, wcat)),
@@ -477,16 +487,19 @@ class GeneralGNN:
     def loss_and_grads(self, inputs, target=None):
         batch = self._as_batch(inputs, target)
         bufs = self._ensure(batch)
-        logits = self._forward(batch, bufs, True)
-        self.loss_acc.fill_zero()
-        D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], batch.n_graphs)
-        self._backward(batch, bufs, True)
+        def seq():
+            logits = self._forward(batch, bufs, True)
+            self.loss_acc.fill_zero()
+            D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], batch.n_graphs)
+            self._backward(batch, bufs, True)
+        self._bind(batch)
+        self._run(("grad", batch.uid), seq)
         return batch
 
     def train_step(self, inputs, target=None, lr=0.02, fetch=True):
         """gcn.py:330-340 for the live model: forward(training=True), CCE, gradients, SGD, accuracy."""
         batch = self.loss_and_grads(inputs, target)
-        D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr)
+        self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
         if not fetch:
             return None
         la = self.loss_acc.numpy()
