@@ -159,12 +159,22 @@ struct __attribute__((aligned(4))) I2u { int x, y; };
 // A row's next (up to) 16 CSR entries in ONE vector-memory instruction per array: lane `slot`
 // of the row's quad fetches entries [e0 + 4*slot, +4) as a dwordx4.  Slots past the row end are
 // redirected to the zero row `pad` (cols) / 0 (vals).  `last4` = nnz - 4 guards the array end.
-template <bool WEIGHTED>
+// SCALE: the stored value is (col - row0) * SCALE -- the byte offset of the tile row, computed once per
+// fetched entry instead of once per lane that consumes the broadcast.
+// SCALE == 128 (32-column tiles) additionally folds the bank swizzle into the offset: rows with bit 1 of
+// their index set keep their two 64-byte halves swapped (tile_dma stores them that way), so the offset
+// points at the row's logical first half and `offset ^ 64` at the second.
+__device__ __forceinline__ int tile_off(int row, int scale) {
+  return scale == -128 ? row * 128 + ((row & 2) << 5) : row * scale;   // -128: 128-byte rows with the half-swap swizzle
+}
+
+template <bool WEIGHTED, int SCALE = 1>
 __device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
                                               int e0, int slot, int b, int row0, int pad, int last4, int (&mc)[4],
                                               float (&mv)[4]) {
+  // (A branch-free variant -- clamped address, select afterwards -- measured 10 % slower end to end: it also
+  // fetches for the slots past the row end.)
   const int e = e0 + 4 * slot;
-  if (b < 0) { for (int i = 0; i < 4; ++i) { mc[i] = pad; mv[i] = 0.f; } return; }
   int c0 = pad, c1 = pad, c2 = pad, c3 = pad;
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   if (e < b) {
@@ -177,56 +187,39 @@ __device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx
       if (WEIGHTED) { v0 = vals[e]; if (e + 1 < b) v1 = vals[e + 1]; if (e + 2 < b) v2 = vals[e + 2]; }
     }
   }
-  mc[0] = e + 0 < b ? c0 - row0 : pad;  mv[0] = e + 0 < b ? v0 : 0.f;
-  mc[1] = e + 1 < b ? c1 - row0 : pad;  mv[1] = e + 1 < b ? v1 : 0.f;
-  mc[2] = e + 2 < b ? c2 - row0 : pad;  mv[2] = e + 2 < b ? v2 : 0.f;
-  mc[3] = e + 3 < b ? c3 - row0 : pad;  mv[3] = e + 3 < b ? v3 : 0.f;
+  mc[0] = tile_off(e + 0 < b ? c0 - row0 : pad, SCALE);  mv[0] = e + 0 < b ? v0 : 0.f;
+  mc[1] = tile_off(e + 1 < b ? c1 - row0 : pad, SCALE);  mv[1] = e + 1 < b ? v1 : 0.f;
+  mc[2] = tile_off(e + 2 < b ? c2 - row0 : pad, SCALE);  mv[2] = e + 2 < b ? v2 : 0.f;
+  mc[3] = tile_off(e + 3 < b ? c3 - row0 : pad, SCALE);  mv[3] = e + 3 < b ? v3 : 0.f;
 }
 
 // ----------------------------------------------------------------------------------------------
-// Tile kernel: persistent, double-buffered version of the block kernel.
-//
-// One 1024-thread workgroup per CU owns all 160 KiB of LDS as two tile buffers and pulls
-// (graph, 32-column slab) items from a device work queue.  While item k is reduced out of
-// buffer k&1, the feature tile of item k+1 streams into the other buffer by LDS-DMA
+// Tile kernels: persistent workgroups that own a CU's 160 KiB of LDS as two tile buffers.
+// While one tile is reduced, the next one streams into the other buffer by LDS-DMA
 // (global_load_lds_dwordx4: no VGPRs, nothing to wait for until the next barrier), so HBM reads,
-// LDS gathers and output stores of neighbouring items overlap inside one CU.  All CSR data an
-// item needs (row pointers + the first 16 entries of each of the wave's rows) is fetched into
-// registers as ONE burst after the previous item's reduction, never inside the reduction:
-// vector-memory returns are in order, and a late index load would otherwise have to wait for the
-// whole in-flight tile.  One barrier per item.
+// LDS gathers and output stores of neighbouring steps overlap inside one CU.
 // ----------------------------------------------------------------------------------------------
-constexpr int kPT = 1024;                         // threads per persistent workgroup
+constexpr int kPT = 1024;                         // threads per workgroup of the queue-driven kernel
 constexpr int kPWaves = kPT / 64;
 constexpr int kTilePieces = 5056;                 // float4 pieces per tile buffer = 79 wave-instructions
 constexpr int kTileFloats = kTilePieces * 4;      // zero row starts here (same byte offset for every tier)
 constexpr int kBufFloats = 80 * 1024 / 4;         // one buffer; 2 buffers = all 160 KiB of a CU
 constexpr int kCtrlFloat = kTileFloats + 64;      // two int slots for queue hand-off, inside buffer 0's tail
 constexpr int kCap32 = kTilePieces / 8;           // 632 rows at FT = 32
-constexpr int kSpan = kPWaves * 16;               // rows a workgroup covers per wave iteration (16 rows per wave)
+constexpr int kSpan = kPWaves * 16;               // rows a 1024-thread workgroup covers per wave iteration (quad per row)
 
-// Tile rows are gathered at random, so a ds_read_b128 pass (16 lanes = 4 quads = 4 rows x 64 B)
-// collides whenever two of its rows start in the same bank quarter.  With plain 128-B rows only
-// the row parity picks the quarter pair (2.75x the ideal LDS cycles, simulated and consistent
-// with SQ_LDS_BANK_CONFLICT); XOR-ing the 16-byte chunk index with bits of the row index spreads
-// rows over all four quarters (2.1x).  LDS-DMA writes linearly, so the swizzle is applied to the
-// SOURCE address of each piece and, as the same involution, to the read.
-template <int PPR>
-__device__ __forceinline__ int tile_swz(int row) {
-  return PPR == 8 ? ((row >> 1) & 7) : PPR == 4 ? ((row >> 2) & 3) : 0;
-}
-
-template <int PPR>   // float4 pieces per tile row
+template <int PPR, int THREADS = kPT, bool HALFSWAP = (PPR == 8)>   // float4 pieces per tile row
 __device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h, int64_t ldh, int row0, int ng, int c0) {
   const int tid = threadIdx.x;
   const int total = ng * PPR;
 #pragma unroll
-  for (int u = 0; u < (kTilePieces + kPT - 1) / kPT; ++u) {
-    const int i = tid + u * kPT;
+  for (int u = 0; u < (kTilePieces + THREADS - 1) / THREADS; ++u) {
+    const int i = tid + u * THREADS;
     if (i < total) {
       const int r = i / PPR;
-      const float* src = h + (int64_t)(row0 + r) * ldh + c0 + (((i % PPR) ^ tile_swz<PPR>(r)) * 4);
-      float* dst = buf + (u * kPT + (tid & ~63)) * 4;   // wave-uniform base; the DMA adds lane*16 bytes
+      const int q = HALFSWAP ? ((i % PPR) ^ ((r & 2) << 1)) : (i % PPR);   // half-swap swizzle (tile_off), queue kernel only
+      const float* src = h + (int64_t)(row0 + r) * ldh + c0 + q * 4;
+      float* dst = buf + (u * THREADS + (tid & ~63)) * 4;   // wave-uniform base; the DMA adds lane*16 bytes
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -235,14 +228,14 @@ __device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h
 
 // Index burst of an item, part 1: row pointers of every row this quad owns (NI wave iterations),
 // branch-free so that all loads are in flight at once.
-template <int NI>
+template <int NI, int SPAN = kSpan, int LPR = 4>
 __device__ __forceinline__ void tile_load_rowptr(const int32_t* __restrict__ rowptr, int row0, int ng, int (&a)[NI],
                                                  int (&b)[NI], int rlo = 0) {
   // rows [rlo, ng) of the block; ng doubles as the (exclusive) end of the row range
-  const int rbase = rlo + (threadIdx.x >> 6) * 16 + ((threadIdx.x & 63) >> 2);
+  const int rbase = rlo + (threadIdx.x >> 6) * (64 / LPR) + ((threadIdx.x & 63) / LPR);
 #pragma unroll
   for (int t = 0; t < NI; ++t) {
-    const int r = rbase + t * kSpan;
+    const int r = rbase + t * SPAN;
     const I2u p = *reinterpret_cast<const I2u*>(rowptr + row0 + min(r, ng - 1));   // clamped: always in bounds
     a[t] = p.x;
     b[t] = r < ng ? p.y : p.x;   // rows past the range end become empty
@@ -250,18 +243,23 @@ __device__ __forceinline__ void tile_load_rowptr(const int32_t* __restrict__ row
 }
 
 // Part 2: the first 16 entries of each of those rows.
-template <int NI, bool WEIGHTED>
+template <int NI, bool WEIGHTED, int SCALE>
 __device__ __forceinline__ void tile_load_entries(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
                                                   int row0, int pad, int last4, const int (&a)[NI], const int (&b)[NI],
                                                   int (&mc)[NI][4], float (&mv)[NI][4]) {
 #pragma unroll
   for (int t = 0; t < NI; ++t)
-    fetch_entries<WEIGHTED>(colidx, vals, a[t], threadIdx.x & 3, b[t], row0, pad, last4, mc[t], mv[t]);
+    fetch_entries<WEIGHTED, SCALE>(colidx, vals, a[t], threadIdx.x & 3, b[t], row0, pad, last4, mc[t], mv[t]);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // Reduction of one item out of its LDS tile (indices already in registers).  One quad per row,
-// CPL float4 column chunks per lane.  KEEP: leave mc/mv holding each row's FIRST 16 entries on
-// return (the next pass over the sibling columns reuses them).
+// CPL float4 column chunks per lane.  The loop is VALU-bound (PMC: VALU 58 % busy over the whole
+// launch, LDS 34 %), so per (entry, lane) it is cut to the minimum: the entry's tile-row BYTE
+// OFFSET and value arrive by one DPP broadcast each, the float4 chunks are read at immediate
+// offsets from that address, and the 4*CPL multiply-adds are issued as packed v_pk_fma_f32.
+// KEEP: leave mc/mv holding each row's FIRST 16 entries on return.
 template <int NI, int CPL, bool WEIGHTED, bool KEEP>
 __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, const int32_t* __restrict__ colidx,
                                             const float* __restrict__ vals, const float4 (&bv)[CPL],
@@ -270,27 +268,35 @@ __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, cons
                                             int (&mc)[NI][4], float (&mv)[NI][4], int rlo = 0) {
   // output rows [rlo, ng) of the block (ng = exclusive end of the row range)
   constexpr int FT = 16 * CPL;
+  constexpr int RB = FT * 4;   // bytes per tile row
   const int lane = threadIdx.x & 63;
   const int sub = lane & 3;
   const int rbase = rlo + (threadIdx.x >> 6) * 16 + (lane >> 2);
+  const char* tbase = reinterpret_cast<const char*>(tile) + sub * 16;
 #pragma unroll
   for (int t = 0; t < NI; ++t) if (rlo + t * kSpan < ng) {
     const int r = rbase + t * kSpan;
-    float4 acc[CPL];
+    f32x2 acc[CPL][2];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
     int base = a[t];
     const int bb = b[t];
     while (true) {
 #define GCNX_TSTEP4(J)                                                                                         \
       if ((J) == 0 || __builtin_amdgcn_ballot_w64(base + 4 * (J) < bb) != 0) {                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-          const int c = quad_bcast<4, (J)>(mc[t][i]);                                                          \
-          float w = 0.f;                                                                                       \
-          if (WEIGHTED) w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(mv[t][i])));                     \
+          const int off = quad_bcast<4, (J)>(mc[t][i]);                                                        \
+          f32x2 w2 = f32x2{1.f, 1.f};                                                                          \
+          if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(mv[t][i]))); w2 = f32x2{w, w}; } \
           _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                    \
-            const float4 hv = *reinterpret_cast<const float4*>(tile + c * FT + (((sub + 4 * j) ^ tile_swz<FT / 4>(c)) * 4)); \
-            acc[j] = WEIGHTED ? f4_fma(w, hv, acc[j]) : f4_add(acc[j], hv);                                    \
+            const float4 hv = *reinterpret_cast<const float4*>(tbase + (CPL == 2 ? (off ^ (64 * j)) : off));   \
+            if (WEIGHTED) {                                                                                    \
+              acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[j][0]);                         \
+              acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[j][1]);                         \
+            } else {                                                                                           \
+              acc[j][0] += f32x2{hv.x, hv.y};                                                                  \
+              acc[j][1] += f32x2{hv.z, hv.w};                                                                  \
+            }                                                                                                  \
           }                                                                                                    \
         }                                                                                                      \
       }
@@ -302,14 +308,14 @@ __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, cons
       base += 16;
       if (base >= bb) break;
       // rows longer than 16 entries (rare in contact graphs): fetched on demand
-      fetch_entries<WEIGHTED>(colidx, vals, base, sub, bb, row0, pad, last4, mc[t], mv[t]);
+      fetch_entries<WEIGHTED, (CPL == 2 ? -128 : RB)>(colidx, vals, base, sub, bb, row0, pad, last4, mc[t], mv[t]);
     }
     if (KEEP && __builtin_amdgcn_ballot_w64(bb - a[t] > 16) != 0)   // a long row overwrote its first batch
-      fetch_entries<WEIGHTED>(colidx, vals, a[t], sub, bb, row0, pad, last4, mc[t], mv[t]);
+      fetch_entries<WEIGHTED, (CPL == 2 ? -128 : RB)>(colidx, vals, a[t], sub, bb, row0, pad, last4, mc[t], mv[t]);
     if (r < ng) {
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        float4 o = f4_add(acc[j], bv[j]);
+        float4 o = make_float4(acc[j][0][0] + bv[j].x, acc[j][0][1] + bv[j].y, acc[j][1][0] + bv[j].z, acc[j][1][1] + bv[j].w);
         if (act == GCNX_ACT_RELU) {
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
@@ -318,6 +324,109 @@ __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, cons
     }
   }
 }
+
+// Two-phase reduction for the static-schedule kernel.  Vector-memory results return in order, so a
+// load issued after the next tile's LDS-DMA cannot be consumed before that whole tile has landed:
+// the on-demand fetch of rows longer than 16 entries (a few per cent of the rows, hence in most waves)
+// used to stall nearly every wave on the DMA it was supposed to overlap with.  Phase A therefore
+// touches no global memory except its stores: every row is reduced over its first 16 entries (already
+// in registers) and rows that fit are finished.  Phase B, at the end of the step when the DMA is
+// (almost) complete anyway, re-reduces the long rows including their tails.
+#define GCNX_RSTEP4(J, MC, MV, BASE, BB)                                                                       \
+  if ((J) == 0 || __builtin_amdgcn_ballot_w64((BASE) + 4 * (J) < (BB)) != 0) {                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      const int off = quad_bcast<4, (J)>(MC[i]);                                                               \
+      f32x2 w2 = f32x2{1.f, 1.f};                                                                              \
+      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[i]))); w2 = f32x2{w, w}; } \
+      _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                        \
+        const float4 hv = *reinterpret_cast<const float4*>(tbase + (CPL == 2 ? (off ^ (64 * j)) : off));       /* CPL 2 only with LPR 4 */ \
+        if (WEIGHTED) {                                                                                        \
+          acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[j][0]);                             \
+          acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[j][1]);                             \
+        } else {                                                                                               \
+          acc[j][0] += f32x2{hv.x, hv.y};                                                                      \
+          acc[j][1] += f32x2{hv.z, hv.w};                                                                      \
+        }                                                                                                      \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
+template <int NI, int LPR, int CPL, bool WEIGHTED, int SPAN>
+__device__ __forceinline__ void tile_reduce2(const float* __restrict__ tile, const int32_t* __restrict__ colidx,
+                                             const float* __restrict__ vals, const float4 (&bv)[CPL],
+                                             float* __restrict__ out, int64_t ldo, int row0, int ng, int c0, int act,
+                                             int pad, int last4, const int (&a)[NI], const int (&b)[NI],
+                                             const int (&mc)[NI][4], const float (&mv)[NI][4], int dbg) {
+  // LPR lanes per row (4: one quad; 8: two quads holding the same entries), CPL float4 chunks per lane
+  constexpr int FT = LPR * 4 * CPL;
+  constexpr int RB = FT * 4;   // bytes per tile row
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPR;
+  const int rbase = (threadIdx.x >> 6) * (64 / LPR) + lane / LPR;
+  const char* tbase = reinterpret_cast<const char*>(tile) + sub * 16;
+  auto finish = [&](const f32x2 (&acc)[CPL][2], int r) {
+    if (dbg & 4) return;                                       // timing-only: no stores
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      float4 o = make_float4(acc[j][0][0] + bv[j].x, acc[j][0][1] + bv[j].y, acc[j][1][0] + bv[j].z, acc[j][1][1] + bv[j].w);
+      if (act == GCNX_ACT_RELU) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(out + (int64_t)(row0 + r) * ldo + c0 + (sub + LPR * j) * 4) = o;
+    }
+  };
+  // The per-t index registers are selected with a switch (compile-time register names in every case) so that
+  // the loop over t is a real loop: one copy of the 16-entry body, bounded register pressure, no spills --
+  // a spilled value would be a scratch LOAD, i.e. a vector-memory result that has to wait for the whole
+  // in-flight tile DMA.
+  // ---- phase A: first 16 entries of every row, from registers
+#pragma unroll
+  for (int t = 0; t < NI; ++t) if (t * SPAN < ng) {
+    __builtin_amdgcn_sched_barrier(0);   // one row group at a time: bounds the live ranges, no spills
+    const int r = rbase + t * SPAN;
+    const int at = a[t], bt = b[t];
+    const int (&m)[4] = mc[t];
+    const float (&v)[4] = mv[t];
+    f32x2 acc[CPL][2];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
+    if (!(dbg & 2)) {                                          // timing-only: no reduction
+      GCNX_RSTEP4(0, m, v, at, bt)
+      GCNX_RSTEP4(1, m, v, at, bt)
+      GCNX_RSTEP4(2, m, v, at, bt)
+      GCNX_RSTEP4(3, m, v, at, bt)
+    }
+    if (r < ng && (bt - at <= 16 || (dbg & 2))) finish(acc, r);
+  }
+  // ---- phase B: rows with more than 16 entries (rare; wave-uniform skip)
+#pragma unroll
+  for (int t = 0; t < NI; ++t) if (t * SPAN < ng) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int at = a[t], bb = b[t];
+    if (__builtin_amdgcn_ballot_w64(bb - at > 16) == 0 || (dbg & 2)) continue;
+    int m[4] = {mc[t][0], mc[t][1], mc[t][2], mc[t][3]};
+    float v[4] = {mv[t][0], mv[t][1], mv[t][2], mv[t][3]};
+    const int r = rbase + t * SPAN;
+    f32x2 acc[CPL][2];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
+    GCNX_RSTEP4(0, m, v, at, bb)
+    GCNX_RSTEP4(1, m, v, at, bb)
+    GCNX_RSTEP4(2, m, v, at, bb)
+    GCNX_RSTEP4(3, m, v, at, bb)
+    int base = at + 16;
+    while (__builtin_amdgcn_ballot_w64(base < bb) != 0) {
+      fetch_entries<WEIGHTED, RB>(colidx, vals, base, sub & 3, bb, row0, pad, last4, m, v);   // padded past the row end
+      GCNX_RSTEP4(0, m, v, base, bb)
+      GCNX_RSTEP4(1, m, v, base, bb)
+      GCNX_RSTEP4(2, m, v, base, bb)
+      GCNX_RSTEP4(3, m, v, base, bb)
+      base += 16;
+    }
+    if (r < ng && bb - at > 16) finish(acc, r);
+  }
+}
+#undef GCNX_RSTEP4
 
 // Items of one tier: (graph of the tier's list) x (slab of FT*NPASS columns), each done in NPASS
 // steps of FT columns that share one index burst (tier 1: FT = 32; tier 2: FT = 16).
@@ -350,7 +459,7 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
   int c0 = (item % nslabs) * ITEM_COLS;
   int pass = 0;
   tile_load_rowptr<NI>(rowptr, g.x, g.y, a, b);
-  tile_load_entries<NI, WEIGHTED>(colidx, vals, g.x, PAD, last4, a, b, mc, mv);
+  tile_load_entries<NI, WEIGHTED, (FT == 32 ? -128 : FT * 4)>(colidx, vals, g.x, PAD, last4, a, b, mc, mv);
   tile_dma<FT / 4>(lds, h, ldh, g.x, g.y, c0);
 
   for (int k = 0;; ++k) {
@@ -392,7 +501,7 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
       } else {
         tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a, b);     // register budget: no early prefetch in this tier
       }
-      tile_load_entries<NI, WEIGHTED>(colidx, vals, ng2.x, PAD, last4, a, b, mc, mv);
+      tile_load_entries<NI, WEIGHTED, (FT == 32 ? -128 : FT * 4)>(colidx, vals, ng2.x, PAD, last4, a, b, mc, mv);
       item = n_item;
       pass = 0;
     } else {
@@ -400,6 +509,99 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
     }
     g = ng2;
     c0 = nc0;
+  }
+}
+
+// Static-schedule version of the tile kernel.  Ablation of the queue-driven kernel above showed its
+// time does not move when the tile DMA, the reduction and the stores are all removed: each step was
+// bound by a chain of dependent round trips (queue pop -> graph descriptor -> row pointers -> entries)
+// in front of its barrier.  Here nothing on that chain remains per step:
+//  * a work unit = (graph, SG consecutive column slabs).  The CSR data of a unit is fetched into
+//    registers ONCE and reused by its SG steps (the slabs of a graph share rows and entries);
+//  * units are dealt to the persistent workgroups statically, in snake order over the size-sorted
+//    graph list (round r: unit r*G + w, or r*G + G-1-w on odd rounds), which balances the load without
+//    atomics; the next unit's descriptor and row pointers are prefetched a whole unit ahead;
+//  * per step: barrier, start the LDS-DMA of the next tile, reduce the current one.
+template <int THREADS, int NI, int FT, int SG, bool WEIGHTED>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void spmm_tile3_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+    const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
+    const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */, int act, int nunits,
+    int n, int dbg /* timing-only ablation bits: 1 no tile DMA, 2 no reduction, 4 no stores, 8 no index burst */) {
+  constexpr int LPR = FT / 4;                // lanes per row: one float4 each (32-column tile: 8 lanes = 128 B per row per
+                                             // ds_read_b128, 1.6x fewer LDS cycles than 4 lanes x 2 chunks: fewer bank conflicts)
+  constexpr int CPL = 1;
+  constexpr int SPAN = (THREADS / 64) * (64 / LPR);  // rows the workgroup covers per wave iteration
+  constexpr int PAD = kTileFloats / FT;      // index of the all-zero row
+  constexpr bool EARLY_RP = NI <= 3;         // early row-pointer prefetch only where registers allow         // prefetch the next unit's row pointers where registers allow
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int w = blockIdx.x, G = gridDim.x;
+  auto unit_of = [&](int round) { return round * G + ((round & 1) ? (G - 1 - w) : w); };
+  int round = 0;
+  int u = unit_of(0);
+  if (u >= nunits) return;
+  if (tid < 32) lds[kTileFloats + tid] = 0.f;                 // zero rows of both buffers
+  else if (tid < 64) lds[kBufFloats + kTileFloats + tid - 32] = 0.f;
+  const int last4 = rowptr[n] - 4;
+  const int sub = (tid & 63) % LPR;
+
+  int2 g = graphs[u / upg];
+  int cbase = (u % upg) * SG * FT;
+  int a[NI], b[NI], mc[NI][4];
+  float mv[NI][4];
+  tile_load_rowptr<NI, SPAN, LPR>(rowptr, g.x, g.y, a, b);
+  tile_load_entries<NI, WEIGHTED, FT * 4>(colidx, vals, g.x, PAD, last4, a, b, mc, mv);
+  if (!(dbg & 1)) tile_dma<FT / 4, THREADS, false>(lds, h, ldh, g.x, g.y, cbase);
+  int buf = 0;
+
+  while (true) {
+    const int un = unit_of(round + 1);
+    const bool has_next = un < nunits;
+    int2 gn = g;
+    int cnext = 0;
+    int a_n[NI], b_n[NI];
+    if (has_next) {
+      gn = graphs[un / upg];
+      cnext = (un % upg) * SG * FT;
+      if (EARLY_RP) tile_load_rowptr<NI, SPAN, LPR>(rowptr, gn.x, gn.y, a_n, b_n);
+    }
+    // The bias slices of the unit's SG slabs are the only ordinary global loads the reductions consume.  hipcc
+    // waits vmcnt(0) at the use of ANY ordinary load result while an LDS-DMA is in flight -- i.e. for the whole
+    // next tile -- so they are fetched once per unit, here, and consumed (the empty asm is their first use)
+    // before any step of the unit starts its DMA.  Inside the steps nothing but stores touches global memory.
+    float4 bvu[SG];
+#pragma unroll
+    for (int q = 0; q < SG; ++q) {
+      bvu[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bvu[q] = *reinterpret_cast<const float4*>(bias + cbase + q * FT + sub * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < SG; ++q) asm volatile("" : "+v"(bvu[q].x), "+v"(bvu[q].y), "+v"(bvu[q].z), "+v"(bvu[q].w));
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
+      __syncthreads();   // this step's tile has landed (vmcnt drained before the barrier); the previous reduction is over
+      const int c0 = cbase + s * FT;
+      float4 bv[CPL] = {bvu[s]};
+      if (dbg & 1) {}
+      else if (s + 1 < SG) tile_dma<FT / 4, THREADS, false>(lds + (buf ^ 1) * kBufFloats, h, ldh, g.x, g.y, cbase + (s + 1) * FT);
+      else if (has_next) tile_dma<FT / 4, THREADS, false>(lds + (buf ^ 1) * kBufFloats, h, ldh, gn.x, gn.y, cnext);
+      tile_reduce2<NI, LPR, CPL, WEIGHTED, SPAN>(lds + buf * kBufFloats, colidx, vals, bv, out, ldo, g.x, g.y, c0, act, PAD, last4, a, b,
+                                      mc, mv, dbg);
+      buf ^= 1;
+    }
+    if (!has_next) break;
+    // index burst of the next unit (once per SG steps; it is waited for at the next barrier)
+    if (EARLY_RP) {
+#pragma unroll
+      for (int t = 0; t < NI; ++t) { a[t] = a_n[t]; b[t] = b_n[t]; }
+    } else {
+      tile_load_rowptr<NI, SPAN, LPR>(rowptr, gn.x, gn.y, a, b);
+    }
+    if (!(dbg & 8)) tile_load_entries<NI, WEIGHTED, FT * 4>(colidx, vals, gn.x, PAD, last4, a, b, mc, mv);
+    g = gn;
+    cbase = cnext;
+    ++round;
   }
 }
 
@@ -485,6 +687,35 @@ int launch_tiles(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, co
   else
     hipLaunchKernelGGL((spmm_tile_kernel<NI, FT, NPASS, false>), dim3(grid), dim3(kPT), lds_bytes, ctx->stream, rowptr, colidx,
                        vals, h, ldh, bias, out, ldo, graphs, nslabs, act, (int)nwork, n, queue);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+template <int THREADS, int NI, int FT, int SG>
+int launch_tiles3(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                  const int2* graphs, int ngraphs) {
+  constexpr int lds_bytes = 2 * kBufFloats * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile3_kernel<THREADS, NI, FT, SG, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile3_kernel<THREADS, NI, FT, SG, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  int dbg = 0;   // GCNX_SPMM_DBG: timing-only ablation bits (results are WRONG when set)
+  if (const char* e = getenv("GCNX_SPMM_DBG")) dbg = atoi(e);
+  const int upg = f / (FT * SG);   // units per graph
+  const long long nunits = (long long)ngraphs * upg;
+  if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
+  const int grid = (int)(nunits < ctx->num_cus ? nunits : ctx->num_cus);   // one persistent workgroup per CU
+  if (vals)
+    hipLaunchKernelGGL((spmm_tile3_kernel<THREADS, NI, FT, SG, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, colidx,
+                       vals, h, ldh, bias, out, ldo, graphs, upg, act, (int)nunits, n, dbg);
+  else
+    hipLaunchKernelGGL((spmm_tile3_kernel<THREADS, NI, FT, SG, false>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, colidx,
+                       vals, h, ldh, bias, out, ldo, graphs, upg, act, (int)nunits, n, dbg);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -592,6 +823,32 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
   }
   int* queues = ctx->flag + 1;
   GCNX_HIP(ctx, hipMemsetAsync(queues, 0, 2 * sizeof(int), ctx->stream));
+  // GCNX_SPMM_TILE: tuning knob.  Default = the queue-driven kernel (fastest measured on config 3: 0.79-0.83 ms);
+  // "s" = the static-schedule kernel (spmm_tile3_kernel, 0.96 ms), "k" = the same with 1024-thread workgroups.
+  const char* tv = getenv("GCNX_SPMM_TILE");
+  const int sg = (f % 128 == 0) ? 4 : (f % 64 == 0 ? 2 : 1);   // column slabs per work unit (they share one index burst)
+  if (tv && (tv[0] == 's' || tv[0] == 'k')) {
+    const bool t512 = tv[0] != 'k';   // "k": 1024-thread workgroups (128 VGPRs/lane); default 512 threads (256)
+    (void)sg;
+#define GCNX_T3(T, NI, FT, SG, G, NG) launch_tiles3<T, NI, FT, SG>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, G, NG)
+    if (plan->n1 > 0) {
+      int rc = f % 64 == 0 ? (t512 ? GCNX_T3(512, 10, 32, 2, plan->dev, plan->n1) : GCNX_T3(1024, 5, 32, 4, plan->dev, plan->n1))
+                            : (t512 ? GCNX_T3(512, 10, 32, 1, plan->dev, plan->n1) : GCNX_T3(1024, 5, 32, 1, plan->dev, plan->n1));
+      if (rc) return rc;
+    }
+    if (plan->n2 > 0) {
+      int rc = f % 32 == 0 ? (t512 ? GCNX_T3(512, 10, 16, 2, plan->dev + plan->n1, plan->n2) : GCNX_T3(1024, 5, 16, 4, plan->dev + plan->n1, plan->n2))
+                           : (t512 ? GCNX_T3(512, 10, 16, 2, plan->dev + plan->n1, plan->n2) : GCNX_T3(1024, 5, 16, 2, plan->dev + plan->n1, plan->n2));
+      if (rc) return rc;
+    }
+#undef GCNX_T3
+    if (plan->nchunks > 0) {
+      dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
+                    plan->nchunks);
+      GCNX_LAUNCH_OK(ctx);
+    }
+    return GCNX_OK;
+  }
   // One column pass per work item: sharing an index burst between 2 or 4 passes (NPASS > 1) measured 3-10 % slower
   // on config 3 (the items get longer and the work queue coarser), so only NPASS = 1 is instantiated.
   if (plan->n1 > 0) {

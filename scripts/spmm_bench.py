@@ -40,5 +40,6 @@ for rnd in range(args.rounds):
         for _ in range(args.iters): D.spmm(ctx, a, h, bias, out, act="relu")
         e1 = ctx.event().record()
         ms = e1.elapsed_ms_since(e0) / args.iters
-        print(f"round {rnd} slab {slab:>8}: {ms*1e3:9.1f} us  {alg/ms/1e6:8.1f} GB/s  frac {alg/ms/1e6/8000:.3f}", flush=True)
+        chk = float(np.abs(out.numpy()[::1009]).sum())
+        print(f"round {rnd} slab {slab:>8}: {ms*1e3:9.1f} us  {alg/ms/1e6:8.1f} GB/s  frac {alg/ms/1e6/8000:.3f}  chk {chk:.6g}", flush=True)
 ctx.close()
