@@ -25,6 +25,7 @@ struct Epilogue {
   int64_t ldmask;
   int act;
   int accumulate;       // C += result
+  int vec_c;            // C (and mask) rows are 16-byte aligned: float4 epilogue stores
 };
 
 // One 64x32 (or 32x64) operand tile, global -> registers (2 float4 per thread), then registers
@@ -219,8 +220,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
                                                         int kpad, float* __restrict__ c, int64_t ldc, int64_t M,
                                                         int32_t Nc, int64_t K, int64_t kchunk, Epilogue ep, int vec_a,
                                                         int vec_b) {
-  __shared__ __attribute__((aligned(16))) __bf16 As[X3 ? 2 : 1][HM][HLD];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[X3 ? 2 : 1][HN][HLD];
+  // one LDS object: A image | B image (hi then lo planes); the epilogue reuses it as fp32 staging
+  constexpr int NP = X3 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (HM + HN) * HLD];
+  __bf16(*As)[HM][HLD] = reinterpret_cast<__bf16(*)[HM][HLD]>(smem);
+  __bf16(*Bs)[HN][HLD] = reinterpret_cast<__bf16(*)[HN][HLD]>(smem + NP * HM * HLD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * HM;
@@ -333,28 +337,77 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     __syncthreads();
   }
 
-  // C/D map of a 16x16 tile: col = lane & 15, row = (lane >> 4)*4 + reg.
+  // Epilogue.  C/D map of a 16x16 tile: col = lane & 15, row = (lane >> 4)*4 + reg -- stored straight from the
+  // accumulators that is 4 bytes per lane in 64-byte pieces, store-issue bound for a [N, F] output.  Each wave
+  // instead passes its 16 x 64 strips through LDS (the operand images are dead by now) and writes whole 256-byte
+  // row segments, one float4 per lane; bias / activation / mask / accumulate are applied on that float4.
   float* cz = c + (gridDim.z > 1 ? (int64_t)blockIdx.z * M * ldc : 0);
+  float(*stage)[68] = reinterpret_cast<float(*)[68]>(reinterpret_cast<char*>(smem) + wave * (16 * 68 * 4));
+  static_assert(sizeof(smem) >= 4 * 16 * 68 * 4, "epilogue staging must fit in the operand images");
+  const int ec = (lane & 15) * 4;            // this lane's 4 columns of the 64-column strip
+  const int er = lane >> 4;                  // and its row within each group of 4 rows
+  const int64_t gcol = n0 + wn * 64 + ec;
+  const bool col_vec = ep.vec_c && gcol + 3 < Nc;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), alpha4 = bias4;
+  if (ep.bias) {
+    if (gcol + 0 < Nc) bias4.x = ep.bias[gcol + 0];
+    if (gcol + 1 < Nc) bias4.y = ep.bias[gcol + 1];
+    if (gcol + 2 < Nc) bias4.z = ep.bias[gcol + 2];
+    if (gcol + 3 < Nc) bias4.w = ep.bias[gcol + 3];
+  }
+  if (ep.alpha) {
+    if (gcol + 0 < Nc) alpha4.x = ep.alpha[gcol + 0];
+    if (gcol + 1 < Nc) alpha4.y = ep.alpha[gcol + 1];
+    if (gcol + 2 < Nc) alpha4.z = ep.alpha[gcol + 2];
+    if (gcol + 3 < Nc) alpha4.w = ep.alpha[gcol + 3];
+  }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t col = n0 + wn * 64 + j * 16 + fr;
-    if (col >= Nc) continue;
-    const float bias = (ep.bias ? ep.bias[col] : 0.f);
-    const float alpha = (ep.alpha ? ep.alpha[col] : 0.f);
+  for (int i = 0; i < 4; ++i) {
+    // accumulators of the strip -> LDS (own region of this wave: no workgroup barrier needed)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 16 + fq * 4 + r;
-        if (row >= M) continue;
-        float v = acc[i][j][r] + bias;
-        if (ep.act == GCNX_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (ep.act == GCNX_ACT_PRELU) v = v > 0.f ? v : alpha * v;
-        if (ep.mask) v = ep.mask[row * ep.ldmask + col] > 0.f ? v : 0.f;
-        float* dst = cz + row * ldc + col;
-        if (ep.accumulate) v += *dst;
-        *dst = v;
+      for (int r = 0; r < 4; ++r) stage[fq * 4 + r][j * 16 + fr] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lr = q * 4 + er;             // row of the strip
+      const int64_t row = m0 + wm * 64 + i * 16 + lr;
+      float4 v = *reinterpret_cast<const float4*>(&stage[lr][ec]);
+      if (row < M && gcol < Nc) {
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (ep.act == GCNX_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (ep.act == GCNX_ACT_PRELU) {
+          v.x = v.x > 0.f ? v.x : alpha4.x * v.x; v.y = v.y > 0.f ? v.y : alpha4.y * v.y;
+          v.z = v.z > 0.f ? v.z : alpha4.z * v.z; v.w = v.w > 0.f ? v.w : alpha4.w * v.w;
+        }
+        float* dst = cz + row * ldc + gcol;
+        if (col_vec) {
+          if (ep.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(ep.mask + row * ep.ldmask + gcol);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          }
+          if (ep.accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(dst);
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+          }
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (gcol + t < Nc) {
+              float o = vv[t];
+              if (ep.mask) o = ep.mask[row * ep.ldmask + gcol + t] > 0.f ? o : 0.f;
+              if (ep.accumulate) o += dst[t];
+              dst[t] = o;
+            }
+        }
       }
+    }
+    __builtin_amdgcn_wave_barrier();         // the strip is consumed before the next one overwrites it
   }
 }
 
@@ -405,7 +458,7 @@ int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const 
   if (n == 0 || fo == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, x && w && out, "gcnx_gemm: NULL pointer");
   GCNX_REQUIRE(ctx, ldx >= fi && ldo >= fo, "gcnx_gemm: leading dimension too small");
-  Epilogue ep{bias, act == GCNX_ACT_PRELU ? alpha : nullptr, nullptr, 0, act, 0};
+  Epilogue ep{bias, act == GCNX_ACT_PRELU ? alpha : nullptr, nullptr, 0, act, 0, al16(out) && ldo % 4 == 0};
   if (prec != GCNX_PREC_F32) return launch_bf16_nn(ctx, x, ldx, w, fi, fo, 1, out, ldo, n, prec, ep);
   dim3 grid(gcnx_cdiv(fo, BN), gcnx_cdiv(n, BM), 1);
   const int va = al16(x) && ldx % 4 == 0, vb = al16(w) && fo % 4 == 0;
@@ -428,7 +481,8 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
   GCNX_REQUIRE(ctx, dh && w && dx, "gcnx_gemm_dx: NULL pointer");
   GCNX_REQUIRE(ctx, lddh >= fo && lddx >= fi && (!y_mask || ldy >= fi), "gcnx_gemm_dx: leading dimension too small");
   // dX[n, i] = sum_o dH[n, o] * W[i, o]:  A = dH (k contiguous), B[k=o][j=i] = W[i*fo + o] (k contiguous).
-  Epilogue ep{nullptr, nullptr, y_mask, ldy, GCNX_ACT_NONE, accumulate};
+  Epilogue ep{nullptr, nullptr, y_mask, ldy, GCNX_ACT_NONE, accumulate,
+              al16(dx) && lddx % 4 == 0 && (!y_mask || (al16(y_mask) && ldy % 4 == 0))};
   if (prec != GCNX_PREC_F32) {
     int rc = launch_bf16_nn(ctx, dh, lddh, w, fi, fo, 0, dx, lddx, n, prec, ep);
     if (rc) return rc;
@@ -466,7 +520,7 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
     if (ns < 1) ns = 1;
     const int64_t kchunk_h = ((ksteps_h + ns - 1) / ns) * HK;
     ns = (int)((n + kchunk_h - 1) / kchunk_h);
-    Epilogue eph{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0};
+    Epilogue eph{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0, fo % 4 == 0 && (ns > 1 || al16(dw))};
     float* tgt = dw;
     if (ns > 1) {
       int rc = gcnx_ws_reserve(ctx, (size_t)ns * fi * fo * sizeof(float));
@@ -499,7 +553,7 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   if (nsplit < 1) nsplit = 1;
   const int64_t kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
   nsplit = (int)((n + kchunk - 1) / kchunk);
-  Epilogue ep{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0};
+  Epilogue ep{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0, 0};
   const int va = al16(x) && ldx % 4 == 0, vb = al16(dh) && lddh % 4 == 0;
   float* target = dw;
   if (nsplit > 1) {
