@@ -234,7 +234,7 @@ def main():
                        "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32)",
                        "hip_graph": not args.no_graph, "gemm_precision": args.prec},
             "device_ms_per_step": dev_ms / args.steps, "final_loss": loss, "final_acc": acc,
-            "roofline": {"kernel": ("spmm_rows_kernel" if small else "spmm_tile_kernel(+rows)") +
+            "roofline": {"kernel": ("spmm_rows_kernel" if small else "spmm_duo_kernel(+rows)") +
                                    " (GCNConv aggregation, weighted, bias+relu fused)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload), "algorithmic_bytes": alg, "avg_launch_us": 1e3 * spmm_ms, "launches": iters},

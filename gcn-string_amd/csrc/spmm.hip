@@ -8,16 +8,14 @@
 //
 // Two kernels.
 //
-// Kernel "block" (used when the caller passes the diagonal blocks of the disjoint batch, i.e.
-// graph_ptr): the gather never leaves the CU.  A workgroup owns (graph g, 32-column slab): it
-// copies the slab of g's feature rows H[rows of g, slab] into LDS once (coalesced 128-B row
-// segments), then every output row of g is a sum of LDS rows.  HBM/L2 see each feature element
-// once (compulsory traffic); the ~10x re-read of the gather is served by LDS.  Each group of
-// LPR = 8 lanes owns one output row (8 rows per wave in flight); a row's CSR entries are fetched
-// 8 at a time into the group's registers and broadcast inside the group with __shfl, so there
-// is no cross-lane reduction at all.  80 KiB of LDS per workgroup -> 2 workgroups per CU: one
-// streams its tile in while the other computes.  Graphs too large for a 32-column tile are
-// done in 2 (4) passes of 16 (8) columns; beyond that the same loop gathers from global memory.
+// Tile kernel (used when the caller passes the diagonal blocks of the disjoint batch, i.e. a plan over graph_ptr,
+// and the batch has enough (graph, slab) units to fill the chip): the gather never leaves the CU.  A workgroup
+// owns (graph g, 32-column slab): it copies the slab of g's feature rows H[rows of g, slab] into LDS once by
+// LDS-DMA (128-byte row pieces), then every output row of g is a sum of LDS rows.  HBM sees each feature element
+// once (compulsory traffic); the ~10x re-read of the gather is served by LDS.  A quad of lanes owns one output
+// row; a row's CSR entries reach the quad's lanes by DPP broadcasts, so there is no cross-lane reduction.
+// Graphs of up to 604 rows: 79.5 KiB of LDS per 512-thread workgroup, two workgroups per CU; up to 1236 rows: one
+// 1024-thread workgroup with all 160 KiB; taller graphs: plan-listed row chunks on the rows kernel.
 //
 // Kernel "rows" (no block structure known / odd widths): one 256-thread workgroup owns a contiguous chunk of rows.  The chunk's CSR
 // segment (column indices, values, row pointers) is contiguous in memory and is staged into LDS
@@ -208,12 +206,12 @@ constexpr int kCtrlFloat = kTileFloats + 64;      // two int slots for queue han
 constexpr int kCap32 = kTilePieces / 8;           // 632 rows at FT = 32
 constexpr int kSpan = kPWaves * 16;               // rows a 1024-thread workgroup covers per wave iteration (quad per row)
 
-template <int PPR, int THREADS = kPT, bool HALFSWAP = (PPR == 8)>   // float4 pieces per tile row
+template <int PPR, int THREADS = kPT, bool HALFSWAP = (PPR == 8), int PIECES = kTilePieces>   // float4 pieces per tile row
 __device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h, int64_t ldh, int row0, int ng, int c0) {
   const int tid = threadIdx.x;
   const int total = ng * PPR;
 #pragma unroll
-  for (int u = 0; u < (kTilePieces + THREADS - 1) / THREADS; ++u) {
+  for (int u = 0; u < (PIECES + THREADS - 1) / THREADS; ++u) {
     const int i = tid + u * THREADS;
     if (i < total) {
       const int r = i / PPR;
@@ -325,109 +323,6 @@ __device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, cons
   }
 }
 
-// Two-phase reduction for the static-schedule kernel.  Vector-memory results return in order, so a
-// load issued after the next tile's LDS-DMA cannot be consumed before that whole tile has landed:
-// the on-demand fetch of rows longer than 16 entries (a few per cent of the rows, hence in most waves)
-// used to stall nearly every wave on the DMA it was supposed to overlap with.  Phase A therefore
-// touches no global memory except its stores: every row is reduced over its first 16 entries (already
-// in registers) and rows that fit are finished.  Phase B, at the end of the step when the DMA is
-// (almost) complete anyway, re-reduces the long rows including their tails.
-#define GCNX_RSTEP4(J, MC, MV, BASE, BB)                                                                       \
-  if ((J) == 0 || __builtin_amdgcn_ballot_w64((BASE) + 4 * (J) < (BB)) != 0) {                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      const int off = quad_bcast<4, (J)>(MC[i]);                                                               \
-      f32x2 w2 = f32x2{1.f, 1.f};                                                                              \
-      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[i]))); w2 = f32x2{w, w}; } \
-      _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                        \
-        const float4 hv = *reinterpret_cast<const float4*>(tbase + (CPL == 2 ? (off ^ (64 * j)) : off));       /* CPL 2 only with LPR 4 */ \
-        if (WEIGHTED) {                                                                                        \
-          acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[j][0]);                             \
-          acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[j][1]);                             \
-        } else {                                                                                               \
-          acc[j][0] += f32x2{hv.x, hv.y};                                                                      \
-          acc[j][1] += f32x2{hv.z, hv.w};                                                                      \
-        }                                                                                                      \
-      }                                                                                                        \
-    }                                                                                                          \
-  }
-
-template <int NI, int LPR, int CPL, bool WEIGHTED, int SPAN>
-__device__ __forceinline__ void tile_reduce2(const float* __restrict__ tile, const int32_t* __restrict__ colidx,
-                                             const float* __restrict__ vals, const float4 (&bv)[CPL],
-                                             float* __restrict__ out, int64_t ldo, int row0, int ng, int c0, int act,
-                                             int pad, int last4, const int (&a)[NI], const int (&b)[NI],
-                                             const int (&mc)[NI][4], const float (&mv)[NI][4], int dbg) {
-  // LPR lanes per row (4: one quad; 8: two quads holding the same entries), CPL float4 chunks per lane
-  constexpr int FT = LPR * 4 * CPL;
-  constexpr int RB = FT * 4;   // bytes per tile row
-  const int lane = threadIdx.x & 63;
-  const int sub = lane % LPR;
-  const int rbase = (threadIdx.x >> 6) * (64 / LPR) + lane / LPR;
-  const char* tbase = reinterpret_cast<const char*>(tile) + sub * 16;
-  auto finish = [&](const f32x2 (&acc)[CPL][2], int r) {
-    if (dbg & 4) return;                                       // timing-only: no stores
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      float4 o = make_float4(acc[j][0][0] + bv[j].x, acc[j][0][1] + bv[j].y, acc[j][1][0] + bv[j].z, acc[j][1][1] + bv[j].w);
-      if (act == GCNX_ACT_RELU) {
-        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-      }
-      *reinterpret_cast<float4*>(out + (int64_t)(row0 + r) * ldo + c0 + (sub + LPR * j) * 4) = o;
-    }
-  };
-  // The per-t index registers are selected with a switch (compile-time register names in every case) so that
-  // the loop over t is a real loop: one copy of the 16-entry body, bounded register pressure, no spills --
-  // a spilled value would be a scratch LOAD, i.e. a vector-memory result that has to wait for the whole
-  // in-flight tile DMA.
-  // ---- phase A: first 16 entries of every row, from registers
-#pragma unroll
-  for (int t = 0; t < NI; ++t) if (t * SPAN < ng) {
-    __builtin_amdgcn_sched_barrier(0);   // one row group at a time: bounds the live ranges, no spills
-    const int r = rbase + t * SPAN;
-    const int at = a[t], bt = b[t];
-    const int (&m)[4] = mc[t];
-    const float (&v)[4] = mv[t];
-    f32x2 acc[CPL][2];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
-    if (!(dbg & 2)) {                                          // timing-only: no reduction
-      GCNX_RSTEP4(0, m, v, at, bt)
-      GCNX_RSTEP4(1, m, v, at, bt)
-      GCNX_RSTEP4(2, m, v, at, bt)
-      GCNX_RSTEP4(3, m, v, at, bt)
-    }
-    if (r < ng && (bt - at <= 16 || (dbg & 2))) finish(acc, r);
-  }
-  // ---- phase B: rows with more than 16 entries (rare; wave-uniform skip)
-#pragma unroll
-  for (int t = 0; t < NI; ++t) if (t * SPAN < ng) {
-    __builtin_amdgcn_sched_barrier(0);
-    const int at = a[t], bb = b[t];
-    if (__builtin_amdgcn_ballot_w64(bb - at > 16) == 0 || (dbg & 2)) continue;
-    int m[4] = {mc[t][0], mc[t][1], mc[t][2], mc[t][3]};
-    float v[4] = {mv[t][0], mv[t][1], mv[t][2], mv[t][3]};
-    const int r = rbase + t * SPAN;
-    f32x2 acc[CPL][2];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
-    GCNX_RSTEP4(0, m, v, at, bb)
-    GCNX_RSTEP4(1, m, v, at, bb)
-    GCNX_RSTEP4(2, m, v, at, bb)
-    GCNX_RSTEP4(3, m, v, at, bb)
-    int base = at + 16;
-    while (__builtin_amdgcn_ballot_w64(base < bb) != 0) {
-      fetch_entries<WEIGHTED, RB>(colidx, vals, base, sub & 3, bb, row0, pad, last4, m, v);   // padded past the row end
-      GCNX_RSTEP4(0, m, v, base, bb)
-      GCNX_RSTEP4(1, m, v, base, bb)
-      GCNX_RSTEP4(2, m, v, base, bb)
-      GCNX_RSTEP4(3, m, v, base, bb)
-      base += 16;
-    }
-    if (r < ng && bb - at > 16) finish(acc, r);
-  }
-}
-#undef GCNX_RSTEP4
-
 // Items of one tier: (graph of the tier's list) x (slab of FT*NPASS columns), each done in NPASS
 // steps of FT columns that share one index burst (tier 1: FT = 32; tier 2: FT = 16).
 // NI = wave iterations that cover the largest graph of the tier.
@@ -512,98 +407,181 @@ __global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
   }
 }
 
-// Static-schedule version of the tile kernel.  Ablation of the queue-driven kernel above showed its
-// time does not move when the tile DMA, the reduction and the stores are all removed: each step was
-// bound by a chain of dependent round trips (queue pop -> graph descriptor -> row pointers -> entries)
-// in front of its barrier.  Here nothing on that chain remains per step:
-//  * a work unit = (graph, SG consecutive column slabs).  The CSR data of a unit is fetched into
-//    registers ONCE and reused by its SG steps (the slabs of a graph share rows and entries);
-//  * units are dealt to the persistent workgroups statically, in snake order over the size-sorted
-//    graph list (round r: unit r*G + w, or r*G + G-1-w on odd rounds), which balances the load without
-//    atomics; the next unit's descriptor and row pointers are prefetched a whole unit ahead;
-//  * per step: barrier, start the LDS-DMA of the next tile, reduce the current one.
-template <int THREADS, int NI, int FT, int SG, bool WEIGHTED>
-__global__ __launch_bounds__(THREADS, THREADS / 256) void spmm_tile3_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-    const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-    const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */, int act, int nunits,
-    int n, int dbg /* timing-only ablation bits: 1 no tile DMA, 2 no reduction, 4 no stores, 8 no index burst */) {
-  constexpr int LPR = FT / 4;                // lanes per row: one float4 each (32-column tile: 8 lanes = 128 B per row per
-                                             // ds_read_b128, 1.6x fewer LDS cycles than 4 lanes x 2 chunks: fewer bank conflicts)
-  constexpr int CPL = 1;
-  constexpr int SPAN = (THREADS / 64) * (64 / LPR);  // rows the workgroup covers per wave iteration
-  constexpr int PAD = kTileFloats / FT;      // index of the all-zero row
-  constexpr bool EARLY_RP = NI <= 3;         // early row-pointer prefetch only where registers allow         // prefetch the next unit's row pointers where registers allow
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+// Tile DMA with a uniform 64-bit base (SGPR pair) and a 32-bit per-lane element offset: one register per piece
+// instead of a 64-bit pointer (hoisted 64-bit row addresses were spilled, and each reload put a vmcnt(0) in
+// front of its piece, serialising the tile stream).  Needs ng * ldh < 2^32.
+template <int PPR, int THREADS, int PIECES>
+__device__ __forceinline__ void tile_dma32(float* buf, const float* __restrict__ gbase, unsigned ld32, int ng) {
   const int tid = threadIdx.x;
-  const int w = blockIdx.x, G = gridDim.x;
-  auto unit_of = [&](int round) { return round * G + ((round & 1) ? (G - 1 - w) : w); };
-  int round = 0;
-  int u = unit_of(0);
-  if (u >= nunits) return;
-  if (tid < 32) lds[kTileFloats + tid] = 0.f;                 // zero rows of both buffers
-  else if (tid < 64) lds[kBufFloats + kTileFloats + tid - 32] = 0.f;
-  const int last4 = rowptr[n] - 4;
-  const int sub = (tid & 63) % LPR;
-
-  int2 g = graphs[u / upg];
-  int cbase = (u % upg) * SG * FT;
-  int a[NI], b[NI], mc[NI][4];
-  float mv[NI][4];
-  tile_load_rowptr<NI, SPAN, LPR>(rowptr, g.x, g.y, a, b);
-  tile_load_entries<NI, WEIGHTED, FT * 4>(colidx, vals, g.x, PAD, last4, a, b, mc, mv);
-  if (!(dbg & 1)) tile_dma<FT / 4, THREADS, false>(lds, h, ldh, g.x, g.y, cbase);
-  int buf = 0;
-
-  while (true) {
-    const int un = unit_of(round + 1);
-    const bool has_next = un < nunits;
-    int2 gn = g;
-    int cnext = 0;
-    int a_n[NI], b_n[NI];
-    if (has_next) {
-      gn = graphs[un / upg];
-      cnext = (un % upg) * SG * FT;
-      if (EARLY_RP) tile_load_rowptr<NI, SPAN, LPR>(rowptr, gn.x, gn.y, a_n, b_n);
-    }
-    // The bias slices of the unit's SG slabs are the only ordinary global loads the reductions consume.  hipcc
-    // waits vmcnt(0) at the use of ANY ordinary load result while an LDS-DMA is in flight -- i.e. for the whole
-    // next tile -- so they are fetched once per unit, here, and consumed (the empty asm is their first use)
-    // before any step of the unit starts its DMA.  Inside the steps nothing but stores touches global memory.
-    float4 bvu[SG];
+  const int total = ng * PPR;
 #pragma unroll
-    for (int q = 0; q < SG; ++q) {
-      bvu[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) bvu[q] = *reinterpret_cast<const float4*>(bias + cbase + q * FT + sub * 4);
+  for (int u = 0; u < (PIECES + THREADS - 1) / THREADS; ++u) {
+    const int i = tid + u * THREADS;
+    if (i < total) {
+      const unsigned off = (unsigned)(i / PPR) * ld32 + (unsigned)(i % PPR) * 4u;
+      float* dst = buf + (u * THREADS + (tid & ~63)) * 4;   // wave-uniform base; the DMA adds lane*16 bytes
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-#pragma unroll
-    for (int q = 0; q < SG; ++q) asm volatile("" : "+v"(bvu[q].x), "+v"(bvu[q].y), "+v"(bvu[q].z), "+v"(bvu[q].w));
-#pragma unroll
-    for (int s = 0; s < SG; ++s) {
-      __syncthreads();   // this step's tile has landed (vmcnt drained before the barrier); the previous reduction is over
-      const int c0 = cbase + s * FT;
-      float4 bv[CPL] = {bvu[s]};
-      if (dbg & 1) {}
-      else if (s + 1 < SG) tile_dma<FT / 4, THREADS, false>(lds + (buf ^ 1) * kBufFloats, h, ldh, g.x, g.y, cbase + (s + 1) * FT);
-      else if (has_next) tile_dma<FT / 4, THREADS, false>(lds + (buf ^ 1) * kBufFloats, h, ldh, gn.x, gn.y, cnext);
-      tile_reduce2<NI, LPR, CPL, WEIGHTED, SPAN>(lds + buf * kBufFloats, colidx, vals, bv, out, ldo, g.x, g.y, c0, act, PAD, last4, a, b,
-                                      mc, mv, dbg);
-      buf ^= 1;
-    }
-    if (!has_next) break;
-    // index burst of the next unit (once per SG steps; it is waited for at the next barrier)
-    if (EARLY_RP) {
-#pragma unroll
-      for (int t = 0; t < NI; ++t) { a[t] = a_n[t]; b[t] = b_n[t]; }
-    } else {
-      tile_load_rowptr<NI, SPAN, LPR>(rowptr, gn.x, gn.y, a, b);
-    }
-    if (!(dbg & 8)) tile_load_entries<NI, WEIGHTED, FT * 4>(colidx, vals, gn.x, PAD, last4, a, b, mc, mv);
-    g = gn;
-    cbase = cnext;
-    ++round;
   }
 }
+
+// ----------------------------------------------------------------------------------------------
+// Tile kernel (default with a plan): independent workgroups, no pipeline inside a workgroup.  Per work unit
+// (graph, sg column slabs) one index burst -- row pointers and the first 16 entries of every row, kept in registers
+// and shared by the unit's slabs -- then per slab
+//     barrier | LDS-DMA of the tile -> LDS | barrier | reduce + store.
+// Nothing in a workgroup is consumed while its own DMA is in flight, so the in-order vmcnt problem of the
+// double-buffered queue kernel above does not arise (a row's entries past 16 are fetched on demand).
+// Units are dealt statically in snake order over the size-sorted graph list; workgroup ids are folded so that the
+// slabs of one graph (consecutive units) run on ONE XCD and share its L2 for the index arrays.
+// Measured on config 3 (same box): tier 1 0.53-0.57 ns/row against 0.71-0.73 for the queue kernel; copying the
+// tile in and zeros out (no index burst, no reduction) alone runs at 5.1 TB/s.  An L2 prefetch of the next tile
+// during the reduction (one dword per row piece) and a chunk-order swizzle against LDS bank conflicts were both
+// measured: -6 % and 0 %.
+// ----------------------------------------------------------------------------------------------
+// Two shapes of the same kernel: THREADS = 512 with 79.5 KiB (two workgroups per CU; graphs up to kDuoCap32 rows)
+// and THREADS = 1024 with all 160 KiB (one workgroup per CU; graphs up to kSoloCap32 rows).
+constexpr int kDuoLdsFloats = 20352;             // 81 408 B: two workgroups fit one CU's 160 KiB
+constexpr int kSoloLdsFloats = 40960;            // 160 KiB
+constexpr int kDuoCap32 = 604;                   // rows of a 32-column tile (+ zero row + bias + row pointers)
+constexpr int kSoloCap32 = 1236;
+template <int THREADS, int FT> struct DuoShape {
+  static constexpr int LDSF = THREADS == 512 ? kDuoLdsFloats : kSoloLdsFloats;
+  static constexpr int CAP = (FT == 32 ? (THREADS == 512 ? kDuoCap32 : kSoloCap32) : ((LDSF - 2 * FT - 2) / (FT + 1)) & ~3);
+};
+
+#define GCNX_DSTEP4(J, MC, MV, BASE, BB)                                                                       \
+  if ((J) == 0 || __builtin_amdgcn_ballot_w64((BASE) + 4 * (J) < (BB)) != 0) {                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      const int off = quad_bcast<4, (J)>(MC[i]);                                                               \
+      f32x2 w2 = f32x2{1.f, 1.f};                                                                              \
+      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[i]))); w2 = f32x2{w, w}; } \
+      _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                        \
+        const float4 hv = *reinterpret_cast<const float4*>(tb[j] + off);                                       \
+        if (WEIGHTED) {                                                                                        \
+          acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[j][0]);                             \
+          acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[j][1]);                             \
+        } else {                                                                                               \
+          acc[j][0] += f32x2{hv.x, hv.y};                                                                      \
+          acc[j][1] += f32x2{hv.z, hv.w};                                                                      \
+        }                                                                                                      \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
+template <int THREADS, int FT, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+    const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
+    const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */,
+    int sg /* column slabs per unit */, int act, int nunits, int n, int dbg) {
+  constexpr int CPL = FT / (4 * LPR);           // float4 chunks per lane (2 only with LPR = 4, FT = 32)
+  constexpr int RPW = 64 / LPR;                 // rows per wave
+  constexpr int SPAN = (THREADS / 64) * RPW;
+  constexpr int CAP = DuoShape<THREADS, FT>::CAP;
+  constexpr int NI = (CAP + SPAN - 1) / SPAN;   // row groups per unit: their first 16 entries live in registers
+  constexpr int RB = FT * 4;                    // bytes per tile row
+  static_assert((CAP + 2) * FT + CAP + 2 <= DuoShape<THREADS, FT>::LDSF, "tile + zero row + bias + row pointers must fit");
+  static_assert(NI <= 5, "index registers");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lbias = lds + (CAP + 1) * FT;          // this step's bias slice
+  int* rp = reinterpret_cast<int*>(lds + (CAP + 2) * FT);   // the unit's row pointers (ng + 1)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sub = lane % LPR, slot = sub & 3;
+  const int rbase = (tid >> 6) * RPW + lane / LPR;
+  // ds_read_b128 is served in four 16-lane groups {quads 0,3,5,6}, {1,2,4,7} (+8 for the upper half-wave) over
+  // 64 banks: a 128-byte tile row covers half a bank row, a 64-byte chunk a quarter.  With one quad per row and
+  // two chunks per lane (CPL = 2), reading chunk j in the same order everywhere leaves the 4 rows of a group only
+  // the 2 quarters (row parity, j): expected 2.75 LDS cycles per read.  Quads 2..5 therefore read their chunks in
+  // the opposite order (chunk j ^ 1 first): each group then has two quads on either chunk, 1.75 expected.
+  const int csw = (CPL == 2) ? ((((lane >> 2) + 2) >> 2) & 1) : 0;
+  const char* tb[CPL];                          // LDS base of this lane's j-th chunk
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) tb[j] = reinterpret_cast<const char*>(lds) + (sub + LPR * (j ^ csw)) * 16;
+  // workgroup id folded per XCD (ids are dealt round-robin to the 8 XCDs): consecutive virtual ids share an L2
+  const int G = gridDim.x;
+  const int w = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+  auto unit_of = [&](int round) { return round * G + ((round & 1) ? (G - 1 - w) : w); };
+  int u = unit_of(0);
+  if (u >= nunits) return;                      // uniform per workgroup
+  if (tid < FT) lds[CAP * FT + tid] = 0.f;      // the all-zero row padding entries point at
+  const int last4 = rowptr[n] - 4;
+
+  int2 g = graphs[u / upg];
+  for (int round = 0;; ++round) {
+    const int cbase = (u % upg) * sg * FT;
+    const int un = unit_of(round + 1);
+    const bool has_next = un < nunits;
+    const int2 gn = has_next ? graphs[un / upg] : g;
+    // index burst of the unit: row pointers and the first 16 entries of every row this lane group owns, once
+    // for all sg slabs (they share rows and entries).  In flight together with the first tile.
+    int mc[NI][4];
+    float mv[NI][4];
+    {
+      int a[NI], b[NI];
+      tile_load_rowptr<NI, SPAN, LPR>(rowptr, g.x, g.y, a, b);
+      if (!(dbg & 8)) tile_load_entries<NI, WEIGHTED, RB>(colidx, vals, g.x, CAP, last4, a, b, mc, mv);
+    }
+    for (int s = 0; s < sg; ++s) {
+      const int c0 = cbase + s * FT;
+      // The previous reduction no longer reads the tile / bias / row pointers.  Its LDS reads were consumed by
+      // the arithmetic, so a bare s_barrier is enough: __syncthreads() would also drain the output stores
+      // (vmcnt(0) of its release fence) before the next tile may even be requested.
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      unsigned ld32 = (unsigned)ldh;
+      asm volatile("" : "+s"(ld32));            // opaque per step: the piece offsets are recomputed, not hoisted and spilled
+      if (!(dbg & 1)) tile_dma32<FT / 4, THREADS, CAP * (FT / 4)>(lds, h + (int64_t)g.x * ldh + c0, ld32, g.y);
+      if (s == 0) for (int i = tid; i <= g.y; i += THREADS) rp[i] = rowptr[g.x + i];
+      if (tid < FT) lbias[tid] = bias ? bias[c0 + tid] : 0.f;
+      __syncthreads();                          // the tile (and on s == 0 the index burst) has landed
+#pragma unroll
+      for (int t = 0; t < NI; ++t) if (t * SPAN < g.y) {
+        __builtin_amdgcn_sched_barrier(0);      // one row group at a time: bounded live ranges
+        const int r = rbase + t * SPAN;
+        const int rc = min(r, g.y - 1);
+        const int at = rp[rc], bt = r < g.y ? rp[rc + 1] : at;
+        f32x2 acc[CPL][2];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
+        if (!(dbg & 2)) {
+          GCNX_DSTEP4(0, mc[t], mv[t], at, bt)
+          GCNX_DSTEP4(1, mc[t], mv[t], at, bt)
+          GCNX_DSTEP4(2, mc[t], mv[t], at, bt)
+          GCNX_DSTEP4(3, mc[t], mv[t], at, bt)
+          int base = at + 16;
+          while (__builtin_amdgcn_ballot_w64(base < bt) != 0) {   // rows longer than 16 entries (2 % at degree 10)
+            int xc[4];
+            float xv[4];
+            fetch_entries<WEIGHTED, RB>(colidx, vals, base, slot, bt, g.x, CAP, last4, xc, xv);
+            GCNX_DSTEP4(0, xc, xv, base, bt)
+            GCNX_DSTEP4(1, xc, xv, base, bt)
+            GCNX_DSTEP4(2, xc, xv, base, bt)
+            GCNX_DSTEP4(3, xc, xv, base, bt)
+            base += 16;
+          }
+        }
+        if (r < g.y && !(dbg & 4)) {
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) {
+            const float4 bvj = *reinterpret_cast<const float4*>(lbias + (sub + LPR * (j ^ csw)) * 4);
+            float4 o = make_float4(acc[j][0][0] + bvj.x, acc[j][0][1] + bvj.y, acc[j][1][0] + bvj.z, acc[j][1][1] + bvj.w);
+            if (act == GCNX_ACT_RELU) {
+              o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    g = gn;
+    u = un;
+  }
+}
+#undef GCNX_DSTEP4
 
 // Fallback for widths / strides that are not multiples of 4 floats: one lane per column.
 __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restrict__ rowptr,
@@ -691,31 +669,38 @@ int launch_tiles(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, co
   return GCNX_OK;
 }
 
-template <int THREADS, int NI, int FT, int SG>
-int launch_tiles3(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
-                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                  const int2* graphs, int ngraphs) {
-  constexpr int lds_bytes = 2 * kBufFloats * 4;
+template <int THREADS, int FT, int LPR>
+int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+               int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+               const int2* graphs, int ngraphs) {
+  constexpr int lds_bytes = DuoShape<THREADS, FT>::LDSF * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile3_kernel<THREADS, NI, FT, SG, true>),
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile3_kernel<THREADS, NI, FT, SG, false>),
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   int dbg = 0;   // GCNX_SPMM_DBG: timing-only ablation bits (results are WRONG when set)
   if (const char* e = getenv("GCNX_SPMM_DBG")) dbg = atoi(e);
-  const int upg = f / (FT * SG);   // units per graph
+  const int full = (THREADS == 512 ? 2 : 1) * ctx->num_cus;   // resident workgroups
+  // column slabs per unit share one index burst; keep >= 6 units per workgroup so the static deal stays balanced
+  const int slabs = f / FT;
+  int sg = 1;
+  for (int c = 8; c > 1; c >>= 1)
+    if (slabs % c == 0 && (long long)ngraphs * (slabs / c) >= 6LL * full) { sg = c; break; }
+  if (const char* e = getenv("GCNX_SPMM_SG")) { const int v = atoi(e); if (v >= 1 && slabs % v == 0) sg = v; }
+  const int upg = slabs / sg;
   const long long nunits = (long long)ngraphs * upg;
   if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
-  const int grid = (int)(nunits < ctx->num_cus ? nunits : ctx->num_cus);   // one persistent workgroup per CU
+  const int grid = (int)(nunits < full ? nunits : full);
   if (vals)
-    hipLaunchKernelGGL((spmm_tile3_kernel<THREADS, NI, FT, SG, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, colidx,
-                       vals, h, ldh, bias, out, ldo, graphs, upg, act, (int)nunits, n, dbg);
+    hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
+                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg);
   else
-    hipLaunchKernelGGL((spmm_tile3_kernel<THREADS, NI, FT, SG, false>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, colidx,
-                       vals, h, ldh, bias, out, ldo, graphs, upg, act, (int)nunits, n, dbg);
+    hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, false>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
+                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -729,6 +714,7 @@ struct gcnx_spmm_plan {
   int nblocks = 0;
   int n1 = 0, n2 = 0, nchunks = 0;      // tier-1 graphs, tier-2 graphs, row chunks of larger graphs
   long long tile_rows = 0;
+  int cap1 = kDuoCap32, cap2 = kSoloCap32;   // tier limits the lists were built for
   int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
 };
 
@@ -748,12 +734,14 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     }
     std::vector<int2> t1, t2, ch;
     long long tile_rows = 0;
+    int cap1 = kDuoCap32, cap2 = kSoloCap32;
+    if (const char* tv = getenv("GCNX_SPMM_TILE")) if (tv[0] == 'q') { cap1 = kCap32; cap2 = 2 * kCap32; }   // queue kernel's tiers
     for (int g = 0; g < nblocks; ++g) {
       const int r0 = bp[g], ng = bp[g + 1] - bp[g];
       if (ng < 0) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g);
       if (ng == 0) continue;
-      if (ng <= kCap32) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; }
-      else if (ng <= 2 * kCap32) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; }
+      if (ng <= cap1) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; }
+      else if (ng <= cap2) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; }
       else for (int r = r0; r < r0 + ng; r += kRowsPerChunk) ch.push_back(make_int2(r, std::min(r + kRowsPerChunk, r0 + ng)));
     }
     auto by_size = [](const int2& x, const int2& y) { return x.y != y.y ? x.y > y.y : x.x < y.x; };
@@ -763,6 +751,7 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     p->nblocks = nblocks;
     p->n1 = (int)t1.size(); p->n2 = (int)t2.size(); p->nchunks = (int)ch.size();
     p->tile_rows = tile_rows;
+    p->cap1 = cap1; p->cap2 = cap2;
     const size_t total = t1.size() + t2.size() + ch.size();
     if (total) {
       std::vector<int2> all;
@@ -821,46 +810,35 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  int* queues = ctx->flag + 1;
-  GCNX_HIP(ctx, hipMemsetAsync(queues, 0, 2 * sizeof(int), ctx->stream));
-  // GCNX_SPMM_TILE: tuning knob.  Default = the queue-driven kernel (fastest measured on config 3: 0.79-0.83 ms);
-  // "s" = the static-schedule kernel (spmm_tile3_kernel, 0.96 ms), "k" = the same with 1024-thread workgroups.
-  const char* tv = getenv("GCNX_SPMM_TILE");
-  const int sg = (f % 128 == 0) ? 4 : (f % 64 == 0 ? 2 : 1);   // column slabs per work unit (they share one index burst)
-  if (tv && (tv[0] == 's' || tv[0] == 'k')) {
-    const bool t512 = tv[0] != 'k';   // "k": 1024-thread workgroups (128 VGPRs/lane); default 512 threads (256)
-    (void)sg;
-#define GCNX_T3(T, NI, FT, SG, G, NG) launch_tiles3<T, NI, FT, SG>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, G, NG)
+  // GCNX_SPMM_TILE=q (read at plan creation too: the tiers differ): the older queue-driven kernel, one persistent
+  // 1024-thread workgroup per CU with two tile buffers; measured 0.78-0.82 ms on config 3 against 0.67-0.69 ms.
+  if (plan->cap1 == kCap32) {
+    int* queues = ctx->flag + 1;
+    GCNX_HIP(ctx, hipMemsetAsync(queues, 0, 2 * sizeof(int), ctx->stream));
+    // One column pass per work item: sharing an index burst between 2 or 4 passes (NPASS > 1) measured 3-10 % slower
+    // there (the items get longer and the work queue coarser), so only NPASS = 1 is instantiated.
     if (plan->n1 > 0) {
-      int rc = f % 64 == 0 ? (t512 ? GCNX_T3(512, 10, 32, 2, plan->dev, plan->n1) : GCNX_T3(1024, 5, 32, 4, plan->dev, plan->n1))
-                            : (t512 ? GCNX_T3(512, 10, 32, 1, plan->dev, plan->n1) : GCNX_T3(1024, 5, 32, 1, plan->dev, plan->n1));
+      int rc = launch_tiles<3, 32, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, queues);
       if (rc) return rc;
     }
     if (plan->n2 > 0) {
-      int rc = f % 32 == 0 ? (t512 ? GCNX_T3(512, 10, 16, 2, plan->dev + plan->n1, plan->n2) : GCNX_T3(1024, 5, 16, 4, plan->dev + plan->n1, plan->n2))
-                           : (t512 ? GCNX_T3(512, 10, 16, 2, plan->dev + plan->n1, plan->n2) : GCNX_T3(1024, 5, 16, 2, plan->dev + plan->n1, plan->n2));
+      int rc = launch_tiles<5, 16, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
+                                      plan->n2, queues + 1);
       if (rc) return rc;
     }
-#undef GCNX_T3
-    if (plan->nchunks > 0) {
-      dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
-                    plan->nchunks);
-      GCNX_LAUNCH_OK(ctx);
+  } else {
+    // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
+    if (plan->n1 > 0) {
+      int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1);
+      if (rc) return rc;
     }
-    return GCNX_OK;
+    if (plan->n2 > 0) {
+      int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
+                                       plan->n2);
+      if (rc) return rc;
+    }
   }
-  // One column pass per work item: sharing an index burst between 2 or 4 passes (NPASS > 1) measured 3-10 % slower
-  // on config 3 (the items get longer and the work queue coarser), so only NPASS = 1 is instantiated.
-  if (plan->n1 > 0) {
-    int rc = launch_tiles<3, 32, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, queues);
-    if (rc) return rc;
-  }
-  if (plan->n2 > 0) {
-    int rc = launch_tiles<5, 16, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                    plan->n2, queues + 1);
-    if (rc) return rc;
-  }
-  if (plan->nchunks > 0) {
+  if (plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
                   plan->nchunks);
     GCNX_LAUNCH_OK(ctx);
