@@ -64,6 +64,7 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->flag, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(ctx->flag, 0, 4 * sizeof(int));   // [3] is the head kernel's arrival ticket
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {

@@ -354,6 +354,17 @@ def softmax_cce(ctx, logits, y, probs, loss_acc, dlogits=None, denom=None):
                                      _p(loss_acc), _p(dlogits)))
 
 
+def dense_softmax_cce(ctx, pooled, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None, dpooled=None):
+    """The classifier head in one launch (gcnx_dense_softmax_cce): probs = softmax(pooled W + b); with labels y
+    also loss_acc = [CCE sum / denom, #correct] (overwritten); with dw also dw, db, dpooled."""
+    b, h = pooled.shape
+    c = w.shape[1]
+    ctx._ck(ctx.lib.gcnx_dense_softmax_cce(ctx.h, _p(pooled), pooled.ld, _p(w), _p(bias), _p(y), b, h, c,
+                                           float(denom if denom else max(b, 1)), _p(probs), _p(loss_acc), _p(dw), _p(db),
+                                           _p(dpooled), dpooled.ld if dpooled is not None else 0))
+    return probs
+
+
 def act_bias_grad(ctx, dy, y, dz, act, db=None, alpha=None, dalpha=None):
     n, f = dy.shape
     ctx._ck(ctx.lib.gcnx_act_bias_grad(ctx.h, _p(dy), dy.ld, _p(y), y.ld if y is not None else 0, _p(dz), dz.ld, n,

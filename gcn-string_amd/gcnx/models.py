@@ -157,8 +157,7 @@ class GCN2(_GraphRunner):
         self._bufs = {
             "key": key,
             "h": ctx.empty((n, h)), "y1": ctx.empty((n, h)), "y2": ctx.empty((n, h)), "dz": ctx.empty((n, h)),
-            "pooled": ctx.empty((b, h)), "logits": ctx.empty((b, c)), "probs": ctx.empty((b, c)),
-            "dlogits": ctx.empty((b, c)), "dpooled": ctx.empty((b, h)),
+            "pooled": ctx.empty((b, h)), "probs": ctx.empty((b, c)), "dpooled": ctx.empty((b, h)),
             "arg": ctx.empty((b, h), np.int32) if self.pool == "max" else None,
         }
         return self._bufs
@@ -171,17 +170,18 @@ class GCN2(_GraphRunner):
         D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
         D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
         D.segment_pool(ctx, batch.seg, bufs["y2"], bufs["pooled"], self.pool, bufs["arg"])
-        D.gemm(ctx, bufs["pooled"], p["w3"], p["b3"], bufs["logits"], prec="f32")
-        if with_loss:
-            self.loss_acc.fill_zero()
-            D.softmax_cce(ctx, bufs["logits"], batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom)
+        # Dense(softmax) + CCE + accuracy + the head gradients: one launch (gcnx_dense_softmax_cce)
+        if with_loss == "grads":
+            D.dense_softmax_cce(ctx, bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"], self.loss_acc, denom,
+                                dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"])
+        elif with_loss:
+            D.dense_softmax_cce(ctx, bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"], self.loss_acc, denom)
+        else:
+            D.dense_softmax_cce(ctx, bufs["pooled"], p["w3"], p["b3"], None, bufs["probs"])
 
     def _backward(self, batch, bufs):
         ctx, p, g, prec = self.ctx, self.p, self.g, self.prec
         at = batch.a.transpose()
-        D.gemm_dw(ctx, bufs["pooled"], bufs["dlogits"], g["w3"], prec="f32")
-        D.act_bias_grad(ctx, bufs["dlogits"], None, bufs["dlogits"], None, db=g["b3"])
-        D.gemm_dx(ctx, bufs["dlogits"], p["w3"], bufs["dpooled"], prec="f32")
         # pool gradient with the ReLU mask of layer 2 and its bias gradient fused
         D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"], db=g["b2"])
         D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH2 = A^T dZ2
@@ -206,16 +206,8 @@ class GCN2(_GraphRunner):
         batch = self._as_batch(inputs)
         bufs = self._ensure(batch)
         self._bind(batch)
-        self._run(("fwd", batch.uid), lambda: (self._forward(batch, bufs, False, None),
-                                              self._softmax_only(bufs)))
+        self._run(("fwd", batch.uid), lambda: self._forward(batch, bufs, False, None))
         return bufs["probs"].numpy()
-
-    def _softmax_only(self, bufs):
-        # probabilities without labels: y = zeros gives loss 0; reuse the fused kernel
-        if "zero_y" not in bufs or bufs["zero_y"].shape != bufs["logits"].shape:
-            bufs["zero_y"] = self.ctx.zeros(bufs["logits"].shape)
-            bufs["scratch2"] = self.ctx.zeros(2)
-        D.softmax_cce(self.ctx, bufs["logits"], bufs["zero_y"], bufs["probs"], bufs["scratch2"], None, None)
 
     def loss_and_grads(self, inputs, target, global_batch=None):
         """Forward + loss + every gradient (no update).  Returns (loss, acc)."""
@@ -224,7 +216,7 @@ class GCN2(_GraphRunner):
         denom = float(global_batch or batch.n_graphs)
 
         def seq():
-            self._forward(batch, bufs, True, denom)
+            self._forward(batch, bufs, "grads", denom)
             self._backward(batch, bufs)
         self._bind(batch)
         self._run(("grad", batch.uid, denom), seq)

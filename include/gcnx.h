@@ -150,6 +150,17 @@ GCNX_API int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const fl
 GCNX_API int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t b, int32_t c,
                      float denom, float* probs, float* loss_acc, float* dlogits);
 
+/* The classifier head in ONE launch: probs = softmax(pooled * W + b)  (the model's last Dense,
+ * gcn.py:320 activation="softmax"), loss_acc[0] = CCE(y, probs) summed over the b graphs / denom and
+ * loss_acc[1] = #(argmax probs == argmax y)  (gcn.py:326,335,339; loss_acc is OVERWRITTEN, not accumulated),
+ * and, when dw != NULL, the head gradients tape.gradient (gcn.py:337) produces:
+ * dlogits as gcnx_softmax_cce, dw[h,c] = pooled^T dlogits, db[c] = sum_g dlogits, dpooled[b,h] = dlogits W^T.
+ * y == NULL: probabilities only.  c <= 32.  Same results as gcnx_gemm + gcnx_softmax_cce + gcnx_gemm_dw +
+ * gcnx_act_bias_grad + gcnx_gemm_dx up to fp32 summation order; deterministic (fixed reduction order). */
+GCNX_API int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias,
+                           const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
+                           float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp);
+
 /* ---- backward (what tape.gradient, gcn.py:337, generates) -------------------------------- */
 /* dZ = dY * act'(Y) (mask taken from the saved output Y; PReLU uses the saved pre-activation
  * passed as y and alpha); db[f] = sum_rows dZ (BiasAddGrad).  dz may alias dy.  db/dalpha may

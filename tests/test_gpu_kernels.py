@@ -286,6 +286,45 @@ def test_softmax_cce_matches_keras_semantics(ctx):
     assert abs(la.numpy()[0] - o.cce_loss(y[:10].astype(np.float64), p[:10], denom=40)) < 1e-5
 
 
+@pytest.mark.parametrize("b,h,c", [(32, 128, 2), (1, 16, 1), (1667, 256, 2), (200, 40, 7), (40, 2000, 3)])
+def test_dense_softmax_cce_head(ctx, b, h, c):
+    """gcnx_dense_softmax_cce (one launch) == Dense + softmax + clipped CCE + accuracy + the head gradients of the
+    oracle; several workgroups (b > 64) reduce dW/db/loss in a fixed order: two launches agree bitwise."""
+    from gcnx import device as D
+    o = O()
+    rng = np.random.default_rng(11)
+    pooled = (3 * rng.standard_normal((b, h))).astype(np.float32)
+    w = (rng.standard_normal((h, c)) / np.sqrt(h)).astype(np.float32)
+    bias = rng.standard_normal(c).astype(np.float32)
+    y = np.eye(c, dtype=np.float32)[rng.integers(0, c, b)]
+    if c == 2 and b >= 2:
+        pooled[0] = 0; pooled[0, 0] = 400.0; w[0] = [1.0, -1.0]      # a saturated graph: exercises the clip
+    denom = float(b + 3)                                             # a "global batch" larger than this shard
+    dp, dw_, db_ = ctx.empty((b, h)), ctx.empty((h, c)), ctx.empty(c)
+    probs, la = ctx.empty((b, c)), ctx.to_device(np.array([7.0, 7.0], np.float32))   # overwritten, not accumulated
+    args = (ctx, ctx.to_device(pooled), ctx.to_device(w), ctx.to_device(bias), ctx.to_device(y), probs, la, denom)
+    D.dense_softmax_cce(*args, dw=dw_, db=db_, dpooled=dp)
+    P, W, Y = pooled.astype(np.float64), w.astype(np.float64), y.astype(np.float64)
+    p = o.softmax(P @ W + bias.astype(np.float64))
+    dl = o.softmax_cce_grad(Y, p, denom=denom)
+    assert rel_err(probs.numpy(), p) < TIGHT
+    loss, hits = la.numpy()
+    assert abs(loss - o.cce_loss(Y, p, denom=denom)) < 2e-5 * max(1.0, abs(loss))
+    assert hits == round(o.categorical_accuracy(y, p) * b)
+    assert rel_err(dw_.numpy(), P.T @ dl) < TIGHT and rel_err(db_.numpy(), dl.sum(0)) < TIGHT
+    assert rel_err(dp.numpy(), dl @ W.T) < TIGHT
+    first = (dw_.numpy().copy(), db_.numpy().copy(), la.numpy().copy())
+    D.dense_softmax_cce(*args, dw=dw_, db=db_, dpooled=dp)
+    assert np.array_equal(first[0], dw_.numpy()) and np.array_equal(first[1], db_.numpy()) and np.array_equal(first[2], la.numpy())
+    # loss only, and probabilities only
+    la2 = ctx.zeros(2)
+    D.dense_softmax_cce(ctx, args[1], args[2], args[3], args[4], probs, la2, denom)
+    assert np.array_equal(la2.numpy(), first[2])
+    pr2 = ctx.empty((b, c))
+    D.dense_softmax_cce(ctx, args[1], args[2], args[3], None, pr2)
+    assert np.array_equal(pr2.numpy(), probs.numpy())
+
+
 @pytest.mark.parametrize("act", [None, "relu", "prelu"])
 def test_act_bias_grad(ctx, act):
     from gcnx import device as D
