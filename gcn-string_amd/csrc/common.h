@@ -18,6 +18,15 @@ struct gcnx_ctx {
   size_t ws_bytes = 0;
   int* flag = nullptr;       // device int[4] for validation kernels
   bool capturing = false;
+  // Side stream for gradient "leaves" (weight / bias gradients that nothing downstream in the backward pass
+  // consumes): gcnx_side_begin swaps stream and workspace, so every entry point launches there unchanged.
+  hipStream_t main_stream = nullptr, side_stream = nullptr;
+  void* ws_other = nullptr;          // the workspace of the stream that is NOT current
+  size_t ws_other_bytes = 0;
+  bool on_side = false, side_pending = false;
+  static constexpr int kSideEvents = 8;
+  hipEvent_t ev_fork[kSideEvents] = {}, ev_join[kSideEvents] = {};
+  int ev_next = 0;
   int num_cus = 256;
   std::string arch;
 };

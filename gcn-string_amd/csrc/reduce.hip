@@ -339,6 +339,7 @@ int gcnx_act_bias_grad(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || y, "gcnx_act_bias_grad: y needed for activation gradient");
   GCNX_REQUIRE(ctx, act != GCNX_ACT_PRELU || alpha, "gcnx_act_bias_grad: alpha needed for PReLU");
   GCNX_REQUIRE(ctx, lddy >= f && lddz >= f && (!y || ldy >= f), "gcnx_act_bias_grad: leading dimension too small");
+  if (act == GCNX_ACT_NONE && dz == dy) dz = nullptr;   // identity in place: a pure column sum, nothing is written back
   return colsum_impl(ctx, dy, lddy, n, f, db, y ? y : dy, y ? ldy : lddy, dz, lddz, act, alpha, dalpha);
 }
 

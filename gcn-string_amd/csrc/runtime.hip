@@ -1,5 +1,6 @@
 // libgcnx runtime: context lifecycle, device memory, events, HIP-graph capture.
 #include <new>
+#include <utility>
 
 #include "common.h"
 
@@ -63,6 +64,12 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   ctx->device = device;
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
+  ctx->main_stream = ctx->stream;
+  for (int i = 0; i < gcnx_ctx::kSideEvents && e == hipSuccess; ++i) {
+    e = hipEventCreateWithFlags(&ctx->ev_fork[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->flag, 4 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(ctx->flag, 0, 4 * sizeof(int));   // [3] is the head kernel's arrival ticket
   hipDeviceProp_t prop;
@@ -89,10 +96,17 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
 int gcnx_ctx_destroy(gcnx_ctx* ctx) {
   if (!ctx) return GCNX_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->main_stream);
+  if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->ws_other) (void)hipFree(ctx->ws_other);
   if (ctx->flag) (void)hipFree(ctx->flag);
-  (void)hipStreamDestroy(ctx->stream);
+  for (int i = 0; i < gcnx_ctx::kSideEvents; ++i) {
+    if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  (void)hipStreamDestroy(ctx->main_stream);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   delete ctx;
   return GCNX_OK;
 }
@@ -155,6 +169,7 @@ int gcnx_d2h(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   GCNX_CHECK_CTX(ctx);
   if (bytes == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, dst && src, "gcnx_d2h: NULL pointer");
+  if (ctx->side_pending && !ctx->on_side) { int rc = gcnx_side_join(ctx); if (rc) return rc; }   // results of side sections too
   GCNX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return GCNX_OK;
@@ -170,7 +185,52 @@ int gcnx_d2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int gcnx_sync(gcnx_ctx* ctx) {
   GCNX_CHECK_CTX(ctx);
-  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GCNX_REQUIRE(ctx, !ctx->on_side, "gcnx_sync inside a side section");
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
+  ctx->side_pending = false;
+  return GCNX_OK;
+}
+
+// ---- side sections -------------------------------------------------------------------------------------------
+// begin: everything launched until gcnx_side_end runs on the side stream, ordered after all work submitted to
+// the main stream so far, concurrently with what the main stream is given next.  join: the main stream waits
+// for the side sections ended so far.  Works inside stream capture (the side stream joins the capture through
+// the fork event; the graph then has two branches).
+static void gcnx_swap_streams(gcnx_ctx* ctx) {
+  ctx->stream = ctx->on_side ? ctx->main_stream : ctx->side_stream;
+  std::swap(ctx->ws, ctx->ws_other);
+  std::swap(ctx->ws_bytes, ctx->ws_other_bytes);
+  ctx->on_side = !ctx->on_side;
+}
+
+int gcnx_side_begin(gcnx_ctx* ctx) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, !ctx->on_side, "gcnx_side_begin: already inside a side section");
+  hipEvent_t ev = ctx->ev_fork[ctx->ev_next % gcnx_ctx::kSideEvents];
+  GCNX_HIP(ctx, hipEventRecord(ev, ctx->main_stream));
+  GCNX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ev, 0));
+  gcnx_swap_streams(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_side_end(gcnx_ctx* ctx) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, ctx->on_side, "gcnx_side_end: not inside a side section");
+  gcnx_swap_streams(ctx);
+  ctx->side_pending = true;
+  return GCNX_OK;
+}
+
+int gcnx_side_join(gcnx_ctx* ctx) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, !ctx->on_side, "gcnx_side_join inside a side section");
+  if (!ctx->side_pending) return GCNX_OK;
+  hipEvent_t ev = ctx->ev_join[ctx->ev_next % gcnx_ctx::kSideEvents];
+  ctx->ev_next++;
+  GCNX_HIP(ctx, hipEventRecord(ev, ctx->side_stream));
+  GCNX_HIP(ctx, hipStreamWaitEvent(ctx->main_stream, ev, 0));
+  ctx->side_pending = false;
   return GCNX_OK;
 }
 
@@ -211,6 +271,8 @@ int gcnx_event_destroy(gcnx_ctx* ctx, gcnx_event* ev) {
 int gcnx_capture_begin(gcnx_ctx* ctx) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_capture_begin: a capture is already active");
+  GCNX_REQUIRE(ctx, !ctx->on_side, "gcnx_capture_begin inside a side section");
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
   GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GCNX_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   ctx->capturing = true;
@@ -221,6 +283,8 @@ int gcnx_capture_end(gcnx_ctx* ctx, gcnx_graph** out) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, ctx->capturing, "gcnx_capture_end: no capture active");
   GCNX_REQUIRE(ctx, out != nullptr, "gcnx_capture_end: out is NULL");
+  GCNX_REQUIRE(ctx, !ctx->on_side, "gcnx_capture_end inside a side section");
+  if (ctx->side_pending) { int rc = gcnx_side_join(ctx); if (rc) return rc; }   // a capture must end joined
   ctx->capturing = false;
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(ctx->stream, &g);

@@ -43,6 +43,9 @@ SIGNATURES = {
     "gcnx_d2h": [_vp, _vp, _vp, _sz],
     "gcnx_d2d": [_vp, _vp, _vp, _sz],
     "gcnx_sync": [_vp],
+    "gcnx_side_begin": [_vp],
+    "gcnx_side_end": [_vp],
+    "gcnx_side_join": [_vp],
     "gcnx_event_create": [_vp, C.POINTER(_vp)],
     "gcnx_event_record": [_vp, _vp],
     "gcnx_event_elapsed_ms": [_vp, _vp, _vp, C.POINTER(_f32)],

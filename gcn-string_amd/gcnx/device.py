@@ -8,6 +8,19 @@ import numpy as np
 from . import _lib as L
 
 
+class _Side:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.ctx._ck(self.ctx.lib.gcnx_side_begin(self.ctx.h))
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx._ck(self.ctx.lib.gcnx_side_end(self.ctx.h))
+        return False
+
+
 class Context:
     """One GPU + one HIP stream (gcnx_ctx).  Not thread-safe; one per process per GPU."""
 
@@ -48,6 +61,14 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.gcnx_sync(self.h))
+
+    def side(self):
+        """``with ctx.side(): ...`` -- the gcnx calls inside run on the side stream, after everything submitted
+        so far and concurrently with what follows; ``ctx.join()`` makes the main stream wait for them."""
+        return _Side(self)
+
+    def join(self):
+        self._ck(self.lib.gcnx_side_join(self.h))
 
     # -- events / graphs -------------------------------------------------------------------
     def event(self):

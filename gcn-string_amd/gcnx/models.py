@@ -12,6 +12,8 @@ is captured into a HIP graph (the role tf.function plays at gcn.py:328) and repl
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import device as D
@@ -182,13 +184,47 @@ class GCN2(_GraphRunner):
     def _backward(self, batch, bufs):
         ctx, p, g, prec = self.ctx, self.p, self.g, self.prec
         at = batch.a.transpose()
-        # pool gradient with the ReLU mask of layer 2 and its bias gradient fused
-        D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"], db=g["b2"])
+        # The gradient leaves (db2, dW2, db1: nothing later in the backward pass reads them) run in side sections,
+        # concurrently with the main chain pool' -> A^T -> dX -> A^T -> dW1.  Every buffer a side section reads
+        # stays unmodified until its join.
+        side = int(os.environ.get("GCNX_SIDE", "7"))   # tuning knob: bit 0 db2, bit 1 dW2, bit 2 db1 on the side stream
+        if side != 7:
+            return self._backward_knob(batch, bufs, side)
+        D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
+        with ctx.side():
+            D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])         # db2 = colsum(dZ2)
         D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH2 = A^T dZ2
-        D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)              # dW2 = Y1^T dH2
-        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz"], prec=prec, y_mask=bufs["y1"], db=g["b1"])  # dZ1, db1
+        ctx.join()                                                             # before dz is overwritten
+        with ctx.side():
+            D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
+        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz"], prec=prec, y_mask=bufs["y1"])   # dZ1 = (dH2 W2^T) * relu'(Y1)
+        ctx.join()                                                             # before h is overwritten
+        with ctx.side():
+            D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b1"])         # db1 = colsum(dZ1)
         D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH1 = A^T dZ1
         D.gemm_dw(ctx, batch.x, bufs["h"], g["w1"], prec=prec)                 # dW1 = X^T dH1
+        ctx.join()
+
+    def _backward_knob(self, batch, bufs, side):
+        """The same backward with individual side sections switched off (GCNX_SIDE bits; measurement only)."""
+        import contextlib
+        ctx, p, g, prec = self.ctx, self.p, self.g, self.prec
+        at = batch.a.transpose()
+        sec = lambda on: ctx.side() if on else contextlib.nullcontext()
+        D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])
+        with sec(side & 1):
+            D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])
+        D.spmm(ctx, at, bufs["dz"], None, bufs["h"])
+        ctx.join()
+        with sec(side & 2):
+            D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)
+        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz"], prec=prec, y_mask=bufs["y1"])
+        ctx.join()
+        with sec(side & 4):
+            D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b1"])
+        D.spmm(ctx, at, bufs["dz"], None, bufs["h"])
+        D.gemm_dw(ctx, batch.x, bufs["h"], g["w1"], prec=prec)
+        ctx.join()
 
     def _world(self):
         return self.comm.world_size if self.comm is not None else 1
@@ -209,18 +245,22 @@ class GCN2(_GraphRunner):
         self._run(("fwd", batch.uid), lambda: self._forward(batch, bufs, False, None))
         return bufs["probs"].numpy()
 
-    def loss_and_grads(self, inputs, target, global_batch=None):
-        """Forward + loss + every gradient (no update).  Returns (loss, acc)."""
+    def loss_and_grads(self, inputs, target, global_batch=None, _lr=None):
+        """Forward + loss + every gradient (no update).  Returns the device batch."""
         batch = self._as_batch(inputs, target)
         bufs = self._ensure(batch)
         denom = float(global_batch or batch.n_graphs)
+        multi = self.comm is not None and self.comm.world_size > 1
 
         def seq():
             self._forward(batch, bufs, "grads", denom)
             self._backward(batch, bufs)
+            if _lr is not None and not multi:
+                # single process: the update rides in the same captured graph (one graph launch per step)
+                D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
-        self._run(("grad", batch.uid, denom), seq)
-        if self.comm is not None and self.comm.world_size > 1:
+        self._run(("grad", batch.uid, denom, None if multi else _lr), seq)
+        if multi:
             self.comm.allreduce_sum(self.flat_g)
         self._last_batch = batch
         return batch
@@ -228,8 +268,9 @@ class GCN2(_GraphRunner):
     def train_step(self, inputs, target=None, lr=0.02, global_batch=None, fetch=True):
         """One optimisation step (gcn.py:330-340).  With a communicator the batch given here is
         this rank's shard and ``global_batch`` the number of graphs over all ranks."""
-        batch = self.loss_and_grads(inputs, target, global_batch)
-        self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
+        batch = self.loss_and_grads(inputs, target, global_batch, _lr=float(lr))
+        if self.comm is not None and self.comm.world_size > 1:
+            self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
         if not fetch:
             return None
         return self.fetch_metrics(global_batch or batch.n_graphs)

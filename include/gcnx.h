@@ -82,6 +82,15 @@ GCNX_API int gcnx_h2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
 GCNX_API int gcnx_d2h(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
 GCNX_API int gcnx_d2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
 GCNX_API int gcnx_sync(gcnx_ctx* ctx);
+/* Side sections: work launched between gcnx_side_begin and gcnx_side_end runs on a second HIP stream, after
+ * everything submitted so far and concurrently with what follows on the main stream; gcnx_side_join makes the
+ * main stream wait for the side sections ended so far (gcnx_sync and gcnx_capture_end join too).  Meant for the
+ * gradient leaves of tape.gradient (gcn.py:337) -- dW, db -- which nothing later in the backward pass reads;
+ * TensorFlow's executor runs such independent ops concurrently as well.  The caller keeps the buffers a side
+ * section reads unmodified until the join.  Inside a capture the graph gets two branches. */
+GCNX_API int gcnx_side_begin(gcnx_ctx* ctx);
+GCNX_API int gcnx_side_end(gcnx_ctx* ctx);
+GCNX_API int gcnx_side_join(gcnx_ctx* ctx);
 
 /* ---- timing: HIP events on the ctx stream ---------------------------------------------- */
 GCNX_API int gcnx_event_create(gcnx_ctx* ctx, gcnx_event** out);
