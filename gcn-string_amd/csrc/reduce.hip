@@ -170,43 +170,50 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
 }
 
 // Pool backward (+ optional fused ReLU mask of the layer that produced the pooled tensor).
-// One wave per row (64 float4 lanes cover 256 columns per pass); the row's graph is found by
-// binary search in graph_ptr.
+// One wave per run of kPoolBwdRows consecutive rows (64 float4 lanes cover 256 columns per pass).  The graph of
+// the run's first row is found by ONE binary search in graph_ptr (log2 B dependent loads -- per row they were
+// most of this kernel's time); the following rows only step the graph index forward.
+constexpr int kPoolBwdRows = 8;   // at most; small inputs take fewer rows per wave so that the grid still fills the chip
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const int32_t* __restrict__ gp, int32_t b,
                                                        const float* __restrict__ dp, float* __restrict__ dx,
                                                        int64_t lddx, int32_t n, int32_t f, int mode,
                                                        const int32_t* __restrict__ argmax, const float* __restrict__ y,
-                                                       int64_t ldy, int vec) {
+                                                       int64_t ldy, int vec, int rpw) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
-  int lo = 0, hi = b;  // find g with gp[g] <= r < gp[g+1]
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
+  if (r0 >= n) return;
+  const int r1 = min(n, r0 + rpw);
+  int lo = 0, hi = b;  // find g with gp[g] <= r0 < gp[g+1]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (gp[mid] <= r) lo = mid; else hi = mid;
+    if (gp[mid] <= r0) lo = mid; else hi = mid;
   }
-  const int g = lo;
-  const float scale = (mode == GCNX_POOL_AVG) ? 1.0f / (float)(gp[g + 1] - gp[g]) : 1.0f;
-  for (int c = lane * 4; c < f; c += 256) {
-    const int valid = f - c;
-    const bool v4 = vec && valid >= 4;
-    float4 v = ld4(dp + (int64_t)g * f + c, vec && f % 4 == 0 && valid >= 4, valid);
-    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-    if (mode == GCNX_POOL_MAX) {
-      const int32_t* ap = argmax + (int64_t)g * f + c;
-      if (ap[0] != r) v.x = 0.f;
-      if (valid > 1 && ap[1] != r) v.y = 0.f;
-      if (valid > 2 && ap[2] != r) v.z = 0.f;
-      if (valid > 3 && ap[3] != r) v.w = 0.f;
+  int g = lo;
+  int gend = gp[g + 1];
+  for (int r = r0; r < r1; ++r) {
+    while (r >= gend && g + 1 < b) { ++g; gend = gp[g + 1]; }   // empty graphs are skipped too
+    const float scale = (mode == GCNX_POOL_AVG) ? 1.0f / (float)(gend - gp[g]) : 1.0f;
+    for (int c = lane * 4; c < f; c += 256) {
+      const int valid = f - c;
+      const bool v4 = vec && valid >= 4;
+      float4 v = ld4(dp + (int64_t)g * f + c, vec && f % 4 == 0 && valid >= 4, valid);
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      if (mode == GCNX_POOL_MAX) {
+        const int32_t* ap = argmax + (int64_t)g * f + c;
+        if (ap[0] != r) v.x = 0.f;
+        if (valid > 1 && ap[1] != r) v.y = 0.f;
+        if (valid > 2 && ap[2] != r) v.z = 0.f;
+        if (valid > 3 && ap[3] != r) v.w = 0.f;
+      }
+      if (y) {
+        const float4 yy = ld4(y + (int64_t)r * ldy + c, v4, valid);
+        if (!(yy.x > 0.f)) v.x = 0.f;
+        if (!(yy.y > 0.f)) v.y = 0.f;
+        if (!(yy.z > 0.f)) v.z = 0.f;
+        if (!(yy.w > 0.f)) v.w = 0.f;
+      }
+      st4(dx + (int64_t)r * lddx + c, v, v4, valid);
     }
-    if (y) {
-      const float4 yy = ld4(y + (int64_t)r * ldy + c, v4, valid);
-      if (!(yy.x > 0.f)) v.x = 0.f;
-      if (!(yy.y > 0.f)) v.y = 0.f;
-      if (!(yy.z > 0.f)) v.z = 0.f;
-      if (!(yy.w > 0.f)) v.w = 0.f;
-    }
-    st4(dx + (int64_t)r * lddx + c, v, v4, valid);
   }
 }
 
@@ -395,8 +402,10 @@ int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* 
   GCNX_REQUIRE(ctx, mode != GCNX_POOL_MAX || argmax, "gcnx_segment_pool_bwd: MAX needs the argmax buffer");
   auto al = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
   const int vec = al(dx) && lddx % 4 == 0 && al(dpooled) && (!y || (al(y) && ldy % 4 == 0));
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, graph_ptr, b, dpooled, dx,
-                     lddx, n, f, mode, argmax, y, ldy, vec);
+  int rpw = (int)(n / (64LL * ctx->num_cus));   // rows per wave: ~16 waves per SIMD before runs get longer
+  rpw = rpw < 1 ? 1 : (rpw > kPoolBwdRows ? kPoolBwdRows : rpw);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(gcnx_cdiv(n, 4 * rpw)), dim3(256), 0, ctx->stream, graph_ptr, b, dpooled, dx,
+                     lddx, n, f, mode, argmax, y, ldy, vec, rpw);
   GCNX_LAUNCH_OK(ctx);
   if (db) return gcnx_colsum(ctx, dx, lddx, n, f, db);
   return GCNX_OK;
