@@ -62,14 +62,16 @@ def test_spmm_long_rows_overflowing_the_lds_stage(ctx):
 
 
 @pytest.mark.parametrize("weighted", [False, True])
-def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
-    """The persistent LDS-tile kernel on a batch that holds every scheduling class: graphs of
-    <= 632 rows (32-column tile), <= 1264 rows (two 16-column passes), larger ones (row chunks
-    for the rows kernel), a single-node graph, rows with > 16 entries (on-demand index fetch)."""
+@pytest.mark.parametrize("variant", ["", "q"])
+def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, variant, monkeypatch):
+    """The LDS-tile kernels on a batch that holds every scheduling class: graphs at and around the tier limits of
+    the default kernel (604 rows: two 512-thread workgroups per CU; 1236: one 1024-thread workgroup) and of the
+    queue kernel (GCNX_SPMM_TILE=q: 632 / 1264), taller ones (row chunks for the rows kernel), a single-node graph,
+    rows with > 16 entries (on-demand index fetch)."""
     from gcnx import device as D, synth
     import scipy.sparse as sp
     rng = np.random.default_rng(11)
-    sizes = [1, 40, 632, 633, 1264, 1265, 300, 2000, 7]
+    sizes = [1, 40, 604, 605, 632, 633, 1236, 1237, 1264, 1265, 300, 2000, 7]
     blocks = []
     for i, m in enumerate(sizes):
         dens = 0.5 if m == 40 else min(1.0, 9.0 / m)          # the 40-node graph has ~20-entry rows
@@ -81,6 +83,8 @@ def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
     gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     hb = synth.HostBatch(rng.standard_normal((n, 64), dtype=np.float32), a.indptr.astype(np.int32), a.indices.astype(np.int32),
                          None, gp, np.zeros((len(sizes), 2), np.float32))
+    if variant:
+        monkeypatch.setenv("GCNX_SPMM_TILE", variant)          # read when the plan is built, i.e. at the first spmm
     csr, vals = _csr(ctx, hb, weighted)
     bias = rng.standard_normal(64).astype(np.float32)
     ref = _ref_spmm(hb, vals, hb.x, bias, True)
@@ -90,6 +94,50 @@ def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
         out.fill_zero()
         D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out, act="relu")
         assert rel_err(out.numpy(), ref) < TIGHT, kernel
+    # the tile path is deterministic: a second launch reproduces the first bit for bit
+    monkeypatch.setenv("GCNX_SPMM_KERNEL", "tile")
+    out2 = ctx.zeros((n, 64))
+    D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out, act="relu")
+    D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out2, act="relu")
+    assert np.array_equal(out.numpy(), out2.numpy())
+
+
+def test_side_sections_order_and_capture(ctx):
+    """gcnx_side_begin / _end / _join: a side section sees everything submitted before it, the main stream sees the
+    side results after the join, d2h joins implicitly, and a captured sequence with a side section replays
+    correctly (the graph gets two branches)."""
+    from gcnx import device as D
+    rng = np.random.default_rng(3)
+    n, f = 20000, 64
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = (rng.standard_normal((f, f)) / 8).astype(np.float32)
+    dx, dw_, dh = ctx.to_device(x), ctx.to_device(w), ctx.empty((n, f))
+    s1, s2, out = ctx.empty(f), ctx.empty(f), ctx.empty((n, f))
+
+    def seq():
+        D.gemm(ctx, dx, dw_, None, dh)                     # main: dh = x w
+        with ctx.side():
+            D.act_bias_grad(ctx, dh, None, dh, None, db=s1)  # side: column sums of dh (must see the finished GEMM)
+        D.gemm(ctx, dh, dw_, None, out)                    # main, concurrently: out = dh w
+        ctx.join()
+        D.act_bias_grad(ctx, out, None, out, None, db=s2)  # main after the join
+
+    ref_h = x.astype(np.float64) @ w.astype(np.float64)
+    seq()
+    assert rel_err(s1.numpy(), ref_h.sum(0)) < TIGHT          # numpy() = d2h, which joins the side stream
+    assert rel_err(s2.numpy(), (ref_h @ w.astype(np.float64)).sum(0)) < TIGHT
+    first = (s1.numpy().copy(), s2.numpy().copy())
+    g = ctx.capture(seq)
+    for _ in range(3):
+        s1.fill_zero(); s2.fill_zero()
+        g.launch()
+        assert np.array_equal(s1.numpy(), first[0]) and np.array_equal(s2.numpy(), first[1])
+    g.destroy()
+    # misuse is reported, not silently accepted
+    from gcnx import _lib
+    assert ctx.lib.gcnx_side_end(ctx.h) == 1 and "not inside" in _lib.last_error(ctx.h)
+    with ctx.side():
+        assert ctx.lib.gcnx_side_begin(ctx.h) == 1
 
 
 def test_spmm_empty_rows_single_nodes_and_strided_views(ctx):
