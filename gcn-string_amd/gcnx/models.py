@@ -159,6 +159,7 @@ class GCN2(_GraphRunner):
         self._bufs = {
             "key": key,
             "h": ctx.empty((n, h)), "y1": ctx.empty((n, h)), "y2": ctx.empty((n, h)), "dz": ctx.empty((n, h)),
+            "h2": ctx.empty((n, h)), "dz2": ctx.empty((n, h)),      # second pair: the side section still reads h / dz
             "pooled": ctx.empty((b, h)), "probs": ctx.empty((b, c)), "dpooled": ctx.empty((b, h)),
             "arg": ctx.empty((b, h), np.int32) if self.pool == "max" else None,
         }
@@ -184,25 +185,21 @@ class GCN2(_GraphRunner):
     def _backward(self, batch, bufs):
         ctx, p, g, prec = self.ctx, self.p, self.g, self.prec
         at = batch.a.transpose()
-        # The gradient leaves (db2, dW2, db1: nothing later in the backward pass reads them) run in side sections,
-        # concurrently with the main chain pool' -> A^T -> dX -> A^T -> dW1.  Every buffer a side section reads
-        # stays unmodified until its join.
-        side = int(os.environ.get("GCNX_SIDE", "7"))   # tuning knob: bit 0 db2, bit 1 dW2, bit 2 db1 on the side stream
-        if side != 7:
-            return self._backward_knob(batch, bufs, side)
+        # The gradient leaves of layer 2 (db2, dW2: nothing later in the backward pass reads them) run in ONE side
+        # section, concurrently with the main chain dX -> db1 -> A^T -> dW1.  One fork and one join per step: each
+        # costs ~10 us of cross-queue signalling, which is why there are not three sections.  The buffers the side
+        # section reads (dz, h) stay unmodified until the join: the main chain continues in dz2 / h2.
+        side = int(os.environ.get("GCNX_SIDE", "1"))   # tuning knob: 0 = serial, 1 = one section, 7 = three sections
+        if side != 1:
+            return self._backward_knob(batch, bufs, 0 if side == 0 else 7)
         D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
+        D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH2 = A^T dZ2
         with ctx.side():
             D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])         # db2 = colsum(dZ2)
-        D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH2 = A^T dZ2
-        ctx.join()                                                             # before dz is overwritten
-        with ctx.side():
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
-        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz"], prec=prec, y_mask=bufs["y1"])   # dZ1 = (dH2 W2^T) * relu'(Y1)
-        ctx.join()                                                             # before h is overwritten
-        with ctx.side():
-            D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b1"])         # db1 = colsum(dZ1)
-        D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH1 = A^T dZ1
-        D.gemm_dw(ctx, batch.x, bufs["h"], g["w1"], prec=prec)                 # dW1 = X^T dH1
+        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
+        D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1
+        D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)                # dW1 = X^T dH1
         ctx.join()
 
     def _backward_knob(self, batch, bufs, side):
