@@ -70,6 +70,7 @@ SIGNATURES = {
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
     "gcnx_bn_stats": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "gcnx_bn_finalize": [_vp, _vp, _f32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
+    "gcnx_bn_moments": [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "gcnx_bn_act": [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _int, _vp, _vp, _i64],
     "gcnx_bn_act_bwd": [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _i64, _vp, _vp, _vp,
                         _vp],

@@ -427,13 +427,13 @@ def bn_finalize(ctx, sums, count, mean, inv, moving_mean=None, moving_var=None, 
                                      _p(moving_mean), _p(moving_var)))
 
 
-def bn_moments(ctx, z, sums, mean, inv, moving_mean=None, moving_var=None):
+def bn_moments(ctx, z, sums, mean, inv, moving_mean=None, moving_var=None, momentum=BN_MOMENTUM, eps=BN_EPS):
     """Batch mean / biased variance the way tf.nn.moments takes them (variance of the centred data): a first
-    pass for the mean, a second one centred on it."""
-    bn_stats(ctx, z, sums)
-    bn_finalize(ctx, sums, z.shape[0], mean, inv)
-    bn_stats(ctx, z, sums, shift=mean)
-    bn_finalize(ctx, sums, z.shape[0], mean, inv, moving_mean, moving_var, shift=mean)
+    pass for the mean, a second one centred on it (gcnx_bn_moments; `sums` is kept for signature compatibility
+    with the bn_stats / bn_finalize pair used for sync-BN)."""
+    n, f = z.shape
+    ctx._ck(ctx.lib.gcnx_bn_moments(ctx.h, _p(z), z.ld, n, f, momentum, eps, _p(mean), _p(inv), _p(moving_mean),
+                                    _p(moving_var)))
 
 
 def bn_act(ctx, z, mean, inv, gamma, beta, y, act=None, alpha=None):

@@ -208,6 +208,11 @@ GCNX_API int gcnx_bn_stats(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n
 GCNX_API int gcnx_bn_finalize(gcnx_ctx* ctx, const float* sums, float count, int32_t f, float momentum,
                               float eps, const float* shift, float* mean, float* inv, float* moving_mean,
                               float* moving_var);
+/* Single-device shortcut for the training-mode moments: gcnx_bn_stats + gcnx_bn_finalize for the mean, then again
+ * centred on it for the variance (the two-pass tf.nn.moments form), with each reduce + finalise pair fused: four
+ * launches instead of six, bit-identical results.  moving_* (both or none) get the momentum update. */
+GCNX_API int gcnx_bn_moments(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f, float momentum, float eps,
+                    float* mean, float* inv, float* moving_mean, float* moving_var);
 /* y = act(gamma * (z - mean) * inv + beta); act NONE / RELU / PRELU(alpha[f]). */
 GCNX_API int gcnx_bn_act(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f, const float* mean,
                          const float* inv, const float* gamma, const float* beta, int act, const float* alpha,

@@ -140,6 +140,31 @@ def test_side_sections_order_and_capture(ctx):
         assert ctx.lib.gcnx_side_begin(ctx.h) == 1
 
 
+def test_bn_moments_equals_stats_finalize_pairs(ctx):
+    """gcnx_bn_moments (4 launches) is bit-identical to bn_stats + bn_finalize taken twice (6 launches), and matches
+    numpy's two-pass moments; the moving statistics get the Keras momentum update."""
+    from gcnx import device as D
+    rng = np.random.default_rng(21)
+    n, f = 20001, 200
+    z = (rng.standard_normal((n, f)) * 3 + 50).astype(np.float32)     # large mean: the centred pass matters
+    dz = ctx.to_device(z)
+    mean, inv, sums = ctx.empty(f), ctx.empty(f), ctx.empty(2 * f)
+    mm, mv = ctx.to_device(np.full(f, 0.5, np.float32)), ctx.to_device(np.full(f, 2.0, np.float32))
+    D.bn_moments(ctx, dz, sums, mean, inv, mm, mv)
+    m2, i2 = ctx.empty(f), ctx.empty(f)
+    mm2, mv2 = ctx.to_device(np.full(f, 0.5, np.float32)), ctx.to_device(np.full(f, 2.0, np.float32))
+    D.bn_stats(ctx, dz, sums)
+    D.bn_finalize(ctx, sums, n, m2, i2)
+    D.bn_stats(ctx, dz, sums, shift=m2)
+    D.bn_finalize(ctx, sums, n, m2, i2, mm2, mv2, shift=m2)
+    for a, b in ((mean, m2), (inv, i2), (mm, mm2), (mv, mv2)):
+        assert np.array_equal(a.numpy(), b.numpy())
+    z64 = z.astype(np.float64)
+    assert rel_err(mean.numpy(), z64.mean(0)) < TIGHT
+    assert rel_err(inv.numpy(), 1.0 / np.sqrt(z64.var(0) + 1e-3)) < TIGHT
+    assert rel_err(mm.numpy(), 0.99 * 0.5 + 0.01 * z64.mean(0)) < TIGHT
+
+
 def test_spmm_empty_rows_single_nodes_and_strided_views(ctx):
     from gcnx import device as D, synth
     from gcnx.device import DeviceCSR
