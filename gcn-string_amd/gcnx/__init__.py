@@ -6,10 +6,12 @@ hand-written HIP kernels in libgcnx.so (C ABI: include/gcnx.h), bound with ctype
 No PyTorch, no TensorFlow, no CPU fallback.
 """
 from . import _lib
+from .io import best_epoch, load_weights_npz, save_to_npz
 from .loader import Dataset, DisjointLoader, Graph, ListDataset, SparseTensor
 
 __all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "SparseTensor", "Context", "GCNConv",
-           "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch"]
+           "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch",
+           "save_to_npz", "load_weights_npz", "best_epoch"]
 
 
 def __getattr__(name):  # device-side names load libgcnx lazily, host-only use needs no .so

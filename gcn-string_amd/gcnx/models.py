@@ -514,7 +514,7 @@ class GeneralGNN(_GraphRunner):
         D.softmax_cce(self.ctx, logits, bufs["zy"], bufs["probs"], la, None, None)
         return bufs["probs"].numpy()
 
-    def loss_and_grads(self, inputs, target=None):
+    def loss_and_grads(self, inputs, target=None, _lr=None):
         batch = self._as_batch(inputs, target)
         bufs = self._ensure(batch)
         def seq():
@@ -522,14 +522,15 @@ class GeneralGNN(_GraphRunner):
             self.loss_acc.fill_zero()
             D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], batch.n_graphs)
             self._backward(batch, bufs, True)
+            if _lr is not None:                            # the update rides in the same captured graph
+                D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
-        self._run(("grad", batch.uid), seq)
+        self._run(("grad", batch.uid, _lr), seq)
         return batch
 
     def train_step(self, inputs, target=None, lr=0.02, fetch=True):
         """gcn.py:330-340 for the live model: forward(training=True), CCE, gradients, SGD, accuracy."""
-        batch = self.loss_and_grads(inputs, target)
-        self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
+        batch = self.loss_and_grads(inputs, target, _lr=float(lr))
         if not fetch:
             return None
         la = self.loss_acc.numpy()

@@ -145,3 +145,19 @@ def test_sharded_oracle_step_equals_full_batch():
     assert abs(lsum - full[0]) < 1e-12
     for k in tot:
         assert rel_err(tot[k], full[2][k]) < 1e-12
+
+
+def test_save_to_npz_round_trip_without_pickle(tmp_path):
+    """gcn.py:59-64 mirror: same call, same keys; the per-epoch weight lists come back through plain arrays only."""
+    import gcnx
+    rng = np.random.default_rng(0)
+    epochs = [[rng.standard_normal((4, 3)).astype(np.float32), rng.standard_normal(3).astype(np.float32)] for _ in range(3)]
+    probas, labels = rng.random((10, 2)), np.eye(2)[rng.integers(0, 2, 10)]
+    path = gcnx.save_to_npz(str(tmp_path), "run1", probas, labels, epochs, [0.5, 0.9, 0.7])
+    with np.load(path, allow_pickle=False) as z:
+        assert {"probas", "labels", "performance"} <= set(z.files)
+        assert np.array_equal(z["probas"], probas) and np.array_equal(z["labels"], labels)
+    assert gcnx.best_epoch(path) == 1
+    for e in (0, 1, -1):
+        got = gcnx.load_weights_npz(path, epoch=e)
+        assert len(got) == 2 and all(np.array_equal(a, b) for a, b in zip(got, epochs[e]))
