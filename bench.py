@@ -214,7 +214,7 @@ def main():
         big = {"workload": "config3: N=1,000,000 nnz=10,000,000 F=256 fp32, weighted, bias+relu", "bound": "hbm",
                "achieved": alg3 / (ms3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("block1m"), "algorithmic_bytes": alg3, "avg_launch_us": 1e3 * ms3,
-               "launches": 20, "kernels": "spmm_tile_kernel x2 + spmm_rows_kernel (one gcnx_spmm_csr call)"}
+               "launches": 20, "kernels": "spmm_duo_kernel (512- and 1024-thread shapes) + spmm_rows_kernel: one gcnx_spmm_csr call"}
         for t in (a3, h3, o3):
             pass
 
