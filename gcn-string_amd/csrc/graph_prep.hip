@@ -68,6 +68,48 @@ __global__ __launch_bounds__(256) void gcn_scale_kernel(const int32_t* __restric
   }
 }
 
+
+// ---- device-side collate -------------------------------------------------------------
+// The dataset lives in HBM as ONE disjoint union of all its graphs (features, CSR, labels, node_ptr).  A
+// batch = the graphs sel[0..b) in that order: their feature rows, CSR rows (row pointers and column indices
+// re-based to the batch) and labels are gathered by one launch -- what DisjointLoader's collate does on the
+// host with vstack / block_diag / find (gcn.py:316-317, 367).  Per batch only 3(b+1) ints cross PCIe.
+__global__ __launch_bounds__(256) void collate_kernel(const int32_t* __restrict__ desc /* sel | bnode | bent, each b+1 */,
+                                                      int32_t b, const int32_t* __restrict__ node_ptr,
+                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                      const float* __restrict__ vals, const float* __restrict__ x,
+                                                      int64_t ldx, int32_t f, const float* __restrict__ y, int32_t c,
+                                                      int32_t* __restrict__ o_rowptr, int32_t* __restrict__ o_colidx,
+                                                      float* __restrict__ o_vals, float* __restrict__ o_x, int64_t ldo,
+                                                      float* __restrict__ o_y, int32_t* __restrict__ o_gp) {
+  const int g = blockIdx.y;                       // position in the batch
+  const int src = desc[g];
+  const int bn = desc[(b + 1) + g], be = desc[2 * (b + 1) + g];
+  const int n0 = node_ptr[src], ng = node_ptr[src + 1] - n0;
+  const int e0 = rowptr[n0], ne = rowptr[n0 + ng] - e0;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  // CSR rows: row pointers re-based to the batch's entry offset
+  for (int i = tid; i < ng; i += nth) o_rowptr[bn + i] = rowptr[n0 + i] - e0 + be;
+  // entries: column indices re-based to the batch's node offset
+  for (int e = tid; e < ne; e += nth) {
+    o_colidx[be + e] = colidx[e0 + e] - n0 + bn;
+    if (o_vals) o_vals[be + e] = vals[e0 + e];
+  }
+  // feature rows (f % 4 == 0 and 16-byte aligned rows are the caller's guarantee when vec4 != 0 ... handled scalar otherwise)
+  const int64_t total = (int64_t)ng * f;
+  for (int64_t k = tid; k < total; k += nth) {
+    const int64_t i = k / f, j = k - i * f;
+    o_x[(int64_t)(bn + i) * ldo + j] = x[(int64_t)(n0 + i) * ldx + j];
+  }
+  if (blockIdx.x == 0) {
+    if (y) for (int k = threadIdx.x; k < c; k += blockDim.x) o_y[(int64_t)g * c + k] = y[(int64_t)src * c + k];
+    if (threadIdx.x == 0) {
+      o_gp[g] = bn;
+      if (g == b - 1) { o_gp[b] = desc[(b + 1) + b]; o_rowptr[desc[(b + 1) + b]] = desc[2 * (b + 1) + b]; }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -160,6 +202,24 @@ int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* coli
   } catch (const std::bad_alloc&) {
     return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_csr_transpose: out of host memory");
   }
+  return GCNX_OK;
+}
+
+
+int gcnx_collate(gcnx_ctx* ctx, const int32_t* desc, int32_t b, const int32_t* node_ptr, const int32_t* rowptr,
+                 const int32_t* colidx, const float* vals, const float* x, int64_t ldx, int32_t f, const float* y, int32_t c,
+                 int32_t* o_rowptr, int32_t* o_colidx, float* o_vals, float* o_x, int64_t ldo, float* o_y,
+                 int32_t* o_graph_ptr) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, b >= 0 && f >= 0 && c >= 0, "gcnx_collate: negative size");
+  if (b == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, desc && node_ptr && rowptr && colidx && o_rowptr && o_colidx && o_graph_ptr, "gcnx_collate: NULL pointer");
+  GCNX_REQUIRE(ctx, f == 0 || (x && o_x && ldx >= f && ldo >= f), "gcnx_collate: bad feature buffers");
+  GCNX_REQUIRE(ctx, (vals == nullptr) == (o_vals == nullptr), "gcnx_collate: values in and out go together");
+  GCNX_REQUIRE(ctx, !y || o_y, "gcnx_collate: labels need an output");
+  hipLaunchKernelGGL(collate_kernel, dim3(16, b), dim3(256), 0, ctx->stream, desc, b, node_ptr, rowptr, colidx, vals, x, ldx,
+                     f, y, c, o_rowptr, o_colidx, o_vals, o_x, ldo, o_y, o_graph_ptr);
+  GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
 

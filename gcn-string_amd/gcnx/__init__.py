@@ -11,7 +11,7 @@ from .loader import Dataset, DisjointLoader, Graph, ListDataset, SparseTensor
 
 __all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "SparseTensor", "Context", "GCNConv",
            "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch",
-           "save_to_npz", "load_weights_npz", "best_epoch"]
+           "save_to_npz", "load_weights_npz", "best_epoch", "DeviceDataset", "DeviceDisjointLoader"]
 
 
 def __getattr__(name):  # device-side names load libgcnx lazily, host-only use needs no .so
@@ -21,6 +21,9 @@ def __getattr__(name):  # device-side names load libgcnx lazily, host-only use n
     if name in ("GCNConv", "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense"):
         from . import layers
         return getattr(layers, name)
+    if name in ("DeviceDataset", "DeviceDisjointLoader", "collate_on_device"):
+        from . import device_loader
+        return getattr(device_loader, name)
     if name in ("GCN2", "GeneralGNN", "DeviceBatch", "evaluate"):
         from . import models
         return getattr(models, name)

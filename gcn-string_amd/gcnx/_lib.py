@@ -55,6 +55,7 @@ SIGNATURES = {
     "gcnx_graph_launch": [_vp, _vp],
     "gcnx_graph_destroy": [_vp, _vp],
     "gcnx_coo_to_csr": [_vp, _vp, _vp, _i64, _i64, _vp, _vp],
+    "gcnx_collate": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "gcnx_gcn_norm": [_vp, _vp, _vp, _vp, _i32, _int, _vp],
     "gcnx_csr_transpose": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gcnx_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp],

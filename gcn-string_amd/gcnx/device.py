@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -229,6 +230,10 @@ class DeviceCSR:
         CSR that shares block_ptr: normalised / unweighted / transposed views)."""
         if self.block_ptr is None or self.n_blocks == 0:
             return None
+        # The tile kernels need >= 4 (graph, 32-column slab) units per CU (gcnx_spmm_csr); below ~128 graphs no
+        # width reaches that, and building a plan (a D2H copy, a host sort, an upload) per streamed batch is wasted.
+        if self.n_blocks < 128 and os.environ.get("GCNX_SPMM_KERNEL", "") != "tile":
+            return None
         holder = self.block_ptr
         p = getattr(holder, "_spmm_plan", None)
         if p is None:
@@ -313,6 +318,14 @@ class Segments:
         self.ctx, self.n_graphs, self.n = ctx, len(gp) - 1, int(gp[-1])
         self.host = gp
         self.dev = ctx.to_device(gp, np.int32)
+
+    @classmethod
+    def from_device(cls, ctx, dev, graph_ptr_host):
+        """graph_ptr already on the device (device-side collate); the host copy is kept for shapes."""
+        self = cls.__new__(cls)
+        gp = np.asarray(graph_ptr_host, dtype=np.int32)
+        self.ctx, self.n_graphs, self.n, self.host, self.dev = ctx, len(gp) - 1, int(gp[-1]), gp, dev
+        return self
 
     @classmethod
     def from_ids(cls, ctx, i, n_graphs=None):

@@ -149,6 +149,9 @@ class GCN2(_GraphRunner):
 
     # ---- buffers for one batch shape ---------------------------------------------------------
     def _ensure(self, batch):
+        """Activation buffers for this batch shape.  Storage is grow-only capacity (a streamed epoch brings a new
+        (N, B) with every batch: re-allocating ~60 MB per step cost more than the step); the returned arrays are
+        views of exactly the batch's shape."""
         if not self.built:
             self.build(batch.f)
         key = (batch.n, batch.n_graphs)
@@ -156,13 +159,24 @@ class GCN2(_GraphRunner):
             return self._bufs
         ctx, n, b, h, c = self.ctx, batch.n, batch.n_graphs, self.hidden, self.n_labels
         self._drop_graphs()
-        self._bufs = {
-            "key": key,
-            "h": ctx.empty((n, h)), "y1": ctx.empty((n, h)), "y2": ctx.empty((n, h)), "dz": ctx.empty((n, h)),
-            "h2": ctx.empty((n, h)), "dz2": ctx.empty((n, h)),      # second pair: the side section still reads h / dz
-            "pooled": ctx.empty((b, h)), "probs": ctx.empty((b, c)), "dpooled": ctx.empty((b, h)),
-            "arg": ctx.empty((b, h), np.int32) if self.pool == "max" else None,
-        }
+        cap = getattr(self, "_cap", None)
+        if cap is None or n > cap["n"] or b > cap["b"]:
+            cn = max(n, int(1.25 * cap["n"]) if cap else 0)
+            cb = max(b, cap["b"] if cap else 0)
+            cap = {"n": cn, "b": cb}
+            for k in ("h", "y1", "y2", "dz", "h2", "dz2"):
+                cap[k] = ctx.empty((cn, h))
+            for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
+                cap[k] = ctx.empty((cb, w))
+            cap["arg"] = ctx.empty((cb, h), np.int32) if self.pool == "max" else None
+            self._cap = cap
+        view = lambda k, rows, w: cap[k].flat(0, rows * w, (rows, w))
+        self._bufs = {"key": key}
+        for k in ("h", "y1", "y2", "dz", "h2", "dz2"):
+            self._bufs[k] = view(k, n, h)
+        for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
+            self._bufs[k] = view(k, b, w)
+        self._bufs["arg"] = view("arg", b, h) if cap["arg"] is not None else None
         return self._bufs
 
     # ---- the call sequences --------------------------------------------------------------------

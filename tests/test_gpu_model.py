@@ -84,6 +84,38 @@ def test_disjoint_loader_to_model_end_to_end(ctx):
         assert rel_err(gk, rg[k]) < TOL, k
 
 
+def test_device_side_collate_equals_host_loader(ctx):
+    """DeviceDataset + DeviceDisjointLoader assemble the same batches as DisjointLoader +
+    DeviceBatch.from_host (same seed, same order): features, CSR (row pointers / column indices exact), filter
+    values, labels, graph pointers -- including a ragged last batch -- and the model takes the same step on them."""
+    from gcnx import DisjointLoader, Graph, ListDataset, synth, DeviceDataset, DeviceDisjointLoader
+    from gcnx.models import DeviceBatch, GCN2
+    raw = synth.tiny_graphs(11, 16, seed=4)
+    ds = ListDataset([Graph(x=x, a=a, y=y) for x, a, y in raw])
+    host = DisjointLoader(ds, batch_size=4, epochs=2, shuffle=True, seed=9)
+    dds = DeviceDataset(ctx, ds, normalize="spektral")
+    dev = DeviceDisjointLoader(dds, batch_size=4, epochs=2, shuffle=True, seed=9)
+    assert dev.steps_per_epoch == host.steps_per_epoch == 3
+    m1, m2 = GCN2(ctx, 2, hidden=16, use_graph=False, seed=1), GCN2(ctx, 2, hidden=16, use_graph=False, seed=1)
+    n_batches = 0
+    for (inputs, target), (dbatch, _) in zip(host, dev):
+        hbatch = DeviceBatch.from_host(ctx, inputs, target, normalize="spektral")
+        assert dbatch.n == hbatch.n and dbatch.n_graphs == hbatch.n_graphs
+        assert np.array_equal(dbatch.x.numpy(), hbatch.x.numpy())
+        assert np.array_equal(dbatch.a.rowptr.numpy(), hbatch.a.rowptr.numpy())
+        assert np.array_equal(dbatch.a.colidx.numpy()[:dbatch.a.nnz], hbatch.a.colidx.numpy()[:hbatch.a.nnz])
+        assert np.array_equal(dbatch.a.vals.numpy()[:dbatch.a.nnz], hbatch.a.vals.numpy()[:hbatch.a.nnz])
+        assert np.array_equal(dbatch.y.numpy(), hbatch.y.numpy())
+        assert np.array_equal(dbatch.seg.dev.numpy(), hbatch.seg.dev.numpy())
+        l1 = m1.train_step(hbatch, None, lr=0.05)
+        l2 = m2.train_step(dbatch, None, lr=0.05)
+        assert l1 == l2
+        n_batches += 1
+    assert n_batches == 6
+    for a, b in zip(m1.get_weights(), m2.get_weights()):
+        assert np.array_equal(a, b)
+
+
 def test_layer_surface_gcnconv_pool_dense(ctx):
     """The Spektral call surface: GCNConv([x, a]), GlobalSumPool([x, i]), Dense(x) + backward."""
     from oracle import gcn_oracle as O
