@@ -8,10 +8,12 @@ No PyTorch, no TensorFlow, no CPU fallback.
 from . import _lib
 from .io import best_epoch, load_weights_npz, save_to_npz
 from .loader import Dataset, DisjointLoader, Graph, ListDataset, SparseTensor
+from .train import PiecewiseConstantDecay, auc, fit, roc_curve
 
 __all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "SparseTensor", "Context", "GCNConv",
            "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch",
-           "save_to_npz", "load_weights_npz", "best_epoch", "DeviceDataset", "DeviceDisjointLoader"]
+           "save_to_npz", "load_weights_npz", "best_epoch", "DeviceDataset", "DeviceDisjointLoader",
+           "PiecewiseConstantDecay", "fit", "roc_curve", "auc"]
 
 
 def __getattr__(name):  # device-side names load libgcnx lazily, host-only use needs no .so

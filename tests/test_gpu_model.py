@@ -116,6 +116,36 @@ def test_device_side_collate_equals_host_loader(ctx):
         assert np.array_equal(a, b)
 
 
+def test_fit_loop_host_and_device_loaders_agree(ctx, capsys):
+    """n4: gcnx.fit (the loop of gcn.py:364-385 with the per-step PiecewiseConstantDecay and the size-weighted
+    per-epoch evaluation) gives the same history through the host loader and through the device-side loader."""
+    import gcnx
+    from gcnx import DisjointLoader, Graph, ListDataset, synth, DeviceDataset, DeviceDisjointLoader
+    from gcnx.models import GCN2
+    raw = synth.tiny_graphs(14, 16, seed=7)
+    tr = ListDataset([Graph(x=x, a=a, y=y) for x, a, y in raw[:10]])
+    te = ListDataset([Graph(x=x, a=a, y=y) for x, a, y in raw[10:]])
+    epochs = 3
+    runs = []
+    for mode in ("host", "device"):
+        m = GCN2(ctx, 2, hidden=16, use_graph=False, seed=2)
+        if mode == "host":
+            ltr = DisjointLoader(tr, batch_size=4, epochs=epochs, shuffle=True, seed=5)
+            lte = DisjointLoader(te, batch_size=3, shuffle=False)
+            out = gcnx.fit(m, ltr, lte, epochs=epochs, normalize="spektral")
+        else:
+            ltr = DeviceDisjointLoader(DeviceDataset(ctx, tr, normalize="spektral"), batch_size=4, epochs=epochs, shuffle=True, seed=5)
+            lte = DeviceDisjointLoader(DeviceDataset(ctx, te, normalize="spektral"), batch_size=3, shuffle=False)
+            out = gcnx.fit(m, ltr, lte, epochs=epochs)
+        runs.append(out)
+    assert "Ep. 3 - Loss:" in capsys.readouterr().out
+    h0, h1 = np.array(runs[0]["history"]), np.array(runs[1]["history"])
+    assert h0.shape == (epochs, 4) and np.array_equal(h0, h1)
+    assert len(runs[0]["weights"]) == epochs and len(runs[0]["performance"]) == epochs
+    for a, b in zip(runs[0]["weights"][-1], runs[1]["weights"][-1]):
+        assert np.array_equal(a, b)
+
+
 def test_layer_surface_gcnconv_pool_dense(ctx):
     """The Spektral call surface: GCNConv([x, a]), GlobalSumPool([x, i]), Dense(x) + backward."""
     from oracle import gcn_oracle as O

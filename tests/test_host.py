@@ -161,3 +161,24 @@ def test_save_to_npz_round_trip_without_pickle(tmp_path):
     for e in (0, 1, -1):
         got = gcnx.load_weights_npz(path, epoch=e)
         assert len(got) == 2 and all(np.array_equal(a, b) for a, b in zip(got, epochs[e]))
+
+
+def test_piecewise_schedule_and_roc_auc_match_keras_and_sklearn():
+    """n4 harness pieces: the per-step PiecewiseConstantDecay of gcn.py:321-324 (same values as the oracle's
+    restatement) and roc_curve / auc against scikit-learn."""
+    import gcnx
+    from oracle import gcn_oracle as O
+    sched = gcnx.PiecewiseConstantDecay.reference(20)
+    assert [sched(s) for s in (0, 1, 6, 7, 100)] == [0.02, 0.002, 0.002, 0.0002, 0.0002]
+    assert all(sched(s) == O.piecewise_lr(s, 20) for s in range(40))
+    with pytest.raises(ValueError):
+        gcnx.PiecewiseConstantDecay([0, 1], [0.1, 0.2])
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 2, 200)
+    p = np.round(np.clip(0.3 * y + rng.random(200) * 0.8, 0, 1), 2)        # ties included
+    fpr, tpr, thr = gcnx.roc_curve(y, p)
+    from sklearn import metrics
+    f2, t2, th2 = metrics.roc_curve(y, p, drop_intermediate=False)
+    assert np.allclose(fpr, f2) and np.allclose(tpr, t2) and np.allclose(thr[1:], th2[1:])
+    assert abs(gcnx.auc(fpr, tpr) - metrics.auc(f2, t2)) < 1e-12
+    assert abs(gcnx.auc(fpr, tpr) - metrics.roc_auc_score(y, p)) < 1e-12
