@@ -57,6 +57,23 @@ class DeviceBatch:
         return cls(ctx, dx, csr, seg, dy)
 
 
+class _Capacity:
+    """Grow-only device storage behind per-batch views.  A streamed epoch brings a new (N, B) with every batch;
+    re-allocating the activations per step (tens of MB) cost more than the step itself."""
+
+    def __init__(self, ctx):
+        self.ctx, self.store = ctx, {}
+
+    def view(self, name, rows, width, dtype=np.float32, zero=False):
+        need = int(rows) * int(width)
+        cur = self.store.get(name)
+        if cur is None or cur.size < need or cur.dtype != np.dtype(dtype):
+            size = max(need, int(1.25 * cur.size) if cur is not None else 0, 1)
+            cur = (self.ctx.zeros if zero else self.ctx.empty)(size, dtype)
+            self.store[name] = cur
+        return cur.flat(0, need, (int(rows), int(width)))
+
+
 class _GraphRunner:
     """Runs a fixed call sequence eagerly once (sizes the workspace), captures it into a HIP graph on the second
     use and replays it afterwards -- the role tf.function plays at gcn.py:328.  Graphs hold the pointers of one
@@ -157,26 +174,17 @@ class GCN2(_GraphRunner):
         key = (batch.n, batch.n_graphs)
         if self._bufs is not None and self._bufs["key"] == key:
             return self._bufs
-        ctx, n, b, h, c = self.ctx, batch.n, batch.n_graphs, self.hidden, self.n_labels
+        n, b, h, c = batch.n, batch.n_graphs, self.hidden, self.n_labels
         self._drop_graphs()
-        cap = getattr(self, "_cap", None)
-        if cap is None or n > cap["n"] or b > cap["b"]:
-            cn = max(n, int(1.25 * cap["n"]) if cap else 0)
-            cb = max(b, cap["b"] if cap else 0)
-            cap = {"n": cn, "b": cb}
-            for k in ("h", "y1", "y2", "dz", "h2", "dz2"):
-                cap[k] = ctx.empty((cn, h))
-            for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
-                cap[k] = ctx.empty((cb, w))
-            cap["arg"] = ctx.empty((cb, h), np.int32) if self.pool == "max" else None
-            self._cap = cap
-        view = lambda k, rows, w: cap[k].flat(0, rows * w, (rows, w))
+        if getattr(self, "_cap", None) is None:
+            self._cap = _Capacity(self.ctx)
+        v = self._cap.view
         self._bufs = {"key": key}
-        for k in ("h", "y1", "y2", "dz", "h2", "dz2"):
-            self._bufs[k] = view(k, n, h)
+        for k in ("h", "y1", "y2", "dz", "h2", "dz2"):          # h2 / dz2: the side section still reads h / dz
+            self._bufs[k] = v(k, n, h)
         for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
-            self._bufs[k] = view(k, b, w)
-        self._bufs["arg"] = view("arg", b, h) if cap["arg"] is not None else None
+            self._bufs[k] = v(k, b, w)
+        self._bufs["arg"] = v("arg", b, h, np.int32) if self.pool == "max" else None
         return self._bufs
 
     # ---- the call sequences --------------------------------------------------------------------
@@ -420,13 +428,16 @@ class GeneralGNN(_GraphRunner):
         ctx, n, b, h = self.ctx, batch.n, batch.n_graphs, self.hidden
         self._drop_graphs()
         wcat = h * (self.mp + 1)
-        bufs = {"key": key, "cat": ctx.empty((n, wcat)), "dcat": ctx.empty((n, wcat)), "h": ctx.empty((n, h)),
-                "dh": ctx.empty((n, h)), "pooled": ctx.empty((b, wcat)), "dpooled": ctx.empty((b, wcat)),
-                "probs": ctx.empty((b, self.output)), "dlogits": ctx.empty((b, self.output)), "zy": ctx.zeros((b, self.output))}
+        if getattr(self, "_cap", None) is None:
+            self._cap = _Capacity(ctx)
+        v = self._cap.view
+        bufs = {"key": key, "cat": v("cat", n, wcat), "dcat": v("dcat", n, wcat), "h": v("h", n, h), "dh": v("dh", n, h),
+                "pooled": v("pooled", b, wcat), "dpooled": v("dpooled", b, wcat), "probs": v("probs", b, self.output),
+                "dlogits": v("dlogits", b, self.output), "zy": v("zy", b, self.output, zero=True)}
         for i, L in enumerate(self.layers):
             rows = b if L["group"] == "post" else n
-            bufs[f"z{i}"] = ctx.empty((rows, L["fo"]))           # Dense output (pre-BN), kept for the backward pass
-            bufs[f"y{i}"] = ctx.empty((rows, L["fo"]))           # layer output where it is not a slice of `cat`
+            bufs[f"z{i}"] = v(f"z{i}", rows, L["fo"])             # Dense output (pre-BN), kept for the backward pass
+            bufs[f"y{i}"] = v(f"y{i}", rows, L["fo"])             # layer output where it is not a slice of `cat`
         self._bufs = bufs
         return bufs
 
@@ -508,7 +519,12 @@ class GeneralGNN(_GraphRunner):
 
     def _tmp(self, bufs, key, shape):
         if key not in bufs or bufs[key].shape != tuple(shape):
-            bufs[key] = self.ctx.empty(shape)
+            if getattr(self, "_cap", None) is None:
+                self._cap = _Capacity(self.ctx)
+            shape = tuple(shape) if len(shape) == 2 else (1, int(np.prod(shape)))
+            bufs[key] = self._cap.view("tmp_" + key, shape[0], shape[1])
+            if len(shape) != 2:
+                bufs[key] = bufs[key].flat(0, shape[1])
         return bufs[key]
 
     # ---- public surface ----------------------------------------------------------------------------
