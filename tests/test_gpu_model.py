@@ -259,6 +259,53 @@ def test_rccl_path_single_rank(ctx):
     assert np.array_equal(d.numpy(), x) and float(c1.allreduce_host([3.5], "max")[0]) == 3.5
 
 
+@pytest.mark.gpu
+def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
+    """The sharded step on the DEVICE path at world_size 2: two ranks (threads, each with its own Context on device
+    0, a host-mediated communicator of the Communicator interface, tests/thread_comm.py) take graph shards of one
+    batch, normalise the loss by the global batch, all-reduce the flat gradient (+ loss/accuracy tail) once and
+    apply SGD -- and land on the 1-rank loss, accuracy, gradients and updated weights (fp32 reduction order)."""
+    import gcnx
+    from gcnx import synth, shard
+    from gcnx.models import DeviceBatch, GCN2
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from thread_comm import ThreadWorld
+    hb = synth.ecoli_batch(6, 32, seed=8)
+    hb.vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+
+    def make_batch(ctx, part):
+        a = gcnx.DeviceCSR.from_host_csr(ctx, part.rowptr, part.colidx, part.vals, part.graph_ptr)
+        seg = gcnx.Segments(ctx, part.graph_ptr)
+        return DeviceBatch(ctx, ctx.to_device(part.x), a, seg, ctx.to_device(part.y, np.float32))
+
+    ctx0 = gcnx.Context(0)
+    ref = GCN2(ctx0, 2, hidden=32, seed=5, use_graph=False)
+    ref_loss, ref_acc = ref.train_step(make_batch(ctx0, hb), None, lr=0.05)
+    ref_g, ref_w = ref.gradients(), ref.get_weights()
+    ctx0.close()
+
+    def rank_fn(rank, make_comm):
+        ctx = gcnx.Context(0)
+        part, global_b = shard.shard_batch(hb, rank, 2)
+        m = GCN2(ctx, 2, hidden=32, seed=5, use_graph=False, comm=make_comm(ctx))
+        loss, acc = m.train_step(make_batch(ctx, part), None, lr=0.05, global_batch=global_b)
+        out = (loss, acc, m.gradients(), m.get_weights(), m.comm.calls)
+        ctx.close()
+        return out
+
+    res = ThreadWorld(2).run(rank_fn)
+    for loss, acc, g, w, calls in res:
+        assert calls == 1                                  # ONE all-reduce per step
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)) and acc == pytest.approx(ref_acc)
+        for k in g:
+            assert rel_err(g[k], ref_g[k]) < 2e-5, k
+        for a, b in zip(w, ref_w):
+            assert rel_err(a, b) < 2e-5
+    for a, b in zip(res[0][3], res[1][3]):
+        assert np.array_equal(a, b)                        # both ranks hold the same weights, bit for bit
+
+
 def test_evaluate_loop_matches_reference_semantics(ctx):
     """evaluate(loader) of gcn.py:342-362: eager forward per batch, loss/acc weighted by batch size."""
     from oracle import gcn_oracle as O
