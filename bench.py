@@ -99,7 +99,7 @@ def bench_generalgnn(ctx, args):
     from gcnx import synth
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch, GeneralGNN
-    assert args.gpus == 1, "GeneralGNN is single-GPU this round (sync-BN not built)"
+    assert args.gpus == 1, "this secondary line is single-GPU; the sync-BN multi-GPU step is exercised by tests/ (world_size 2)"
     hb = synth.ecoli_batch(32, 16, seed=1) if args.workload == "ecoli" else synth.block_diag_batch(1_000_000, 10_000_000, 16, seed=2)
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))

@@ -372,43 +372,66 @@ int gcnx_bn_act(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f
   return GCNX_OK;
 }
 
-int gcnx_bn_act_bwd(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n, int32_t f,
-                    const float* mean, const float* inv, const float* gamma, const float* beta, int act,
-                    const float* alpha, int training, float* dz, int64_t lddz, float* dgamma, float* dbeta,
-                    float* dalpha, float* sums_scratch) {
+// Two halves of the BatchNorm backward, so that a multi-GPU caller can all-reduce the three column sums between
+// them (sync-BN); gcnx_bn_act_bwd below is stats + apply with the local row count.
+int gcnx_bn_act_bwd_stats(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n, int32_t f,
+                          const float* mean, const float* inv, const float* gamma, const float* beta, int act,
+                          const float* alpha, float* sums_scratch, float* dgamma, float* dbeta, float* dalpha) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_bn_act_bwd: negative size");
   GCNX_REQUIRE(ctx, act >= GCNX_ACT_NONE && act <= GCNX_ACT_PRELU, "gcnx_bn_act_bwd: unknown activation %d", act);
   if (f == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, sums_scratch != nullptr, "gcnx_bn_act_bwd: sums_scratch (device float[3f]) is NULL");
-  if (n == 0) {
+  if (n == 0) {   // no rows: sums and gradients are zero
     GCNX_HIP(ctx, hipMemsetAsync(sums_scratch, 0, (size_t)3 * f * 4, ctx->stream));
-  } else {
-    GCNX_REQUIRE(ctx, dy && z && dz && mean && inv && gamma && beta, "gcnx_bn_act_bwd: NULL pointer");
-    GCNX_REQUIRE(ctx, act != GCNX_ACT_PRELU || alpha, "gcnx_bn_act_bwd: PReLU needs alpha");
-    GCNX_REQUIRE(ctx, lddy >= f && ldz >= f && lddz >= f, "gcnx_bn_act_bwd: leading dimension too small");
-    const int nchunks = gcnx_cdiv(n, kRows);
-    int rc = gcnx_ws_reserve(ctx, (size_t)nchunks * 3 * f * sizeof(float));
-    if (rc) return rc;
-    const int vec = al16(dy) && al16(z) && al16(dz) && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0;
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(gcnx_cdiv(f, 64), nchunks), dim3(256), 0, ctx->stream, dy, lddy, z, ldz, n,
-                       f, mean, inv, gamma, beta, act, alpha, (float*)ctx->ws, vec);
-    GCNX_LAUNCH_OK(ctx);
-    // parameter gradients ride along: dbeta = sum dzb, dgamma = sum dzb*xhat, dalpha = sum dy*min(zb,0)
-    rc = reduce_parts(ctx, nchunks, 3, f, sums_scratch, dbeta, dgamma, dalpha);
-    if (rc) return rc;
-    int gy = gcnx_cdiv(n, 4);
-    if (gy > 8 * ctx->num_cus) gy = 8 * ctx->num_cus;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gcnx_cdiv(f, 256), gy), dim3(256), 0, ctx->stream, dy, lddy, z, ldz, n, f,
-                       mean, inv, gamma, beta, act, alpha, (const float*)sums_scratch, (float)n, training, dz, lddz, vec);
-    GCNX_LAUNCH_OK(ctx);
-  }
-  if (n == 0) {   // no rows: the gradients are the zeros just written
     if (dbeta) GCNX_HIP(ctx, hipMemsetAsync(dbeta, 0, (size_t)f * 4, ctx->stream));
     if (dgamma) GCNX_HIP(ctx, hipMemsetAsync(dgamma, 0, (size_t)f * 4, ctx->stream));
     if (dalpha) GCNX_HIP(ctx, hipMemsetAsync(dalpha, 0, (size_t)f * 4, ctx->stream));
+    return GCNX_OK;
   }
+  GCNX_REQUIRE(ctx, dy && z && mean && inv && gamma && beta, "gcnx_bn_act_bwd: NULL pointer");
+  GCNX_REQUIRE(ctx, act != GCNX_ACT_PRELU || alpha, "gcnx_bn_act_bwd: PReLU needs alpha");
+  GCNX_REQUIRE(ctx, lddy >= f && ldz >= f, "gcnx_bn_act_bwd: leading dimension too small");
+  const int nchunks = gcnx_cdiv(n, kRows);
+  int rc = gcnx_ws_reserve(ctx, (size_t)nchunks * 3 * f * sizeof(float));
+  if (rc) return rc;
+  const int vec = al16(dy) && al16(z) && lddy % 4 == 0 && ldz % 4 == 0;
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(gcnx_cdiv(f, 64), nchunks), dim3(256), 0, ctx->stream, dy, lddy, z, ldz, n,
+                     f, mean, inv, gamma, beta, act, alpha, (float*)ctx->ws, vec);
+  GCNX_LAUNCH_OK(ctx);
+  // parameter gradients ride along: dbeta = sum dzb, dgamma = sum dzb*xhat, dalpha = sum dy*min(zb,0)
+  return reduce_parts(ctx, nchunks, 3, f, sums_scratch, dbeta, dgamma, dalpha);
+}
+
+int gcnx_bn_act_bwd_apply(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n, int32_t f,
+                          const float* mean, const float* inv, const float* gamma, const float* beta, int act,
+                          const float* alpha, const float* sums, float count, int training, float* dz, int64_t lddz) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_bn_act_bwd: negative size");
+  GCNX_REQUIRE(ctx, act >= GCNX_ACT_NONE && act <= GCNX_ACT_PRELU, "gcnx_bn_act_bwd: unknown activation %d", act);
+  if (f == 0 || n == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, dy && z && dz && mean && inv && gamma && beta && sums, "gcnx_bn_act_bwd: NULL pointer");
+  GCNX_REQUIRE(ctx, act != GCNX_ACT_PRELU || alpha, "gcnx_bn_act_bwd: PReLU needs alpha");
+  GCNX_REQUIRE(ctx, lddy >= f && ldz >= f && lddz >= f, "gcnx_bn_act_bwd: leading dimension too small");
+  GCNX_REQUIRE(ctx, count > 0.f, "gcnx_bn_act_bwd: count must be positive");
+  const int vec = al16(dy) && al16(z) && al16(dz) && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0;
+  int gy = gcnx_cdiv(n, 4);
+  if (gy > 8 * ctx->num_cus) gy = 8 * ctx->num_cus;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gcnx_cdiv(f, 256), gy), dim3(256), 0, ctx->stream, dy, lddy, z, ldz, n, f,
+                     mean, inv, gamma, beta, act, alpha, sums, count, training, dz, lddz, vec);
+  GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
+}
+
+int gcnx_bn_act_bwd(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n, int32_t f,
+                    const float* mean, const float* inv, const float* gamma, const float* beta, int act,
+                    const float* alpha, int training, float* dz, int64_t lddz, float* dgamma, float* dbeta,
+                    float* dalpha, float* sums_scratch) {
+  int rc = gcnx_bn_act_bwd_stats(ctx, dy, lddy, z, ldz, n, f, mean, inv, gamma, beta, act, alpha, sums_scratch, dgamma,
+                                 dbeta, dalpha);
+  if (rc || n == 0 || f == 0) return rc;
+  return gcnx_bn_act_bwd_apply(ctx, dy, lddy, z, ldz, n, f, mean, inv, gamma, beta, act, alpha, sums_scratch, (float)n,
+                               training, dz, lddz);
 }
 
 }  // extern "C"

@@ -463,3 +463,18 @@ def bn_act_bwd(ctx, dy, z, mean, inv, gamma, beta, dz, scratch, act=None, alpha=
                                     L.ACTS[act], _p(alpha), 1 if training else 0, _p(dz), dz.ld, _p(dgamma), _p(dbeta),
                                     _p(dalpha), _p(scratch)))
     return dz
+
+
+def bn_act_bwd_stats(ctx, dy, z, mean, inv, gamma, beta, scratch, act=None, alpha=None, dgamma=None, dbeta=None, dalpha=None):
+    """First half of bn_act_bwd (sync-BN): the three local column sums -> scratch[3f] and the parameter gradients."""
+    n, f = z.shape
+    ctx._ck(ctx.lib.gcnx_bn_act_bwd_stats(ctx.h, _p(dy), dy.ld, _p(z), z.ld, n, f, _p(mean), _p(inv), _p(gamma), _p(beta),
+                                          L.ACTS[act], _p(alpha), _p(scratch), _p(dgamma), _p(dbeta), _p(dalpha)))
+
+
+def bn_act_bwd_apply(ctx, dy, z, mean, inv, gamma, beta, sums, count, dz, act=None, alpha=None, training=True):
+    """Second half: dz from the (all-reduced) sums and the global row count."""
+    n, f = z.shape
+    ctx._ck(ctx.lib.gcnx_bn_act_bwd_apply(ctx.h, _p(dy), dy.ld, _p(z), z.ld, n, f, _p(mean), _p(inv), _p(gamma), _p(beta),
+                                          L.ACTS[act], _p(alpha), _p(sums), float(count), 1 if training else 0, _p(dz), dz.ld))
+    return dz

@@ -339,13 +339,16 @@ class GeneralGNN(_GraphRunner):
     else raises).  The skip concatenation is never materialised: every layer reads / writes a
     column slice of one [N, hidden*(message_passing+1)] buffer through leading-dimension views.
     Weights are exposed in Keras order per layer: kernel, bias, gamma, beta, moving_mean,
-    moving_variance, alpha.  Single-GPU only this round (sync-BN is the SURVEY 8(e) follow-up).
+    moving_variance, alpha.  With a communicator (one process per GPU, a graph shard each) BatchNormalization is
+    synchronised: the column sums of both moment passes and of the backward pass are all-reduced, so every rank
+    normalises with the statistics of the GLOBAL batch, and the step equals the single-GPU step on the whole batch.
     """
 
     def __init__(self, ctx, output, activation=None, hidden=256, message_passing=4, pre_process=2, post_process=2,
                  connectivity="cat", batch_norm=True, dropout=0.0, aggregate="sum", hidden_activation="prelu", pool="sum",
-                 prec="f32", seed=0, use_graph=True):
+                 prec="f32", seed=0, use_graph=True, comm=None):
         self.use_graph, self._graphs = use_graph, {}
+        self.comm = comm                                  # gcnx.comm.Communicator: sync-BN + gradient all-reduce
         unsupported = {"connectivity": (connectivity, "cat"), "batch_norm": (batch_norm, True), "dropout": (dropout, 0.0),
                        "aggregate": (aggregate, "sum"), "hidden_activation": (hidden_activation, "prelu"),
                        "pool": (pool, "sum"), "activation": (activation, "softmax")}
@@ -441,10 +444,22 @@ class GeneralGNN(_GraphRunner):
         self._bufs = bufs
         return bufs
 
+    def _multi(self):
+        return self.comm is not None and self.comm.world_size > 1
+
     def _dense_bn(self, L, x, z, y, training):
         ctx = self.ctx
         D.gemm(ctx, x, L["kernel"], L["bias"], z, prec=self.prec)
-        if training:
+        if training and self._multi():
+            # sync-BN: the two moment passes with their column sums all-reduced and the GLOBAL row count
+            count = self._counts["b" if L["group"] == "post" else "n"]
+            D.bn_stats(ctx, z, L["sums"])
+            self.comm.allreduce_sum(L["sums"])
+            D.bn_finalize(ctx, L["sums"], count, L["mean"], L["inv"])
+            D.bn_stats(ctx, z, L["sums"], shift=L["mean"])
+            self.comm.allreduce_sum(L["sums"])
+            D.bn_finalize(ctx, L["sums"], count, L["mean"], L["inv"], L["moving_mean"], L["moving_var"], shift=L["mean"])
+        elif training:
             D.bn_moments(ctx, z, L["sums"], L["mean"], L["inv"], L["moving_mean"], L["moving_var"])
         else:
             D.bn_finalize(ctx, None, 1, L["mean"], L["inv"], L["moving_mean"], L["moving_var"])
@@ -478,9 +493,19 @@ class GeneralGNN(_GraphRunner):
     def _bwd_dense_bn(self, L, dy, x, z, dx, training, accumulate=False):
         ctx = self.ctx
         dz = dy                                            # in place
-        D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
-                     alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
-                     dalpha=L.get("g_alpha"))
+        if training and self._multi():
+            # local column sums -> parameter gradients (summed over ranks by the final all-reduce with the rest);
+            # the same sums, all-reduced, and the global row count give dz
+            count = self._counts["b" if L["group"] == "post" else "n"]
+            D.bn_act_bwd_stats(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], L["scratch"], act=L["act"],
+                               alpha=L.get("alpha"), dgamma=L["g_gamma"], dbeta=L["g_beta"], dalpha=L.get("g_alpha"))
+            self.comm.allreduce_sum(L["scratch"])
+            D.bn_act_bwd_apply(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], L["scratch"], count, dz,
+                               act=L["act"], alpha=L.get("alpha"), training=True)
+        else:
+            D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
+                         alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
+                         dalpha=L.get("g_alpha"))
         D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=self.prec)
         D.act_bias_grad(ctx, dz, None, dz, None, db=L["g_bias"])
         if dx is not None:
@@ -544,27 +569,44 @@ class GeneralGNN(_GraphRunner):
         D.softmax_cce(self.ctx, logits, bufs["zy"], bufs["probs"], la, None, None)
         return bufs["probs"].numpy()
 
-    def loss_and_grads(self, inputs, target=None, _lr=None):
+    def loss_and_grads(self, inputs, target=None, _lr=None, global_batch=None):
+        """Forward (training=True) + loss + every gradient.  With a communicator the batch is this rank's shard:
+        the loss is normalised by ``global_batch`` graphs, BatchNorm runs on the global statistics, and one
+        all-reduce sums the flat gradient buffer (+ loss / accuracy tail) over the ranks."""
         batch = self._as_batch(inputs, target)
         bufs = self._ensure(batch)
+        multi = self._multi()
+        denom = float(global_batch or batch.n_graphs)
+        if multi:
+            tot = self.comm.allreduce_host([batch.n, batch.n_graphs], "sum")
+            self._counts = {"n": float(tot[0]), "b": float(tot[1])}
+            denom = float(global_batch or tot[1])
+
         def seq():
             logits = self._forward(batch, bufs, True)
             self.loss_acc.fill_zero()
-            D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], batch.n_graphs)
+            D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom)
             self._backward(batch, bufs, True)
-            if _lr is not None:                            # the update rides in the same captured graph
+            if _lr is not None and not multi:              # the update rides in the same captured graph
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
-        self._run(("grad", batch.uid, _lr), seq)
+        if multi:
+            seq()                                          # collectives inside: not captured
+            self.comm.allreduce_sum(self.flat_g)
+        else:
+            self._run(("grad", batch.uid, _lr), seq)
         return batch
 
-    def train_step(self, inputs, target=None, lr=0.02, fetch=True):
+    def train_step(self, inputs, target=None, lr=0.02, fetch=True, global_batch=None):
         """gcn.py:330-340 for the live model: forward(training=True), CCE, gradients, SGD, accuracy."""
-        batch = self.loss_and_grads(inputs, target, _lr=float(lr))
+        batch = self.loss_and_grads(inputs, target, _lr=float(lr), global_batch=global_batch)
+        if self._multi():
+            D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr)
         if not fetch:
             return None
         la = self.loss_acc.numpy()
-        return float(la[0]), float(la[1]) / batch.n_graphs
+        n_graphs = global_batch or (self._counts["b"] if self._multi() else batch.n_graphs)
+        return float(la[0]), float(la[1]) / float(n_graphs)
 
     def evaluate_batch(self, inputs, target):
         batch = self._as_batch(inputs, target)

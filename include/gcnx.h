@@ -235,6 +235,15 @@ GCNX_API int gcnx_bn_act_bwd(gcnx_ctx* ctx, const float* dy, int64_t lddy, const
                              int32_t f, const float* mean, const float* inv, const float* gamma, const float* beta,
                              int act, const float* alpha, int training, float* dz, int64_t lddz, float* dgamma,
                              float* dbeta, float* dalpha, float* sums_scratch);
+/* The two halves of gcnx_bn_act_bwd for sync-BN: _stats writes the three LOCAL column sums to sums_scratch[3f]
+ * (and, if given, to dbeta / dgamma / dalpha -- local parts, to be summed with the other parameter gradients);
+ * the caller all-reduces sums_scratch; _apply forms dz with the reduced sums and the GLOBAL row count. */
+GCNX_API int gcnx_bn_act_bwd_stats(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n,
+                          int32_t f, const float* mean, const float* inv, const float* gamma, const float* beta, int act,
+                          const float* alpha, float* sums_scratch, float* dgamma, float* dbeta, float* dalpha);
+GCNX_API int gcnx_bn_act_bwd_apply(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t n,
+                          int32_t f, const float* mean, const float* inv, const float* gamma, const float* beta, int act,
+                          const float* alpha, const float* sums, float count, int training, float* dz, int64_t lddz);
 
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */

@@ -259,7 +259,6 @@ def test_rccl_path_single_rank(ctx):
     assert np.array_equal(d.numpy(), x) and float(c1.allreduce_host([3.5], "max")[0]) == 3.5
 
 
-@pytest.mark.gpu
 def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
     """The sharded step on the DEVICE path at world_size 2: two ranks (threads, each with its own Context on device
     0, a host-mediated communicator of the Communicator interface, tests/thread_comm.py) take graph shards of one
@@ -304,6 +303,50 @@ def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
             assert rel_err(a, b) < 2e-5
     for a, b in zip(res[0][3], res[1][3]):
         assert np.array_equal(a, b)                        # both ranks hold the same weights, bit for bit
+
+
+def test_general_gnn_sync_bn_world_size_2_equals_single_rank():
+    """GeneralGNN with a communicator (sync-BN): two thread ranks with graph shards of one batch normalise with the
+    GLOBAL batch statistics (all-reduced column sums in both moment passes and in the BN backward), and the step --
+    loss, accuracy, every gradient, the updated weights and the moving statistics -- equals the single-rank step on
+    the whole batch up to fp32 reduction order."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gcnx
+    from gcnx import synth, shard
+    from gcnx.models import DeviceBatch, GeneralGNN
+    from thread_comm import ThreadWorld
+    hb = synth.ecoli_batch(6, 16, seed=12)
+
+    def make_batch(ctx, part):
+        a = gcnx.DeviceCSR.from_host_csr(ctx, part.rowptr, part.colidx, None, part.graph_ptr)
+        return DeviceBatch(ctx, ctx.to_device(part.x), a, gcnx.Segments(ctx, part.graph_ptr), ctx.to_device(part.y, np.float32))
+
+    kw = dict(activation="softmax", hidden=32, message_passing=2, seed=3, use_graph=False)
+    ctx0 = gcnx.Context(0)
+    ref = GeneralGNN(ctx0, 2, **kw)
+    ref_loss, ref_acc = ref.train_step(make_batch(ctx0, hb), None, lr=0.05)
+    ref_g = ref.flat_g.numpy()[:ref.n_params]
+    ref_w = [w.copy() for w in ref.get_weights()]
+    ctx0.close()
+
+    def rank_fn(rank, make_comm):
+        ctx = gcnx.Context(0)
+        part, global_b = shard.shard_batch(hb, rank, 2)
+        m = GeneralGNN(ctx, 2, comm=make_comm(ctx), **kw)
+        loss, acc = m.train_step(make_batch(ctx, part), None, lr=0.05, global_batch=global_b)
+        out = (loss, acc, m.flat_g.numpy()[:m.n_params], [w.copy() for w in m.get_weights()])
+        ctx.close()
+        return out
+
+    res = ThreadWorld(2).run(rank_fn)
+    for loss, acc, g, w in res:
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)) and acc == pytest.approx(ref_acc)
+        assert rel_err(g, ref_g) < 1e-4
+        for a, b in zip(w, ref_w):
+            assert rel_err(a, b) < 1e-4 or np.abs(a - b).max() < 1e-6
+    for a, b in zip(res[0][3], res[1][3]):
+        assert np.array_equal(a, b)                        # weights and moving statistics identical on both ranks
 
 
 def test_evaluate_loop_matches_reference_semantics(ctx):
