@@ -39,6 +39,7 @@ constexpr int kRowsPerChunk = 32;    // rows per workgroup (large inputs; plan c
 constexpr int kRowsPerChunkSmall = 8;   // small inputs: more, shorter workgroups (launch-latency regime)
 constexpr int kSlab = 32;             // widest column slab of the tile kernel
 constexpr int kStageCap = 2048;      // CSR entries staged in LDS per chunk (overflow -> global)
+constexpr int kLongRow = 256;        // rows with more entries are split over the workgroup's four waves
 
 __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
   a.x = fmaf(v, h.x, a.x); a.y = fmaf(v, h.y, a.y); a.z = fmaf(v, h.z, a.z); a.w = fmaf(v, h.w, a.w);
@@ -47,7 +48,8 @@ __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 template <int LPR, bool WEIGHTED, int RPC>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256, 8) void spmm_rows_kernel(   // 8 waves per SIMD: at most 64 VGPRs (latency regime)
+   const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx,
                                                         const float* __restrict__ vals,
                                                         const float* __restrict__ h, int64_t ldh,
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
   __shared__ int32_t s_col[kStageCap];
   __shared__ float s_val[WEIGHTED ? kStageCap : 1];
   __shared__ int32_t s_rp[RPC + 1];
+  __shared__ float4 s_long[4][LPR];     // per-wave partial sums of a long row
 
   const int chunk = gcnx_xcd_remap(blockIdx.x, nchunks);
   int r0 = chunk * RPC;
@@ -111,8 +114,11 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
   };
   for (int r = r0 + wave; r < r1; r += 8) {
     const int rB = r + 4;                                          // second row of this trip (may be past the chunk)
-    const int aA = s_rp[r - r0] - e0, bA = s_rp[r - r0 + 1] - e0;  // chunk-relative entry ranges
-    const int aB = rB < r1 ? s_rp[rB - r0] - e0 : 0, bB = rB < r1 ? s_rp[rB - r0 + 1] - e0 : 0;
+    int aA = s_rp[r - r0] - e0, bA = s_rp[r - r0 + 1] - e0;        // chunk-relative entry ranges
+    int aB = rB < r1 ? s_rp[rB - r0] - e0 : 0, bB = rB < r1 ? s_rp[rB - r0 + 1] - e0 : 0;
+    const bool longA = bA - aA > kLongRow, longB = bB - aB > kLongRow;   // hubs: done by all four waves below
+    if (longA) bA = aA;
+    if (longB) bB = aB;
     float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
     if (col_ok) {
       int eA = aA + g, eB = aB + g;
@@ -136,8 +142,51 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int32_t* __restric
         eB += 2 * G;
       }
     }
-    finish(accA, r);
-    finish(accB, rB);
+    finish(accA, longA ? r1 : r);               // r1: outside the chunk = no store (the merge shuffles still run)
+    finish(accB, longB ? r1 : rB);
+  }
+  // Hub rows (power-law batches: one row of a chunk can hold thousands of entries).  Walked by a single wave such a
+  // row alone set the kernel's duration (config 5: a 4096-entry row = 2 ms); here every wave of the workgroup takes
+  // a quarter of its entries and the four partial sums are combined in wave order (deterministic).
+  if (e1 - e0 <= kLongRow) return;               // no row of this chunk can be that long (uniform)
+  for (int r = r0; r < r1; ++r) {                // uniform over the workgroup
+    const int a = s_rp[r - r0] - e0, b = s_rp[r - r0 + 1] - e0;
+    if (b - a <= kLongRow) continue;
+    const int per = (b - a + 3) / 4;
+    const int wa = a + wave * per, wb = min(b, wa + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok) {
+      for (int e = wa + g; e < wb; e += 4 * G) {      // four neighbours in flight per lane
+        float4 hv[4];
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int cc = 0;
+          vv[u] = 0.f;
+          hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e + u * G < wb) { entry(e + u * G, cc, vv[u]); hv[u] = *reinterpret_cast<const float4*>(h + (int64_t)cc * ldh + c); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e + u * G < wb) acc = WEIGHTED ? f4_fma(vv[u], hv[u], acc) : f4_add(acc, hv[u]);
+      }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off);
+      acc.y += __shfl_xor(acc.y, off);
+      acc.z += __shfl_xor(acc.z, off);
+      acc.w += __shfl_xor(acc.w, off);
+    }
+    __syncthreads();                             // s_long free (previous long row consumed)
+    if (g == 0) s_long[wave][sub] = acc;
+    __syncthreads();
+    if (wave == 0 && g == 0 && col_ok) {
+      float4 t = f4_add(f4_add(s_long[0][sub], s_long[1][sub]), f4_add(s_long[2][sub], s_long[3][sub]));
+      t = f4_add(t, bv);
+      if (act == GCNX_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = t;
+    }
   }
 }
 
