@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
 // One wave per run of kPoolBwdRows consecutive rows (64 float4 lanes cover 256 columns per pass).  The graph of
 // the run's first row is found by ONE binary search in graph_ptr (log2 B dependent loads -- per row they were
 // most of this kernel's time); the following rows only step the graph index forward.
-constexpr int kPoolBwdRows = 8;   // at most; small inputs take fewer rows per wave so that the grid still fills the chip
+constexpr int kPoolBwdRows = 32;  // at most; small inputs take fewer rows per wave so that the grid still fills the chip
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const int32_t* __restrict__ gp, int32_t b,
                                                        const float* __restrict__ dp, float* __restrict__ dx,
                                                        int64_t lddx, int32_t n, int32_t f, int mode,
