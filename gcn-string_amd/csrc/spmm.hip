@@ -48,7 +48,7 @@ __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 template <int LPR, bool WEIGHTED, int RPC>
-__global__ __launch_bounds__(256, 8) void spmm_rows_kernel(   // 8 waves per SIMD: at most 64 VGPRs (latency regime)
+__global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   // 8 waves per SIMD = at most 64 VGPRs (latency regime)
    const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx,
                                                         const float* __restrict__ vals,
@@ -208,12 +208,7 @@ struct __attribute__((aligned(4))) I2u { int x, y; };
 // redirected to the zero row `pad` (cols) / 0 (vals).  `last4` = nnz - 4 guards the array end.
 // SCALE: the stored value is (col - row0) * SCALE -- the byte offset of the tile row, computed once per
 // fetched entry instead of once per lane that consumes the broadcast.
-// SCALE == 128 (32-column tiles) additionally folds the bank swizzle into the offset: rows with bit 1 of
-// their index set keep their two 64-byte halves swapped (tile_dma stores them that way), so the offset
-// points at the row's logical first half and `offset ^ 64` at the second.
-__device__ __forceinline__ int tile_off(int row, int scale) {
-  return scale == -128 ? row * 128 + ((row & 2) << 5) : row * scale;   // -128: 128-byte rows with the half-swap swizzle
-}
+__device__ __forceinline__ int tile_off(int row, int scale) { return row * scale; }
 
 template <bool WEIGHTED, int SCALE = 1>
 __device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
@@ -241,41 +236,12 @@ __device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx
 }
 
 // ----------------------------------------------------------------------------------------------
-// Tile kernels: persistent workgroups that own a CU's 160 KiB of LDS as two tile buffers.
-// While one tile is reduced, the next one streams into the other buffer by LDS-DMA
-// (global_load_lds_dwordx4: no VGPRs, nothing to wait for until the next barrier), so HBM reads,
-// LDS gathers and output stores of neighbouring steps overlap inside one CU.
+// Building blocks of the tile kernel: the index burst (row pointers + the first 16 entries of every row, in
+// registers) and the LDS-DMA of a tile.
 // ----------------------------------------------------------------------------------------------
-constexpr int kPT = 1024;                         // threads per workgroup of the queue-driven kernel
-constexpr int kPWaves = kPT / 64;
-constexpr int kTilePieces = 5056;                 // float4 pieces per tile buffer = 79 wave-instructions
-constexpr int kTileFloats = kTilePieces * 4;      // zero row starts here (same byte offset for every tier)
-constexpr int kBufFloats = 80 * 1024 / 4;         // one buffer; 2 buffers = all 160 KiB of a CU
-constexpr int kCtrlFloat = kTileFloats + 64;      // two int slots for queue hand-off, inside buffer 0's tail
-constexpr int kCap32 = kTilePieces / 8;           // 632 rows at FT = 32
-constexpr int kSpan = kPWaves * 16;               // rows a 1024-thread workgroup covers per wave iteration (quad per row)
-
-template <int PPR, int THREADS = kPT, bool HALFSWAP = (PPR == 8), int PIECES = kTilePieces>   // float4 pieces per tile row
-__device__ __forceinline__ void tile_dma(float* buf, const float* __restrict__ h, int64_t ldh, int row0, int ng, int c0) {
-  const int tid = threadIdx.x;
-  const int total = ng * PPR;
-#pragma unroll
-  for (int u = 0; u < (PIECES + THREADS - 1) / THREADS; ++u) {
-    const int i = tid + u * THREADS;
-    if (i < total) {
-      const int r = i / PPR;
-      const int q = HALFSWAP ? ((i % PPR) ^ ((r & 2) << 1)) : (i % PPR);   // half-swap swizzle (tile_off), queue kernel only
-      const float* src = h + (int64_t)(row0 + r) * ldh + c0 + q * 4;
-      float* dst = buf + (u * THREADS + (tid & ~63)) * 4;   // wave-uniform base; the DMA adds lane*16 bytes
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  }
-}
-
 // Index burst of an item, part 1: row pointers of every row this quad owns (NI wave iterations),
 // branch-free so that all loads are in flight at once.
-template <int NI, int SPAN = kSpan, int LPR = 4>
+template <int NI, int SPAN, int LPR>
 __device__ __forceinline__ void tile_load_rowptr(const int32_t* __restrict__ rowptr, int row0, int ng, int (&a)[NI],
                                                  int (&b)[NI], int rlo = 0) {
   // rows [rlo, ng) of the block; ng doubles as the (exclusive) end of the row range
@@ -301,162 +267,6 @@ __device__ __forceinline__ void tile_load_entries(const int32_t* __restrict__ co
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Reduction of one item out of its LDS tile (indices already in registers).  One quad per row,
-// CPL float4 column chunks per lane.  The loop is VALU-bound (PMC: VALU 58 % busy over the whole
-// launch, LDS 34 %), so per (entry, lane) it is cut to the minimum: the entry's tile-row BYTE
-// OFFSET and value arrive by one DPP broadcast each, the float4 chunks are read at immediate
-// offsets from that address, and the 4*CPL multiply-adds are issued as packed v_pk_fma_f32.
-// KEEP: leave mc/mv holding each row's FIRST 16 entries on return.
-template <int NI, int CPL, bool WEIGHTED, bool KEEP>
-__device__ __forceinline__ void tile_reduce(const float* __restrict__ tile, const int32_t* __restrict__ colidx,
-                                            const float* __restrict__ vals, const float4 (&bv)[CPL],
-                                            float* __restrict__ out, int64_t ldo, int row0, int ng, int c0, int act,
-                                            int pad, int last4, const int (&a)[NI], const int (&b)[NI],
-                                            int (&mc)[NI][4], float (&mv)[NI][4], int rlo = 0) {
-  // output rows [rlo, ng) of the block (ng = exclusive end of the row range)
-  constexpr int FT = 16 * CPL;
-  constexpr int RB = FT * 4;   // bytes per tile row
-  const int lane = threadIdx.x & 63;
-  const int sub = lane & 3;
-  const int rbase = rlo + (threadIdx.x >> 6) * 16 + (lane >> 2);
-  const char* tbase = reinterpret_cast<const char*>(tile) + sub * 16;
-#pragma unroll
-  for (int t = 0; t < NI; ++t) if (rlo + t * kSpan < ng) {
-    const int r = rbase + t * kSpan;
-    f32x2 acc[CPL][2];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
-    int base = a[t];
-    const int bb = b[t];
-    while (true) {
-#define GCNX_TSTEP4(J)                                                                                         \
-      if ((J) == 0 || __builtin_amdgcn_ballot_w64(base + 4 * (J) < bb) != 0) {                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-          const int off = quad_bcast<4, (J)>(mc[t][i]);                                                        \
-          f32x2 w2 = f32x2{1.f, 1.f};                                                                          \
-          if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(mv[t][i]))); w2 = f32x2{w, w}; } \
-          _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                    \
-            const float4 hv = *reinterpret_cast<const float4*>(tbase + (CPL == 2 ? (off ^ (64 * j)) : off));   \
-            if (WEIGHTED) {                                                                                    \
-              acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[j][0]);                         \
-              acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[j][1]);                         \
-            } else {                                                                                           \
-              acc[j][0] += f32x2{hv.x, hv.y};                                                                  \
-              acc[j][1] += f32x2{hv.z, hv.w};                                                                  \
-            }                                                                                                  \
-          }                                                                                                    \
-        }                                                                                                      \
-      }
-      GCNX_TSTEP4(0)
-      GCNX_TSTEP4(1)
-      GCNX_TSTEP4(2)
-      GCNX_TSTEP4(3)
-#undef GCNX_TSTEP4
-      base += 16;
-      if (base >= bb) break;
-      // rows longer than 16 entries (rare in contact graphs): fetched on demand
-      fetch_entries<WEIGHTED, (CPL == 2 ? -128 : RB)>(colidx, vals, base, sub, bb, row0, pad, last4, mc[t], mv[t]);
-    }
-    if (KEEP && __builtin_amdgcn_ballot_w64(bb - a[t] > 16) != 0)   // a long row overwrote its first batch
-      fetch_entries<WEIGHTED, (CPL == 2 ? -128 : RB)>(colidx, vals, a[t], sub, bb, row0, pad, last4, mc[t], mv[t]);
-    if (r < ng) {
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        float4 o = make_float4(acc[j][0][0] + bv[j].x, acc[j][0][1] + bv[j].y, acc[j][1][0] + bv[j].z, acc[j][1][1] + bv[j].w);
-        if (act == GCNX_ACT_RELU) {
-          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(out + (int64_t)(row0 + r) * ldo + c0 + (sub + 4 * j) * 4) = o;
-      }
-    }
-  }
-}
-
-// Items of one tier: (graph of the tier's list) x (slab of FT*NPASS columns), each done in NPASS
-// steps of FT columns that share one index burst (tier 1: FT = 32; tier 2: FT = 16).
-// NI = wave iterations that cover the largest graph of the tier.
-template <int NI, int FT, int NPASS, bool WEIGHTED>
-__global__ __launch_bounds__(kPT, 4) void spmm_tile_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-    const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-    const int2* __restrict__ graphs /* (row0, ng), largest first */, int nslabs, int act, int nwork, int n,
-    int* __restrict__ queue) {
-  constexpr int ITEM_COLS = FT * NPASS;     // columns per work item
-  constexpr bool EARLY_RP = NPASS == 1 && NI <= 3;   // early row-pointer prefetch only where registers allow
-  constexpr int CPL = FT / 16;
-  constexpr int PAD = kTileFloats / FT;      // index of the all-zero row
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int* ctrl = reinterpret_cast<int*>(lds + kCtrlFloat);
-  const int tid = threadIdx.x;
-  if (tid == 0) { ctrl[0] = atomicAdd(queue, 1); ctrl[1] = atomicAdd(queue, 1); }
-  if (tid < 32) lds[kTileFloats + tid] = 0.f;                 // zero rows of both buffers
-  else if (tid < 64) lds[kBufFloats + kTileFloats + tid - 32] = 0.f;
-  __syncthreads();
-  int item = ctrl[0], nxt_item = ctrl[1];
-  if (item >= nwork) return;                                  // every workgroup reaches an exit: the queue is finite
-  const int last4 = rowptr[n] - 4;
-  const int sub = tid & 3;
-
-  int a[NI], b[NI], mc[NI][4];
-  float mv[NI][4];
-  int2 g = graphs[item / nslabs];
-  int c0 = (item % nslabs) * ITEM_COLS;
-  int pass = 0;
-  tile_load_rowptr<NI>(rowptr, g.x, g.y, a, b);
-  tile_load_entries<NI, WEIGHTED, (FT == 32 ? -128 : FT * 4)>(colidx, vals, g.x, PAD, last4, a, b, mc, mv);
-  tile_dma<FT / 4>(lds, h, ldh, g.x, g.y, c0);
-
-  for (int k = 0;; ++k) {
-    __syncthreads();   // tile k has landed (hipcc drains vmcnt before the barrier); reduction k-1 is over everywhere
-    // ---- step k+1: sibling columns of the same item, or the look-ahead item
-    const bool same = pass + 1 < NPASS;
-    if (!same && k >= NPASS) nxt_item = ctrl[((k / NPASS) - 1) & 1];   // popped by thread 0 one item ago
-    const int n_item = same ? item : nxt_item;
-    const bool n_valid = n_item < nwork;
-    int2 ng2 = g;
-    int nc0 = c0 + FT;
-    int popped = 0;
-    int a_n[NI], b_n[NI];
-    if (n_valid) {
-      if (!same) {
-        if (tid == 0) popped = atomicAdd(queue, 1);           // look-ahead pop; its latency hides behind the reduction
-        ng2 = graphs[n_item / nslabs];
-        nc0 = (n_item % nslabs) * ITEM_COLS;
-      }
-      tile_dma<FT / 4>(lds + ((k + 1) & 1) * kBufFloats, h, ldh, ng2.x, ng2.y, nc0);   // streams in during the reduction
-      if (!same && EARLY_RP) tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a_n, b_n);   // early: hides one round trip
-    }
-    // ---- reduce step k
-    float4 bv[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) bv[j] = *reinterpret_cast<const float4*>(bias + c0 + (sub + 4 * j) * 4);
-    }
-    tile_reduce<NI, CPL, WEIGHTED, (NPASS > 1)>(lds + (k & 1) * kBufFloats, colidx, vals, bv, out, ldo, g.x, g.y, c0, act,
-                                                PAD, last4, a, b, mc, mv);
-    if (!n_valid) break;
-    if (!same) {
-      // ---- rest of the index burst of the next item (the registers of this item are dead now)
-      if (tid == 0) ctrl[(k / NPASS) & 1] = popped;
-      if (EARLY_RP) {
-#pragma unroll
-        for (int t = 0; t < NI; ++t) { a[t] = a_n[t]; b[t] = b_n[t]; }
-      } else {
-        tile_load_rowptr<NI>(rowptr, ng2.x, ng2.y, a, b);     // register budget: no early prefetch in this tier
-      }
-      tile_load_entries<NI, WEIGHTED, (FT == 32 ? -128 : FT * 4)>(colidx, vals, ng2.x, PAD, last4, a, b, mc, mv);
-      item = n_item;
-      pass = 0;
-    } else {
-      ++pass;
-    }
-    g = ng2;
-    c0 = nc0;
-  }
-}
-
-
 // Tile DMA with a uniform 64-bit base (SGPR pair) and a 32-bit per-lane element offset: one register per piece
 // instead of a 64-bit pointer (hoisted 64-bit row addresses were spilled, and each reload put a vmcnt(0) in
 // front of its piece, serialising the tile stream).  Needs ng * ldh < 2^32.
@@ -481,11 +291,12 @@ __device__ __forceinline__ void tile_dma32(float* buf, const float* __restrict__
 // (graph, sg column slabs) one index burst -- row pointers and the first 16 entries of every row, kept in registers
 // and shared by the unit's slabs -- then per slab
 //     barrier | LDS-DMA of the tile -> LDS | barrier | reduce + store.
-// Nothing in a workgroup is consumed while its own DMA is in flight, so the in-order vmcnt problem of the
-// double-buffered queue kernel above does not arise (a row's entries past 16 are fetched on demand).
+// Nothing in a workgroup is consumed while its own DMA is in flight, so the in-order vmcnt problem of a
+// double-buffered design (the first version of this kernel) does not arise: a row's entries past 16 are simply
+// fetched on demand.
 // Units are dealt statically in snake order over the size-sorted graph list; workgroup ids are folded so that the
 // slabs of one graph (consecutive units) run on ONE XCD and share its L2 for the index arrays.
-// Measured on config 3 (same box): tier 1 0.53-0.57 ns/row against 0.71-0.73 for the queue kernel; copying the
+// Measured on config 3 (same box): tier 1 0.53-0.57 ns/row against 0.71-0.73 for that first version; copying the
 // tile in and zeros out (no index burst, no reduction) alone runs at 5.1 TB/s.  An L2 prefetch of the next tile
 // during the reduction (one dword per row piece) and a chunk-order swizzle against LDS bank conflicts were both
 // measured: -6 % and 0 %.
@@ -691,33 +502,6 @@ void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, 
   else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
 }
 
-template <int NI, int FT, int NPASS>
-int launch_tiles(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
-                 int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                 const int2* graphs, int ngraphs, int* queue) {
-  constexpr int lds_bytes = 2 * kBufFloats * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<NI, FT, NPASS, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<NI, FT, NPASS, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
-  }
-  const int nslabs = f / (FT * NPASS);
-  const long long nwork = (long long)ngraphs * nslabs;
-  if (nwork >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many (graph, slab) work items");
-  const int grid = (int)(nwork < ctx->num_cus ? nwork : ctx->num_cus);   // one persistent workgroup per CU
-  if (vals)
-    hipLaunchKernelGGL((spmm_tile_kernel<NI, FT, NPASS, true>), dim3(grid), dim3(kPT), lds_bytes, ctx->stream, rowptr, colidx,
-                       vals, h, ldh, bias, out, ldo, graphs, nslabs, act, (int)nwork, n, queue);
-  else
-    hipLaunchKernelGGL((spmm_tile_kernel<NI, FT, NPASS, false>), dim3(grid), dim3(kPT), lds_bytes, ctx->stream, rowptr, colidx,
-                       vals, h, ldh, bias, out, ldo, graphs, nslabs, act, (int)nwork, n, queue);
-  GCNX_LAUNCH_OK(ctx);
-  return GCNX_OK;
-}
-
 template <int THREADS, int FT, int LPR>
 int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
@@ -786,7 +570,6 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     std::vector<int2> t1, t2, ch;
     long long tile_rows = 0;
     int cap1 = kDuoCap32, cap2 = kSoloCap32;
-    if (const char* tv = getenv("GCNX_SPMM_TILE")) if (tv[0] == 'q') { cap1 = kCap32; cap2 = 2 * kCap32; }   // queue kernel's tiers
     for (int g = 0; g < nblocks; ++g) {
       const int r0 = bp[g], ng = bp[g + 1] - bp[g];
       if (ng < 0) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g);
@@ -861,33 +644,15 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  // GCNX_SPMM_TILE=q (read at plan creation too: the tiers differ): the older queue-driven kernel, one persistent
-  // 1024-thread workgroup per CU with two tile buffers; measured 0.78-0.82 ms on config 3 against 0.67-0.69 ms.
-  if (plan->cap1 == kCap32) {
-    int* queues = ctx->flag + 1;
-    GCNX_HIP(ctx, hipMemsetAsync(queues, 0, 2 * sizeof(int), ctx->stream));
-    // One column pass per work item: sharing an index burst between 2 or 4 passes (NPASS > 1) measured 3-10 % slower
-    // there (the items get longer and the work queue coarser), so only NPASS = 1 is instantiated.
-    if (plan->n1 > 0) {
-      int rc = launch_tiles<3, 32, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, queues);
-      if (rc) return rc;
-    }
-    if (plan->n2 > 0) {
-      int rc = launch_tiles<5, 16, 1>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                      plan->n2, queues + 1);
-      if (rc) return rc;
-    }
-  } else {
-    // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
-    if (plan->n1 > 0) {
-      int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1);
-      if (rc) return rc;
-    }
-    if (plan->n2 > 0) {
-      int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                       plan->n2);
-      if (rc) return rc;
-    }
+  // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
+  if (plan->n1 > 0) {
+    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1);
+    if (rc) return rc;
+  }
+  if (plan->n2 > 0) {
+    int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
+                                     plan->n2);
+    if (rc) return rc;
   }
   if (plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,

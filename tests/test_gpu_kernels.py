@@ -62,12 +62,10 @@ def test_spmm_long_rows_overflowing_the_lds_stage(ctx):
 
 
 @pytest.mark.parametrize("weighted", [False, True])
-@pytest.mark.parametrize("variant", ["", "q"])
-def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, variant, monkeypatch):
-    """The LDS-tile kernels on a batch that holds every scheduling class: graphs at and around the tier limits of
-    the default kernel (604 rows: two 512-thread workgroups per CU; 1236: one 1024-thread workgroup) and of the
-    queue kernel (GCNX_SPMM_TILE=q: 632 / 1264), taller ones (row chunks for the rows kernel), a single-node graph,
-    rows with > 16 entries (on-demand index fetch)."""
+def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
+    """The LDS-tile kernel on a batch that holds every scheduling class: graphs at and around the tier limits (604
+    rows: two 512-thread workgroups per CU; 1236: one 1024-thread workgroup), taller ones (row chunks for the rows
+    kernel), a single-node graph, rows with > 16 entries (on-demand index fetch)."""
     from gcnx import device as D, synth
     import scipy.sparse as sp
     rng = np.random.default_rng(11)
@@ -83,8 +81,6 @@ def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, variant, monkeypatch):
     gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     hb = synth.HostBatch(rng.standard_normal((n, 64), dtype=np.float32), a.indptr.astype(np.int32), a.indices.astype(np.int32),
                          None, gp, np.zeros((len(sizes), 2), np.float32))
-    if variant:
-        monkeypatch.setenv("GCNX_SPMM_TILE", variant)          # read when the plan is built, i.e. at the first spmm
     csr, vals = _csr(ctx, hb, weighted)
     bias = rng.standard_normal(64).astype(np.float32)
     ref = _ref_spmm(hb, vals, hb.x, bias, True)
