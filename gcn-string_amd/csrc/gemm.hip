@@ -94,8 +94,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ b, int64_t ldb,
                                                        float* __restrict__ c, int64_t ldc, int64_t M, int32_t Nc,
                                                        int64_t K, int64_t kchunk, Epilogue ep, int vec_a, int vec_b) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LD];
+  // Two LDS images per operand: the registers of K step t+1 are written to the other image while the MFMAs of
+  // step t still read this one -- one barrier per K step instead of two, and the (transposing, up to 4-way
+  // conflicting) LDS stores overlap other waves' MFMAs instead of standing between barriers.
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * BM;
@@ -112,22 +115,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   if (kbeg < kend) {
     fetch_tile<A_KCONTIG>(a, lda, m0, M, kbeg, kend, tid, vec_a, ra);
     fetch_tile<B_KCONTIG>(b, ldb, n0, Nc, kbeg, kend, tid, vec_b, rb);
+    store_tile<A_KCONTIG>(As[0], tid, ra);
+    store_tile<B_KCONTIG>(Bs[0], tid, rb);
+    if (kbeg + BK < kend) {
+      fetch_tile<A_KCONTIG>(a, lda, m0, M, kbeg + BK, kend, tid, vec_a, ra);
+      fetch_tile<B_KCONTIG>(b, ldb, n0, Nc, kbeg + BK, kend, tid, vec_b, rb);
+    }
   }
+  int cur = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<A_KCONTIG>(As, tid, ra);
-    store_tile<B_KCONTIG>(Bs, tid, rb);
-    __syncthreads();
-    if (k0 + BK < kend) {   // next tile's loads are in flight during this tile's MFMAs
-      fetch_tile<A_KCONTIG>(a, lda, m0, M, k0 + BK, kend, tid, vec_a, ra);
-      fetch_tile<B_KCONTIG>(b, ldb, n0, Nc, k0 + BK, kend, tid, vec_b, rb);
+    __syncthreads();        // image `cur` is complete; everybody has finished reading image cur^1 (step t-1)
+    if (k0 + BK < kend) {   // registers hold step t+1: into the other image, then fetch step t+2
+      store_tile<A_KCONTIG>(As[cur ^ 1], tid, ra);
+      store_tile<B_KCONTIG>(Bs[cur ^ 1], tid, rb);
+      if (k0 + 2 * BK < kend) {
+        fetch_tile<A_KCONTIG>(a, lda, m0, M, k0 + 2 * BK, kend, tid, vec_a, ra);
+        fetch_tile<B_KCONTIG>(b, ldb, n0, Nc, k0 + 2 * BK, kend, tid, vec_b, rb);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const float av = As[2 * kk + fk][wm * 32 + fr];
-      const float bv = Bs[2 * kk + fk][wn * 32 + fr];
+      const float av = As[cur][2 * kk + fk][wm * 32 + fr];
+      const float bv = Bs[cur][2 * kk + fk][wn * 32 + fr];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
-    __syncthreads();
+    cur ^= 1;
   }
 
   // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
