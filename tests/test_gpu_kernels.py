@@ -161,6 +161,49 @@ def test_bn_moments_equals_stats_finalize_pairs(ctx):
     assert rel_err(mm.numpy(), 0.99 * 0.5 + 0.01 * z64.mean(0)) < TIGHT
 
 
+def test_new_entry_points_zero_sizes_and_argument_errors(ctx):
+    """Edge cases of the entry points added for the fused head, side sections, BN moments and the device collate:
+    empty inputs are no-ops (or zero the outputs), bad arguments come back as GCNX_ERR_INVALID with a message."""
+    from gcnx import _lib
+    lib, h = ctx.lib, ctx.h
+    buf = ctx.zeros((4, 4)); la = ctx.to_device(np.array([5.0, 5.0], np.float32)); dw = ctx.to_device(np.ones((4, 2), np.float32))
+    # head: b == 0 -> loss_acc and dw zeroed, nothing else touched
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 0, 4, 2, 1.0, buf.ptr, la.ptr, dw.ptr, None, buf.ptr, 4) == 0
+    assert not la.numpy().any() and not dw.numpy().any()
+    # head: too many classes / gradients without labels
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 4, 4, 33, 1.0, buf.ptr, la.ptr, None, None, None, 0) == 1
+    assert "at most 32 classes" in _lib.last_error(h)
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, None, 4, 4, 2, 1.0, buf.ptr, la.ptr, dw.ptr, None, buf.ptr, 4) == 1
+    assert "gradients need labels" in _lib.last_error(h)
+    # BN moments need rows
+    assert lib.gcnx_bn_moments(h, buf.ptr, 4, 0, 4, 0.99, 1e-3, buf.ptr, buf.ptr, None, None) == 1
+    # collate: b == 0 is a no-op; values in without values out is refused
+    assert lib.gcnx_collate(h, None, 0, None, None, None, None, None, 0, 0, None, 0, None, None, None, None, 0, None, None) == 0
+    ib = ctx.zeros(8, np.int32)
+    assert lib.gcnx_collate(h, ib.ptr, 1, ib.ptr, ib.ptr, ib.ptr, buf.ptr, buf.ptr, 4, 4, None, 0, ib.ptr, ib.ptr, None, buf.ptr, 4,
+                            None, ib.ptr) == 1
+    assert "values in and out" in _lib.last_error(h)
+
+
+def test_device_collate_single_graph_and_repeated_selection(ctx):
+    """gcnx_collate with a one-graph batch, and with the same graph selected twice (sampling with replacement):
+    the copies are re-based independently."""
+    from gcnx import Graph, ListDataset, synth, DeviceDataset
+    from gcnx.device_loader import collate_on_device
+    raw = synth.tiny_graphs(5, 8, seed=2)
+    dds = DeviceDataset(ctx, ListDataset([Graph(x=x, a=a, y=y) for x, a, y in raw]), normalize="spektral")
+    one = collate_on_device(dds, [3])
+    n3 = raw[3][0].shape[0]
+    assert one.n == n3 and one.n_graphs == 1 and np.array_equal(one.x.numpy(), raw[3][0].astype(np.float32))
+    assert np.array_equal(one.seg.dev.numpy(), [0, n3])
+    two = collate_on_device(dds, [3, 3])
+    rp, ci = two.a.rowptr.numpy(), two.a.colidx.numpy()[:two.a.nnz]
+    assert two.n == 2 * n3 and np.array_equal(two.x.numpy()[:n3], two.x.numpy()[n3:])
+    e = rp[n3]
+    assert np.array_equal(rp[n3:] - e, rp[:n3 + 1]) and np.array_equal(ci[e:] - n3, ci[:e])
+    assert np.array_equal(two.a.vals.numpy()[:e], two.a.vals.numpy()[e:2 * e])
+
+
 def test_spmm_empty_rows_single_nodes_and_strided_views(ctx):
     from gcnx import device as D, synth
     from gcnx.device import DeviceCSR
