@@ -39,7 +39,8 @@ constexpr int kRowsPerChunk = 32;    // rows per workgroup (large inputs; plan c
 constexpr int kRowsPerChunkSmall = 8;   // small inputs: more, shorter workgroups (launch-latency regime)
 constexpr int kSlab = 32;             // widest column slab of the tile kernel
 constexpr int kStageCap = 2048;      // CSR entries staged in LDS per chunk (overflow -> global)
-constexpr int kLongRow = 256;        // rows with more entries are split over the workgroup's four waves
+constexpr int kLongRowSmall = 256;    // rows with more entries are split over the workgroup's four waves: 8-row chunks
+constexpr int kLongRowLarge = 32;     // (latency regime: a chunk below the limit skips the hub phase outright) / 32-row chunks
 
 __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
   a.x = fmaf(v, h.x, a.x); a.y = fmaf(v, h.y, a.y); a.z = fmaf(v, h.z, a.z); a.w = fmaf(v, h.w, a.w);
@@ -112,11 +113,14 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
       *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
     }
   };
+  constexpr int kLongRow = RPC <= 8 ? kLongRowSmall : kLongRowLarge;
+  bool saw_long = false;
   for (int r = r0 + wave; r < r1; r += 8) {
     const int rB = r + 4;                                          // second row of this trip (may be past the chunk)
     int aA = s_rp[r - r0] - e0, bA = s_rp[r - r0 + 1] - e0;        // chunk-relative entry ranges
     int aB = rB < r1 ? s_rp[rB - r0] - e0 : 0, bB = rB < r1 ? s_rp[rB - r0 + 1] - e0 : 0;
     const bool longA = bA - aA > kLongRow, longB = bB - aB > kLongRow;   // hubs: done by all four waves below
+    saw_long |= longA | longB;
     if (longA) bA = aA;
     if (longB) bB = aB;
     float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   // row alone set the kernel's duration (config 5: a 4096-entry row = 2 ms); here every wave of the workgroup takes
   // a quarter of its entries and the four partial sums are combined in wave order (deterministic).
   if (e1 - e0 <= kLongRow) return;               // no row of this chunk can be that long (uniform)
+  if (!__syncthreads_or(saw_long)) return;       // ... and none was (one barrier; the scan below costs more)
   for (int r = r0; r < r1; ++r) {                // uniform over the workgroup
     const int a = s_rp[r - r0] - e0, b = s_rp[r - r0 + 1] - e0;
     if (b - a <= kLongRow) continue;
