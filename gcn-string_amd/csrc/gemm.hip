@@ -142,10 +142,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     cur ^= 1;
   }
 
-  // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+  // Epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5): stored
+  // from the accumulators that is 16 four-byte stores per lane.  With 16-byte-aligned rows each wave instead passes
+  // its tile through LDS (the operand images are dead once every wave has left the K loop) and writes float4s:
+  // 4 store instructions of 8 full 128-byte row segments each; bias / activation / mask / accumulate on the float4.
+  float* cz = c + (gridDim.z > 1 ? (int64_t)blockIdx.z * M * ldc : 0);
+  const int64_t tr0 = m0 + wm * 32, tc0 = n0 + wn * 32;
+  if (ep.vec_c && tc0 + 31 < Nc) {               // uniform per wave; ragged right edge: the scalar path below
+    __syncthreads();
+    float(*st)[36] = reinterpret_cast<float(*)[36]>(wave < 2 ? &As[0][0][0] : &Bs[0][0][0]) + (wave & 1) * 32;
+    static_assert(2 * 32 * 36 <= 2 * BK * LD, "two waves' staging must fit in one operand's images");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[(r & 3) + 8 * (r >> 2) + 4 * fk][fr] = acc[r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int ec = (lane & 7) * 4, er = lane >> 3;   // this lane's 4 columns and its row within each group of 8
+    const int64_t gcol = tc0 + ec;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), alpha4 = bias4;
+    if (ep.bias) bias4 = make_float4(ep.bias[gcol], ep.bias[gcol + 1], ep.bias[gcol + 2], ep.bias[gcol + 3]);
+    if (ep.alpha) alpha4 = make_float4(ep.alpha[gcol], ep.alpha[gcol + 1], ep.alpha[gcol + 2], ep.alpha[gcol + 3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lr = q * 8 + er;
+      const int64_t row = tr0 + lr;
+      if (row >= M) continue;
+      float4 v = *reinterpret_cast<const float4*>(&st[lr][ec]);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (ep.act == GCNX_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      } else if (ep.act == GCNX_ACT_PRELU) {
+        v.x = v.x > 0.f ? v.x : alpha4.x * v.x; v.y = v.y > 0.f ? v.y : alpha4.y * v.y;
+        v.z = v.z > 0.f ? v.z : alpha4.z * v.z; v.w = v.w > 0.f ? v.w : alpha4.w * v.w;
+      }
+      if (ep.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(ep.mask + row * ep.ldmask + gcol);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      float* dst = cz + row * ldc + gcol;
+      if (ep.accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dst);
+        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dst) = v;
+    }
+    return;
+  }
   const int64_t col = n0 + wn * 32 + fr;
   if (col >= Nc) return;
-  float* cz = c + (gridDim.z > 1 ? (int64_t)blockIdx.z * M * ldc : 0);
   const float bias = (ep.bias ? ep.bias[col] : 0.f);
   const float alpha = (ep.alpha ? ep.alpha[col] : 0.f);
 #pragma unroll
@@ -568,6 +611,7 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   Epilogue ep{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0, 0};
   const int va = al16(x) && ldx % 4 == 0, vb = al16(dh) && lddh % 4 == 0;
   float* target = dw;
+  ep.vec_c = fo % 4 == 0 && (nsplit > 1 || al16(dw));   // partial slabs live in the 256-byte aligned workspace
   if (nsplit > 1) {
     int rc = gcnx_ws_reserve(ctx, (size_t)nsplit * fi * fo * sizeof(float));
     if (rc) return rc;
