@@ -275,8 +275,50 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   for (; i < n; i += stride) p[i] = p[i] - lr * g[i];
 }
 
+// db = colsum(dZ) for dZ[j] = scale_g * dPooled[g(j)] * [y[j] > 0] WITHOUT a materialised dZ (the companion of the
+// folded aggregation gcnx_spmm_csr_pool_bwd): sum_j dZ[j][c] = sum_g scale_g dPooled[g][c] * #{j in g : y[j][c] > 0}.
+// Block = (column tile of 64, graph, row slice): count, times the graph's dPooled row -> one partial row each.
+__global__ __launch_bounds__(256) void pool_mask_partial_kernel(const int32_t* __restrict__ gp, const float* __restrict__ y,
+                                                                int64_t ldy, const float* __restrict__ dp, int64_t lddp,
+                                                                float* __restrict__ part, int32_t f, int avg, int vec,
+                                                                int nsplit) {
+  __shared__ float4 s[16][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cl * 4;
+  const int valid = f - c;
+  const bool v4 = vec && valid >= 4;
+  const int g = blockIdx.y;
+  int lo = gp[g], hi = gp[g + 1];
+  const int rows = hi - lo;
+  if (nsplit > 1) {
+    const int per = (hi - lo + nsplit - 1) / nsplit;
+    lo = min(hi, lo + (int)blockIdx.z * per);
+    hi = min(hi, lo + per);
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) {
+#pragma unroll 4
+    for (int r = lo + rg; r < hi; r += 16) {
+      const float4 v = ld4(y + (int64_t)r * ldy + c, v4, valid);
+      acc.x += v.x > 0.f ? 1.f : 0.f; acc.y += v.y > 0.f ? 1.f : 0.f;
+      acc.z += v.z > 0.f ? 1.f : 0.f; acc.w += v.w > 0.f ? 1.f : 0.f;
+    }
+  }
+  s[rg][cl] = acc;
+  __syncthreads();
+  if (rg == 0 && valid > 0) {
+    float4 t = s[0][cl];
+    for (int q = 1; q < 16; ++q) { t.x += s[q][cl].x; t.y += s[q][cl].y; t.z += s[q][cl].z; t.w += s[q][cl].w; }
+    const float sc = (avg && rows > 0) ? 1.0f / (float)rows : 1.0f;
+    const float4 d = ld4(dp + (int64_t)g * lddp + c, false, valid);
+    t.x *= d.x * sc; t.y *= d.y * sc; t.z *= d.z * sc; t.w *= d.w * sc;
+    st4(part + ((int64_t)blockIdx.z * gridDim.y + g) * f + c, t, false, valid);
+  }
+}
+
 int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float* out, const float* y,
-                int64_t ldy, float* dz, int64_t lddz, int act, const float* alpha, float* out_alpha) {
+                int64_t ldy, float* dz, int64_t lddz, int act, const float* alpha, float* out_alpha,
+                size_t ws_off = 0) {   // ws_off: floats at the start of the workspace that belong to the caller
   const bool fuse = (dz != nullptr);
   auto al = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
   const int vec = al(x) && ldx % 4 == 0 && (!fuse || (al(y) && ldy % 4 == 0 && al(dz) && lddz % 4 == 0));
@@ -287,10 +329,10 @@ int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f
   float* part_a = nullptr;
   if (out || want_alpha) {
     if (nchunks > 1) {
-      int rc = gcnx_ws_reserve(ctx, need);
+      int rc = gcnx_ws_reserve(ctx, need + ws_off * sizeof(float));
       if (rc) return rc;
-      part = out ? (float*)ctx->ws : nullptr;
-      part_a = want_alpha ? (float*)ctx->ws + (size_t)nchunks * f : nullptr;
+      part = out ? (float*)ctx->ws + ws_off : nullptr;
+      part_a = want_alpha ? (float*)ctx->ws + ws_off + (size_t)nchunks * f : nullptr;
     } else {
       part = out;
       part_a = want_alpha ? out_alpha : nullptr;
@@ -409,6 +451,39 @@ int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* 
   GCNX_LAUNCH_OK(ctx);
   if (db) return gcnx_colsum(ctx, dx, lddx, n, f, db);
   return GCNX_OK;
+}
+
+int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, const float* dpooled, int64_t lddp,
+                         const float* y, int64_t ldy, int32_t f, int mode, float* db) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, b >= 0 && f >= 0, "gcnx_pool_bwd_colsum: negative size");
+  GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
+               "gcnx_pool_bwd_colsum: pool mode %d has no folded form (use gcnx_segment_pool_bwd + gcnx_act_bias_grad)", mode);
+  if (f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, db, "gcnx_pool_bwd_colsum: NULL pointer");
+  if (b == 0) {
+    GCNX_HIP(ctx, hipMemsetAsync(db, 0, (size_t)f * 4, ctx->stream));
+    return GCNX_OK;
+  }
+  GCNX_REQUIRE(ctx, graph_ptr && dpooled && y, "gcnx_pool_bwd_colsum: NULL pointer");
+  GCNX_REQUIRE(ctx, lddp >= f && ldy >= f, "gcnx_pool_bwd_colsum: leading dimension too small");
+  const int vec = (reinterpret_cast<uintptr_t>(y) & 15) == 0 && ldy % 4 == 0;
+  const int base_wgs = gcnx_cdiv(f, 64) * b;            // as gcnx_segment_pool: few graphs -> slice their rows
+  int nsplit = 1;
+  if (base_wgs < 2 * ctx->num_cus) {
+    nsplit = (2 * ctx->num_cus + base_wgs - 1) / base_wgs;
+    if (nsplit > 16) nsplit = 16;
+  }
+  const int64_t nrows = (int64_t)nsplit * b;            // partial rows [nsplit][b][f] at the start of the workspace
+  const size_t mine = (size_t)nrows * f;
+  const size_t stage2 = (size_t)gcnx_cdiv(nrows, kColsumRows) * f;
+  int rc = gcnx_ws_reserve(ctx, (mine + stage2) * sizeof(float));
+  if (rc) return rc;
+  float* part = (float*)ctx->ws;
+  hipLaunchKernelGGL(pool_mask_partial_kernel, dim3(gcnx_cdiv(f, 64), b, nsplit), dim3(256), 0, ctx->stream, graph_ptr,
+                     y, ldy, dpooled, lddp, part, f, mode == GCNX_POOL_AVG ? 1 : 0, vec, nsplit);
+  GCNX_LAUNCH_OK(ctx);
+  return colsum_impl(ctx, part, f, nrows, f, db, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, mine);
 }
 
 int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t b, int32_t c, float denom,

@@ -46,9 +46,23 @@ __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
   a.x = fmaf(v, h.x, a.x); a.y = fmaf(v, h.y, a.y); a.z = fmaf(v, h.z, a.z); a.w = fmaf(v, h.w, a.w);
   return a;
 }
+__device__ __forceinline__ float4 f4_step(float4 a) {   // [a > 0]
+  return make_float4(a.x > 0.f ? 1.f : 0.f, a.y > 0.f ? 1.f : 0.f, a.z > 0.f ? 1.f : 0.f, a.w > 0.f ? 1.f : 0.f);
+}
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-template <int LPR, bool WEIGHTED, int RPC>
+// Pool' + ReLU' folded into the backward aggregation (FOLD): with dZ[j] = dPooled[graph(j)] * [y[j] > 0] and a
+// block-diagonal operator, (A^T dZ)[i] = dPooled[graph(i)] * sum_j A^T[i,j] [y[j] > 0] -- the gather reads the saved
+// layer output y instead of a materialised dZ, and the row's dPooled vector multiplies the finished sum.
+struct FoldArgs {
+  const int32_t* gp;   // graph_ptr [b + 1]
+  const float* dp;     // dPooled [b, f]
+  int64_t lddp;
+  int32_t b;
+  int32_t avg;         // 1: GlobalAvgPool (row scale 1 / n_g)
+};
+
+template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false>
 __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   // 8 waves per SIMD = at most 64 VGPRs (latency regime)
    const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx,
@@ -56,8 +70,11 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
                                                         const float* __restrict__ h, int64_t ldh,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int64_t ldo, int32_t n, int32_t f, int32_t col0, int act,
-                                                        int nchunks, const int2* __restrict__ chunk_list) {
+                                                        int nchunks, const int2* __restrict__ chunk_list, FoldArgs fo) {
   constexpr int G = 64 / LPR;  // neighbour groups per wave
+  __shared__ int32_t s_g[FOLD ? RPC : 1];   // FOLD: graph of each row of the chunk, and its pool scale
+  __shared__ float s_sc[FOLD ? RPC : 1];
+  __shared__ float4 s_d[FOLD ? 2 : 1][FOLD ? LPR : 1];   // FOLD: dPooled rows of the first row's graph and the next
   __shared__ int32_t s_col[kStageCap];
   __shared__ float s_val[WEIGHTED ? kStageCap : 1];
   __shared__ int32_t s_rp[RPC + 1];
@@ -68,13 +85,51 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   int r1 = min(n, r0 + RPC);
   if (chunk_list) { r0 = chunk_list[chunk].x; r1 = chunk_list[chunk].y; }   // row ranges picked by a plan
   const int tid = threadIdx.x;
+  // FOLD, wave 3 (the wave with the least staging to do): the graph of the chunk's first row by a 64-ary search --
+  // one load level per factor 64 of b, where a binary search's log2 b dependent loads would outlast the staging --
+  // with its first probe issued here, next to the row-pointer loads, and its second level (the dPooled rows, the
+  // next graph boundary) next to the entry loads: the fold adds no load level in front of the barrier.
+  const bool fw = FOLD && tid >= 192;
+  const int fl = tid - 192;
+  int f_stride = FOLD ? (fo.b + 63) >> 6 : 0, f_probe = 0;
+  if (fw) f_probe = fl * f_stride < fo.b ? fo.gp[fl * f_stride] : INT_MAX;
   if (tid <= r1 - r0) s_rp[tid] = rowptr[r0 + tid];
   const int e0 = rowptr[r0];
   const int e1 = rowptr[r1];
+  int f_base = 0, f_nxt = 0;
+  float4 f_d0 = make_float4(0.f, 0.f, 0.f, 0.f), f_d1 = f_d0;
+  if (fw) {
+    int span = fo.b;                                  // gp[f_base] <= r0, answer in [f_base, f_base + span)
+    while (true) {
+      const int k = __popcll(__builtin_amdgcn_ballot_w64(f_probe <= r0)) - 1;   // gp is non-decreasing: a lane prefix
+      span = min(f_stride, span - k * f_stride);
+      f_base += k * f_stride;
+      if (span <= 1) break;
+      f_stride = (span + 63) >> 6;
+      f_probe = fl * f_stride < span ? fo.gp[f_base + fl * f_stride] : INT_MAX;
+    }
+    // A chunk rarely spans more than two graphs: their dPooled rows (this launch's columns) wait in LDS, so the
+    // epilogue's multiply costs an LDS read instead of a dependent trip to L2 at the end of every row.
+    if (fl < LPR && col0 + fl * 4 < f) {
+      f_d0 = *reinterpret_cast<const float4*>(fo.dp + (int64_t)f_base * fo.lddp + col0 + fl * 4);
+      if (f_base + 1 < fo.b) f_d1 = *reinterpret_cast<const float4*>(fo.dp + (int64_t)(f_base + 1) * fo.lddp + col0 + fl * 4);
+    }
+    f_nxt = fo.gp[f_base + 1];
+  }
   const int staged = min(e1 - e0, kStageCap);
   for (int i = tid; i < staged; i += 256) {
     s_col[i] = colidx[e0 + i];
     if (WEIGHTED) s_val[i] = vals[e0 + i];
+  }
+  if (fw) {
+    if (fl < LPR) { s_d[0][fl] = f_d0; s_d[1][fl] = f_d1; }
+    if (fl < r1 - r0) {
+      const int r = r0 + fl;
+      int gq = f_base;
+      while (f_nxt <= r) { ++gq; f_nxt = fo.gp[gq + 1]; }   // gp[b] = n > r: terminates inside the array
+      s_g[fl] = gq;
+      s_sc[fl] = fo.avg ? 1.0f / (float)(f_nxt - fo.gp[gq]) : 1.0f;
+    }
   }
   __syncthreads();
 
@@ -97,6 +152,16 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
       if (WEIGHTED) v = vals[e0 + e];
     }
   };
+  auto fold_row = [&](int r) {                 // FOLD: the row's (scaled) dPooled vector
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FOLD && col_ok && r < r1) {
+      const int gi = s_g[r - r0] - s_g[0];
+      d = gi < 2 ? s_d[gi][sub] : *reinterpret_cast<const float4*>(fo.dp + (int64_t)s_g[r - r0] * fo.lddp + c);
+      const float sc = s_sc[r - r0];
+      d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+    }
+    return d;
+  };
   auto finish = [&](float4 acc, int r) {
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -106,9 +171,14 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
       acc.w += __shfl_xor(acc.w, off);
     }
     if (g == 0 && col_ok && r < r1) {
-      acc = f4_add(acc, bv);
-      if (act == GCNX_ACT_RELU) {
-        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+      if (FOLD) {
+        const float4 d = fold_row(r);
+        acc.x *= d.x; acc.y *= d.y; acc.z *= d.z; acc.w *= d.w;
+      } else {
+        acc = f4_add(acc, bv);
+        if (act == GCNX_ACT_RELU) {
+          acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
       }
       *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
     }
@@ -139,6 +209,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+          if (FOLD) { hA[u] = f4_step(hA[u]); hB[u] = f4_step(hB[u]); }
           if (eA + u * G < bA) accA = WEIGHTED ? f4_fma(vA[u], hA[u], accA) : f4_add(accA, hA[u]);
           if (eB + u * G < bB) accB = WEIGHTED ? f4_fma(vB[u], hB[u], accB) : f4_add(accB, hB[u]);
         }
@@ -173,7 +244,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (e + u * G < wb) acc = WEIGHTED ? f4_fma(vv[u], hv[u], acc) : f4_add(acc, hv[u]);
+          if (e + u * G < wb) acc = WEIGHTED ? f4_fma(vv[u], FOLD ? f4_step(hv[u]) : hv[u], acc) : f4_add(acc, FOLD ? f4_step(hv[u]) : hv[u]);
       }
     }
 #pragma unroll
@@ -188,8 +259,13 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     __syncthreads();
     if (wave == 0 && g == 0 && col_ok) {
       float4 t = f4_add(f4_add(s_long[0][sub], s_long[1][sub]), f4_add(s_long[2][sub], s_long[3][sub]));
-      t = f4_add(t, bv);
-      if (act == GCNX_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      if (FOLD) {
+        const float4 d = fold_row(r);
+        t.x *= d.x; t.y *= d.y; t.z *= d.z; t.w *= d.w;
+      } else {
+        t = f4_add(t, bv);
+        if (act == GCNX_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      }
       *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = t;
     }
   }
@@ -474,16 +550,19 @@ __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restr
 template <int LPR>
 void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                 const int2* chunk_list = nullptr, int list_len = 0) {
+                 const int2* chunk_list = nullptr, int list_len = 0, const FoldArgs* fold = nullptr) {
+  const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
   const bool small = !chunk_list && n < 16 * 1024 * kRowsPerChunk / 4;   // < 128k rows
   const int nchunks = chunk_list ? list_len : gcnx_cdiv(n, small ? kRowsPerChunkSmall : kRowsPerChunk);
   const int span = LPR * 4;
   for (int col0 = 0; col0 < f; col0 += span) {
-#define GCNX_ROWS(W, R)                                                                                              \
-    hipLaunchKernelGGL((spmm_rows_kernel<LPR, W, R>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx, vals, h, \
-                       ldh, bias, out, ldo, n, f, col0, act, nchunks, chunk_list)
+#define GCNX_ROWS_F(W, R, F)                                                                                         \
+    hipLaunchKernelGGL((spmm_rows_kernel<LPR, W, R, F>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx, vals, \
+                       h, ldh, bias, out, ldo, n, f, col0, act, nchunks, chunk_list, fo)
+#define GCNX_ROWS(W, R) do { if (fold) GCNX_ROWS_F(W, R, true); else GCNX_ROWS_F(W, R, false); } while (0)
     if (small) { if (vals) GCNX_ROWS(true, kRowsPerChunkSmall); else GCNX_ROWS(false, kRowsPerChunkSmall); }
     else { if (vals) GCNX_ROWS(true, kRowsPerChunk); else GCNX_ROWS(false, kRowsPerChunk); }
+#undef GCNX_ROWS_F
 #undef GCNX_ROWS
   }
 }
@@ -492,7 +571,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                    int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                   const int2* chunk_list, int list_len) {
+                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr) {
   int lanes = f / 4;
   // Tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in floats
   // forces the lanes-per-row split of the rows kernel; results are identical.
@@ -500,11 +579,11 @@ void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, 
     const int slab = atoi(e);
     if (slab >= 16 && slab / 4 < lanes) lanes = slab / 4;
   }
-  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
-  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
-  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
-  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
-  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len);
+  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
+  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
+  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
+  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
+  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
 }
 
 template <int THREADS, int FT, int LPR>
@@ -664,6 +743,28 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
                   plan->nchunks);
     GCNX_LAUNCH_OK(ctx);
   }
+  return GCNX_OK;
+}
+
+int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                           const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
+                           int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0 && b >= 0, "gcnx_spmm_csr_pool_bwd: negative size");
+  GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
+               "gcnx_spmm_csr_pool_bwd: pool mode %d has no folded form (use gcnx_segment_pool_bwd + gcnx_spmm_csr)", mode);
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, b > 0, "gcnx_spmm_csr_pool_bwd: rows without graphs");
+  GCNX_REQUIRE(ctx, rowptr && colidx && y && graph_ptr && dpooled && out, "gcnx_spmm_csr_pool_bwd: NULL pointer");
+  GCNX_REQUIRE(ctx, ldy >= f && ldo >= f && lddp >= f, "gcnx_spmm_csr_pool_bwd: leading dimension smaller than f=%d", f);
+  GCNX_REQUIRE(ctx, y != out, "gcnx_spmm_csr_pool_bwd: in-place aggregation is not possible");
+  GCNX_REQUIRE(ctx, (f % 4 == 0) && (ldy % 4 == 0) && (ldo % 4 == 0) && (lddp % 4 == 0) && aligned16(y) && aligned16(out) &&
+                        aligned16(dpooled),
+               "gcnx_spmm_csr_pool_bwd: needs f and the leading dimensions in multiples of 4 floats and 16-byte aligned "
+               "operands (use gcnx_segment_pool_bwd + gcnx_spmm_csr otherwise)");
+  const FoldArgs fo{graph_ptr, dpooled, lddp, b, mode == GCNX_POOL_AVG ? 1 : 0};
+  dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo);
+  GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
 

@@ -382,6 +382,22 @@ def segment_pool_bwd(ctx, seg, dpooled, dx, mode="sum", argmax=None, y=None, db=
     return dx
 
 
+def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum"):
+    """out = A^T (pool'(dpooled) * [y > 0]) in one gather (gcnx_spmm_csr_pool_bwd); ``at`` is the transposed operator."""
+    n, f = y.shape
+    assert at.n == n and out.shape == (n, f) and dpooled.shape == (seg.n_graphs, f)
+    ctx._ck(ctx.lib.gcnx_spmm_csr_pool_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y), y.ld, seg.dev.ptr,
+                                           seg.n_graphs, _p(dpooled), dpooled.ld, _p(out), out.ld, n, f, L.POOLS[mode]))
+    return out
+
+
+def pool_bwd_colsum(ctx, seg, dpooled, y, db, mode="sum"):
+    """db = column sums of pool'(dpooled) * [y > 0] without materialising it (gcnx_pool_bwd_colsum)."""
+    ctx._ck(ctx.lib.gcnx_pool_bwd_colsum(ctx.h, seg.dev.ptr, seg.n_graphs, _p(dpooled), dpooled.ld, _p(y), y.ld,
+                                         y.shape[1], L.POOLS[mode], _p(db)))
+    return db
+
+
 def softmax_cce(ctx, logits, y, probs, loss_acc, dlogits=None, denom=None):
     b, c = logits.shape
     ctx._ck(ctx.lib.gcnx_softmax_cce(ctx.h, _p(logits), _p(y), b, c, float(denom if denom else b), _p(probs),

@@ -214,10 +214,20 @@ class GCN2(_GraphRunner):
         side = int(os.environ.get("GCNX_SIDE", "1"))   # tuning knob: 0 = serial, 1 = one section, 7 = three sections
         if side != 1:
             return self._backward_knob(batch, bufs, 0 if side == 0 else 7)
-        D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
-        D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                           # dH2 = A^T dZ2
+        # Batches without a tile plan (the latency regime): dZ2 = pool'(dPooled) * [Y2 > 0] is never materialised --
+        # the aggregation gathers the mask from Y2 and scales by the row's dPooled vector, db2 counts the mask.
+        fold = (at.plan is None and self.pool in ("sum", "avg") and self.hidden % 4 == 0
+                and os.environ.get("GCNX_FOLD", "1") != "0")
+        if fold:
+            D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool)   # dH2 = A^T dZ2
+        else:
+            D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
+            D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                       # dH2 = A^T dZ2
         with ctx.side():
-            D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])         # db2 = colsum(dZ2)
+            if fold:
+                D.pool_bwd_colsum(ctx, batch.seg, bufs["dpooled"], bufs["y2"], g["b2"], self.pool)   # db2 = colsum(dZ2)
+            else:
+                D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
         D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
         D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1

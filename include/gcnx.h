@@ -204,6 +204,22 @@ GCNX_API int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, cons
                           float* dx, int64_t lddx, int32_t n, int32_t b, int32_t f, int mode,
                           const int32_t* argmax, const float* y, int64_t ldy, float* db);
 
+/* The two calls above the last conv layer's backward aggregation as ONE gather (small batches: each launch there is
+ * latency): for SUM / AVG pooling and a block-diagonal operator,
+ *   (A^T dZ)[i] = scale_g * dPooled[g(i)] * sum_j A^T[i,j] * [y[j] > 0],   dZ[j] = scale_g * dPooled[g(j)] * [y[j] > 0]
+ * -- replaces gcnx_segment_pool_bwd(y=...) + gcnx_spmm_csr for the gradient of GlobalSumPool (gcn.py:319) through
+ * the ReLU of the last GCNConv (gcn.py:317) and its aggregation; tf.GradientTape materialises dZ there (gcn.py:337).
+ * (rowptr, colidx, vals) is the TRANSPOSED operator, as for the unfused backward call.  Needs f, ldy, ldo, lddp in
+ * multiples of 4 floats and 16-byte aligned y / out / dpooled; MAX pooling has no such form (GCNX_ERR_INVALID). */
+GCNX_API int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                           const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b,
+                           const float* dpooled, int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f,
+                           int mode);
+/* db[f] = column sums of the same never-materialised dZ (BiasAddGrad of that layer):
+ * sum_g scale_g * dPooled[g] * #{j in g : y[j] > 0}; deterministic (fixed summation order). */
+GCNX_API int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, const float* dpooled,
+                         int64_t lddp, const float* y, int64_t ldy, int32_t f, int mode, float* db);
+
 /* ---- Keras BatchNormalization + PReLU around Dense (MLP / GeneralConv of GeneralGNN, gcn.py:320;
  *      axis -1, momentum 0.99, eps 1e-3, biased batch variance) ------------------- */
 /* sums[0:f] = column sums of (z - shift), sums[f:2f] = column sums of (z - shift)^2 (device float[2f]);

@@ -376,6 +376,56 @@ def test_segment_pool_forward_backward(ctx, mode):
     assert rel_err(dx.numpy(), rm) < TIGHT and rel_err(db.numpy(), rm.sum(0)) < TIGHT
 
 
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+@pytest.mark.parametrize("shape", ["ecoli128", "ecoli16", "ecoli256", "hub64", "tiny"])
+def test_spmm_pool_bwd_fold_equals_pool_bwd_then_spmm(ctx, shape, mode):
+    """gcnx_spmm_csr_pool_bwd / gcnx_pool_bwd_colsum against the oracle's unfused chain: pool' -> ReLU mask ->
+    A^T (and the column sums of the masked gradient), non-symmetric values so that the transpose matters."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    o = O()
+    if shape == "hub64":
+        hb = synth.power_law_batch(n_graphs=2, graph_size=4096, f=64, seed=5)     # rows split over the workgroup
+    elif shape == "tiny":
+        hb = synth.ecoli_batch(1, 4, seed=2)
+    else:
+        hb = synth.ecoli_batch(5, int(shape[5:]), seed=11)
+    n, f, b = hb.n, hb.x.shape[1], len(hb.graph_ptr) - 1
+    rng = np.random.default_rng(7)
+    vals = (rng.random(len(hb.colidx)) + 0.25).astype(np.float32)
+    y = np.maximum(rng.standard_normal((n, f), dtype=np.float32), 0)              # a saved ReLU output (about half zeros)
+    dp = rng.standard_normal((b, f), dtype=np.float32)
+    dz = o.global_pool_bwd(dp.astype(np.float64), hb.graph_ptr, n, mode, None) * (y > 0)
+    ref = o.spmm_csr_T(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals.astype(np.float64), dz)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr, symmetric=False)
+    seg = Segments(ctx, hb.graph_ptr)
+    out = ctx.empty((n, f)); db = ctx.empty(f)
+    D.spmm_pool_bwd(ctx, a.transpose(), ctx.to_device(y), seg, ctx.to_device(dp), out, mode)
+    assert rel_err(out.numpy(), ref) < TIGHT
+    D.pool_bwd_colsum(ctx, seg, ctx.to_device(dp), ctx.to_device(y), db, mode)
+    assert rel_err(db.numpy(), dz.sum(0)) < TIGHT
+    # unweighted operator (GeneralConv aggregation)
+    au = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
+    D.spmm_pool_bwd(ctx, au.transpose(), ctx.to_device(y), seg, ctx.to_device(dp), out, mode)
+    assert rel_err(out.numpy(), o.spmm_csr_T(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None, dz)) < TIGHT
+
+
+def test_spmm_pool_bwd_fold_argument_errors(ctx):
+    from gcnx import device as D, synth
+    from gcnx.device import Segments
+    from gcnx._lib import GcnxError
+    hb = synth.ecoli_batch(2, 10, seed=1)
+    a, _ = _csr(ctx, hb, True)
+    seg = Segments(ctx, hb.graph_ptr)
+    y = ctx.to_device(hb.x); dp = ctx.zeros((2, 10)); out = ctx.empty((hb.n, 10)); db = ctx.empty(10)
+    with pytest.raises(GcnxError, match="multiples of 4"):
+        D.spmm_pool_bwd(ctx, a, y, seg, dp, out)                  # f = 10: the caller takes the unfused pair
+    with pytest.raises(GcnxError, match="no folded form"):
+        D.pool_bwd_colsum(ctx, seg, dp, y, db, "max")
+    D.pool_bwd_colsum(ctx, seg, dp, y, db)                        # scalar-width columns are fine for the column sums
+    assert np.array_equal(db.numpy(), np.zeros(10, np.float32))
+
+
 def test_softmax_cce_matches_keras_semantics(ctx):
     from gcnx import device as D
     o = O()

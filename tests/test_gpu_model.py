@@ -46,6 +46,23 @@ def test_gcn2_matches_golden_vectors(ctx, name):
     assert rel_err(m(batch, training=False), g["probs"]) < TOL
 
 
+@pytest.mark.parametrize("name", [n for n in GOLDEN if "f128" in n or "ecoli" in n][:2])
+def test_gcn2_folded_pool_backward_equals_the_unfused_chain(ctx, name, monkeypatch):
+    """Small batches fold pool' and the ReLU mask into the backward aggregation (gcnx_spmm_csr_pool_bwd); with
+    GCNX_FOLD=0 the materialised chain runs.  Both must meet the golden gradients and agree with each other."""
+    g = load_golden(name)
+    got = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("GCNX_FOLD", fold)
+        m, batch, hb = _model_from_golden(ctx, g)
+        m.loss_and_grads(batch, None)
+        got[fold] = m.gradients()
+        for k in ORDER:
+            assert rel_err(got[fold][k], g["g_" + k]) < TOL, (fold, k)
+    for k in ORDER:
+        assert rel_err(got["1"][k], got["0"][k]) < 2e-5, k
+
+
 @pytest.mark.parametrize("name", [n for n in GOLDEN if "tiny_weighted" in n or "f128" in n or "ecoli" in n])
 def test_gcn2_bf16x3_gemm_meets_the_fp32_bar(ctx, name):
     """Whole step with the bf16x3 MFMA GEMMs against the fp64 golden vectors at the same 1e-4."""
