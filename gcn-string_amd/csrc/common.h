@@ -38,6 +38,13 @@ extern thread_local std::string gcnx_tls_error;
 
 int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...);
 int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes);  // ensures ctx->ws has >= bytes
+// reduce.hip: the split global pool (sum / avg).  gcnx_pool_split = slices per graph worth launching (1: none);
+// gcnx_pool_partials writes the partial row sums [nsplit][b][f] (row stride f) to `part`.
+// wgs_per_cu: first-stage workgroups per CU to aim for (2 for the stand-alone pool; 1 when the head's single
+// workgroup per 32 graphs reads the partials -- its one CU's bandwidth, ~4 us per 128 KB, is what they cost).
+int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs_per_cu);
+int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t f,
+                       int mode, int nsplit, float* part);
 
 #define GCNX_CHECK_CTX(ctx) \
   do { if (!(ctx)) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "%s: ctx is NULL", __func__); } while (0)

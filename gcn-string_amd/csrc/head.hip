@@ -20,14 +20,26 @@ constexpr int kHeadRows = 32;     // graphs per workgroup
 constexpr int kHeadMaxC = 32;     // classes held in LDS per graph
 constexpr int kHeadLdsFloats = 14 * 1024;   // 56 KiB for the staged operands (else they are read from global)
 
-template <bool STAGED>
+// PARTS (with STAGED): the pooled operand arrives as the split pool's partial row sums and is combined here, in
+// slice order, while it is staged (what pool_combine_kernel would do in a launch of its own); the combined rows
+// are also written to `pooled_out`.
+struct PoolParts {
+  const float* part;        // [nsplit][b][h], row stride h
+  const int32_t* gp;        // graph_ptr (AVG: row counts)
+  float* pooled_out;        // [b, ldp]
+  int32_t nsplit;
+  int32_t avg;
+};
+
+template <bool STAGED, bool PARTS = false>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ pooled, int64_t ldp,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ y, int32_t b, int32_t h, int32_t c,
                                                    float denom, float* __restrict__ probs,
                                                    float* __restrict__ loss_acc, float* __restrict__ dw,
                                                    float* __restrict__ db, float* __restrict__ dpooled, int64_t lddp,
-                                                   float* __restrict__ slabs, int* __restrict__ ticket) {
+                                                   float* __restrict__ slabs, int* __restrict__ ticket, PoolParts pp) {
+  static_assert(STAGED || !PARTS, "partials are combined into the LDS copy");
   constexpr bool staged = STAGED;
   __shared__ float s_z[kHeadRows][kHeadMaxC + 1];   // logits, then dlogits
   __shared__ float s_y[kHeadRows * kHeadMaxC];      // labels of this workgroup's graphs, [rows][c] packed
@@ -45,8 +57,63 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
   float* s_w = s_dyn + kHeadRows * ps;
   if (y) for (int idx = tid; idx < rows * c; idx += 256) s_y[idx] = y[(int64_t)g0 * c + idx];
   if (staged) {
+    if (PARTS && (h & 3) == 0) {
+      // float4 lanes, four elements per thread and pass, the slice loop unrolled: all of a thread's loads (32 with
+      // 8 slices) are in flight together -- one memory latency for the whole combine at the E. coli shape
+      const int h4 = h >> 2, total = rows * h4;
+      const int64_t zs = (int64_t)b * h;
+      const bool st4 = (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(pp.pooled_out) & 15) == 0;
+      for (int e0 = 0; e0 < total; e0 += 1024) {
+        float4 acc[4];
+        int ii[4], jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = min(e0 + u * 256 + tid, total - 1);       // clamped: loads stay in range, stores are guarded
+          ii[u] = idx / h4;
+          jj[u] = (idx - ii[u] * h4) * 4;
+          acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll 8
+        for (int z = 0; z < pp.nsplit; ++z) {                       // slice order, as pool_combine_kernel
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(pp.part + z * zs + (int64_t)(g0 + ii[u]) * h + jj[u]);
+            acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (e0 + u * 256 + tid >= total) continue;
+          float4 v = acc[u];
+          if (pp.avg) {
+            const int cnt = pp.gp[g0 + ii[u] + 1] - pp.gp[g0 + ii[u]];
+            if (cnt > 0) { v.x /= (float)cnt; v.y /= (float)cnt; v.z /= (float)cnt; v.w /= (float)cnt; }
+          }
+          float* sp = s_p + ii[u] * ps + jj[u];
+          sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
+          float* po = pp.pooled_out + (int64_t)(g0 + ii[u]) * ldp + jj[u];
+          if (st4) *reinterpret_cast<float4*>(po) = v;
+          else { po[0] = v.x; po[1] = v.y; po[2] = v.z; po[3] = v.w; }
+        }
+      }
+    } else
     for (int i = tid >> 6; i < rows; i += 4)             // one wave per row: no integer division in the loops
-      for (int j = tid & 63; j < h; j += 64) s_p[i * ps + j] = pooled[(int64_t)(g0 + i) * ldp + j];
+      for (int j = tid & 63; j < h; j += 64) {
+        if (PARTS) {
+          const int64_t at = (int64_t)(g0 + i) * h + j, zs = (int64_t)b * h;
+          float v = 0.f;
+#pragma unroll 8
+          for (int z = 0; z < pp.nsplit; ++z) v += pp.part[z * zs + at];     // slice order, as pool_combine_kernel
+          if (pp.avg) {
+            const int cnt = pp.gp[g0 + i + 1] - pp.gp[g0 + i];
+            if (cnt > 0) v /= (float)cnt;
+          }
+          s_p[i * ps + j] = v;
+          pp.pooled_out[(int64_t)(g0 + i) * ldp + j] = v;
+        } else {
+          s_p[i * ps + j] = pooled[(int64_t)(g0 + i) * ldp + j];
+        }
+      }
     for (int idx = tid; idx < h * c; idx += 256) s_w[idx] = w[idx];
     __syncthreads();
   }
@@ -159,9 +226,46 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
 
 extern "C" {
 
+static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias, const float* y,
+                     int32_t b, int32_t h, int32_t c, float denom, float* probs, float* loss_acc, float* dw, float* db,
+                     float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
+                     float* pooled_out);
+
 int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias,
                            const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
                            float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp) {
+  return head_impl(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, nullptr, nullptr,
+                   0, 0, nullptr);
+}
+
+int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
+                                int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
+                                const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
+                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_pool_dense_softmax_cce: bad shape");
+  GCNX_REQUIRE(ctx, pool_mode >= GCNX_POOL_SUM && pool_mode <= GCNX_POOL_MAX, "gcnx_pool_dense_softmax_cce: unknown pool mode %d",
+               pool_mode);
+  GCNX_REQUIRE(ctx, b == 0 || h == 0 || (graph_ptr && x && pooled), "gcnx_pool_dense_softmax_cce: NULL pointer");
+  GCNX_REQUIRE(ctx, ldx >= h && ldp >= h, "gcnx_pool_dense_softmax_cce: leading dimension too small");
+  const size_t need = (size_t)kHeadRows * (h + 1) + (size_t)h * c;
+  const bool fused = b > 0 && h > 0 && c <= kHeadMaxC && need <= (size_t)kHeadLdsFloats &&
+                     gcnx_pool_split(ctx, b, h, pool_mode, 1) > 1;
+  if (!fused) {   // MAX pooling, many graphs (no split), operands too large for LDS: the two calls as they are
+    int rc = gcnx_segment_pool(ctx, graph_ptr, x, ldx, pooled, b, h, pool_mode, argmax);
+    if (rc) return rc;
+    return gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp);
+  }
+  return head_impl(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, graph_ptr, x, ldx,
+                   pool_mode, pooled);
+}
+
+}  // extern "C"
+
+static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias, const float* y,
+                     int32_t b, int32_t h, int32_t c, float denom, float* probs, float* loss_acc, float* dw, float* db,
+                     float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
+                     float* pooled_out) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_dense_softmax_cce: bad shape");
   GCNX_REQUIRE(ctx, c <= kHeadMaxC, "gcnx_dense_softmax_cce: at most %d classes (got %d); use gcnx_gemm + gcnx_softmax_cce",
@@ -177,22 +281,31 @@ int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, cons
   GCNX_REQUIRE(ctx, !y || (loss_acc && denom > 0.f), "gcnx_dense_softmax_cce: labels need loss_acc and a positive denom");
   GCNX_REQUIRE(ctx, !dw || (y && dpooled && lddp >= h), "gcnx_dense_softmax_cce: gradients need labels and dpooled");
   const int nblk = gcnx_cdiv(b, kHeadRows);
-  float* slabs = nullptr;
-  if (nblk > 1 && y) {
-    int rc = gcnx_ws_reserve(ctx, (size_t)nblk * ((size_t)h * c + c + 2) * sizeof(float));
+  const size_t slab_floats = (nblk > 1 && y) ? (((size_t)nblk * ((size_t)h * c + c + 2) + 3) & ~(size_t)3) : 0;   // partials 16-B aligned
+  const int nsplit = pooled_out ? gcnx_pool_split(ctx, b, h, pool_mode, 1) : 1;       // > 1 (checked by the caller)
+  const size_t part_floats = pooled_out ? (size_t)nsplit * b * h : 0;
+  if (slab_floats + part_floats) {
+    int rc = gcnx_ws_reserve(ctx, (slab_floats + part_floats) * sizeof(float));
     if (rc) return rc;
-    slabs = (float*)ctx->ws;
   }
+  float* slabs = slab_floats ? (float*)ctx->ws : nullptr;
   const size_t need = (size_t)kHeadRows * (h + 1) + (size_t)h * c;   // floats of the staged operands
   const int staged = need <= (size_t)kHeadLdsFloats;
-  if (staged)
-    hipLaunchKernelGGL(head_kernel<true>, dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w, bias, y,
-                       b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3);
-  else
-    hipLaunchKernelGGL(head_kernel<false>, dim3(nblk), dim3(256), 0, ctx->stream, pooled, ldp, w, bias, y, b, h, c, denom,
-                       probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3);
+  PoolParts pp{nullptr, nullptr, nullptr, 0, 0};
+  if (pooled_out) {
+    float* part = (float*)ctx->ws + slab_floats;
+    int rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, pool_mode, nsplit, part);
+    if (rc) return rc;
+    pp = PoolParts{part, graph_ptr, pooled_out, nsplit, pool_mode == GCNX_POOL_AVG ? 1 : 0};
+    hipLaunchKernelGGL((head_kernel<true, true>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w,
+                       bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
+  } else if (staged) {
+    hipLaunchKernelGGL((head_kernel<true, false>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w,
+                       bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
+  } else {
+    hipLaunchKernelGGL((head_kernel<false, false>), dim3(nblk), dim3(256), 0, ctx->stream, pooled, ldp, w, bias, y, b, h, c,
+                       denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
+  }
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
-
-}  // extern "C"

@@ -382,6 +382,19 @@ def segment_pool_bwd(ctx, seg, dpooled, dx, mode="sum", argmax=None, y=None, db=
     return dx
 
 
+def pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None,
+                           dpooled=None, mode="sum", argmax=None):
+    """segment_pool + dense_softmax_cce as one call (gcnx_pool_dense_softmax_cce): ``pooled`` is written as well."""
+    b, h = pooled.shape
+    c = w.shape[1]
+    assert x.shape[1] == h and seg.n_graphs == b
+    ctx._ck(ctx.lib.gcnx_pool_dense_softmax_cce(ctx.h, seg.dev.ptr, _p(x), x.ld, L.POOLS[mode], _p(argmax), _p(pooled),
+                                                pooled.ld, _p(w), _p(bias), _p(y), b, h, c,
+                                                float(denom if denom else max(b, 1)), _p(probs), _p(loss_acc), _p(dw),
+                                                _p(db), _p(dpooled), dpooled.ld if dpooled is not None else 0))
+    return probs
+
+
 def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum"):
     """out = A^T (pool'(dpooled) * [y > 0]) in one gather (gcnx_spmm_csr_pool_bwd); ``at`` is the transposed operator."""
     n, f = y.shape

@@ -194,15 +194,17 @@ class GCN2(_GraphRunner):
         D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
         D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
         D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
-        D.segment_pool(ctx, batch.seg, bufs["y2"], bufs["pooled"], self.pool, bufs["arg"])
-        # Dense(softmax) + CCE + accuracy + the head gradients: one launch (gcnx_dense_softmax_cce)
+        # Global pool, then Dense(softmax) + CCE + accuracy + the head gradients in one launch; with few graphs the
+        # head also combines the pool's row-slice partial sums (gcnx_pool_dense_softmax_cce)
+        head = dict(mode=self.pool, argmax=bufs["arg"])
         if with_loss == "grads":
-            D.dense_softmax_cce(ctx, bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"], self.loss_acc, denom,
-                                dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"])
+            D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
+                                     self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"], **head)
         elif with_loss:
-            D.dense_softmax_cce(ctx, bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"], self.loss_acc, denom)
+            D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
+                                     self.loss_acc, denom, **head)
         else:
-            D.dense_softmax_cce(ctx, bufs["pooled"], p["w3"], p["b3"], None, bufs["probs"])
+            D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], None, bufs["probs"], **head)
 
     def _backward(self, batch, bufs):
         ctx, p, g, prec = self.ctx, self.p, self.g, self.prec

@@ -180,6 +180,17 @@ GCNX_API int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t 
                            const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
                            float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp);
 
+/* GlobalSumPool / GlobalAvgPool / GlobalMaxPool (gcn.py:319) + the head above as one call: pooled[b,h] =
+ * gcnx_segment_pool(x[n,h]) is still written (the caller's saved activation), but where the pool is split into
+ * row slices (few graphs: SUM / AVG) the head combines the partial sums itself while staging its operand, so the
+ * pair runs as 2 launches instead of 3 (with half as many row slices: the head's workgroup reads them all).
+ * Otherwise exactly gcnx_segment_pool + gcnx_dense_softmax_cce.  Results equal those of the two calls up to the
+ * fp32 summation order of the pool; deterministic.  argmax: as gcnx_segment_pool (MAX only). */
+GCNX_API int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
+                                int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
+                                const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
+                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp);
+
 /* ---- backward (what tape.gradient, gcn.py:337, generates) -------------------------------- */
 /* dZ = dY * act'(Y) (mask taken from the saved output Y; PReLU uses the saved pre-activation
  * passed as y and alpha); db[f] = sum_rows dZ (BiasAddGrad).  dz may alias dy.  db/dalpha may

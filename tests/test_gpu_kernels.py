@@ -487,6 +487,45 @@ def test_dense_softmax_cce_head(ctx, b, h, c):
     assert np.array_equal(pr2.numpy(), probs.numpy())
 
 
+@pytest.mark.parametrize("b,h,c,mode", [(32, 128, 2, "sum"), (5, 16, 3, "avg"), (100, 64, 2, "sum"), (100, 64, 2, "avg"),
+                                        (700, 64, 2, "sum"), (6, 32, 2, "max"), (3, 600, 2, "sum")])
+def test_pool_dense_softmax_cce_equals_the_two_calls(ctx, b, h, c, mode):
+    """gcnx_pool_dense_softmax_cce: split pools (few graphs, sum/avg) are combined by the head itself; one or several
+    head workgroups (partials and dW slabs share the workspace), MAX / many graphs / wide operands take the two calls.
+    Every output must equal gcnx_segment_pool + gcnx_dense_softmax_cce up to the pool's fp32 summation order (the
+    fused form slices the rows differently), and two runs of the fused call must agree bit for bit."""
+    from gcnx import device as D
+    from gcnx.device import Segments
+    rng = np.random.default_rng(b + h)
+    sizes = rng.integers(1, 90, b); sizes[0] = 1
+    gp = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(gp[-1])
+    x = ctx.to_device(rng.standard_normal((n, h), dtype=np.float32))
+    w = ctx.to_device((rng.standard_normal((h, c)) / np.sqrt(h)).astype(np.float32))
+    bias = ctx.to_device(rng.standard_normal(c).astype(np.float32))
+    y = ctx.to_device(np.eye(c, dtype=np.float32)[rng.integers(0, c, b)])
+    seg = Segments(ctx, gp)
+    out = {}
+    for fused in (False, True, "again"):
+        pooled, probs, la = ctx.zeros((b, h)), ctx.empty((b, c)), ctx.zeros(2)
+        dw_, db_, dp = ctx.empty((h, c)), ctx.empty(c), ctx.empty((b, h))
+        arg = ctx.empty((b, h), np.int32) if mode == "max" else None
+        if fused:
+            D.pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, la, float(b), dw=dw_, db=db_, dpooled=dp,
+                                     mode=mode, argmax=arg)
+        else:
+            D.segment_pool(ctx, seg, x, pooled, mode, arg)
+            D.dense_softmax_cce(ctx, pooled, w, bias, y, probs, la, float(b), dw=dw_, db=db_, dpooled=dp)
+        out[fused] = [a.numpy() for a in (pooled, probs, la, dw_, db_, dp)]
+    for a0, a1, a2 in zip(out[False], out[True], out["again"]):
+        assert rel_err(a1, a0) < TIGHT and np.array_equal(a1, a2)
+    assert out[True][2][1] == out[False][2][1]                       # hit count
+    pr = ctx.empty((b, c)); pooled = ctx.zeros((b, h))
+    D.pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, None, pr, mode=mode,
+                             argmax=ctx.empty((b, h), np.int32) if mode == "max" else None)    # inference surface
+    assert np.array_equal(pr.numpy(), out[True][1]) and np.array_equal(pooled.numpy(), out[True][0])
+
+
 @pytest.mark.parametrize("act", [None, "relu", "prelu"])
 def test_act_bias_grad(ctx, act):
     from gcnx import device as D
