@@ -38,6 +38,11 @@ extern thread_local std::string gcnx_tls_error;
 
 int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...);
 int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes);  // ensures ctx->ws has >= bytes
+// reduce.hip: out[f] = column sums of the `rows` partial rows [rows][f] that a producer kernel left at the START of
+// the workspace (fixed order).  gcnx_colsum_partials_ws = bytes to reserve BEFORE the producer runs (partials plus
+// this reduction's own second-stage scratch behind them).
+size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f);
+int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out);
 // reduce.hip: the split global pool (sum / avg).  gcnx_pool_split = slices per graph worth launching (1: none);
 // gcnx_pool_partials writes the partial row sums [nsplit][b][f] (row stride f) to `part`.
 // wgs_per_cu: first-stage workgroups per CU to aim for (2 for the stand-alone pool; 1 when the head's single

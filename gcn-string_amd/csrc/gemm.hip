@@ -26,6 +26,8 @@ struct Epilogue {
   int act;
   int accumulate;       // C += result
   int vec_c;            // C (and mask) rows are 16-byte aligned: float4 epilogue stores
+  float* colpart = nullptr;   // f32 kernel, float4 epilogue only: column sums of each wave's 32 rows of what it
+                              // wrote -> colpart[(blockIdx.y * 2 + wm) * Nc + col] (BiasAddGrad partials)
 };
 
 // One 64x32 (or 32x64) operand tile, global -> registers (2 float4 per thread), then registers
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     __builtin_amdgcn_wave_barrier();
     const int ec = (lane & 7) * 4, er = lane >> 3;   // this lane's 4 columns and its row within each group of 8
     const int64_t gcol = tc0 + ec;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), alpha4 = bias4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), alpha4 = bias4, csum = bias4;
     if (ep.bias) bias4 = make_float4(ep.bias[gcol], ep.bias[gcol + 1], ep.bias[gcol + 2], ep.bias[gcol + 3]);
     if (ep.alpha) alpha4 = make_float4(ep.alpha[gcol], ep.alpha[gcol + 1], ep.alpha[gcol + 2], ep.alpha[gcol + 3]);
 #pragma unroll
@@ -184,6 +186,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
       }
       *reinterpret_cast<float4*>(dst) = v;
+      csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+    }
+    if (ep.colpart) {     // rows q*8 + er summed in-lane above (q ascending), then over er: fixed order, no atomics
+#pragma unroll
+      for (int off = 8; off < 64; off <<= 1) {
+        csum.x += __shfl_xor(csum.x, off); csum.y += __shfl_xor(csum.y, off);
+        csum.z += __shfl_xor(csum.z, off); csum.w += __shfl_xor(csum.w, off);
+      }
+      if (lane < 8) *reinterpret_cast<float4*>(ep.colpart + ((int64_t)blockIdx.y * 2 + wm) * Nc + gcol) = csum;
     }
     return;
   }
@@ -546,9 +557,20 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
   }
   dim3 grid(gcnx_cdiv(fi, BN), gcnx_cdiv(n, BM), 1);
   const int va = al16(dh) && lddh % 4 == 0, vb = al16(w) && fo % 4 == 0;
+  // db: every wave adds up the columns of the 32 rows it writes (float4 epilogue, all column tiles full) and a
+  // second launch sums those n/32 partial rows -- instead of a column-sum pass that reads dX back (2 launches over
+  // the whole matrix; at config 2 they were 17 us of the critical path, the partial reduce is 5).
+  const bool fused_db = db && ep.vec_c && fi % BN == 0;
+  const int64_t prow = 2LL * grid.y;
+  if (fused_db) {
+    int rc = gcnx_ws_reserve(ctx, (size_t)gcnx_colsum_partials_ws(prow, fi));
+    if (rc) return rc;
+    ep.colpart = (float*)ctx->ws;
+  }
   hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, ctx->stream, dh, lddh, w, (int64_t)fo, dx,
                      lddx, n, fi, (int64_t)fo, (int64_t)fo + BK, ep, va, vb);
   GCNX_LAUNCH_OK(ctx);
+  if (fused_db) return gcnx_colsum_partials(ctx, prow, fi, db);
   if (db) return gcnx_colsum(ctx, dx, lddx, n, fi, db);
   return GCNX_OK;
 }

@@ -392,6 +392,55 @@ int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, 
   return GCNX_OK;
 }
 
+constexpr int64_t kPartialsOneLaunch = 4096;   // partial rows one launch of the kernel below still walks quickly
+
+// Column sums of a few hundred partial rows in ONE launch.  colsum_kernel's shape (64 columns x 16 row groups per
+// workgroup) would leave this to f/64 workgroups walking rows/16 dependent trips each (config 2: 2 workgroups, 40
+// trips, 22 us); here a workgroup owns 8 columns (two float4 lanes) x 128 row groups -- f/8 workgroups, rows/128
+// trips -- and folds the 128 partial sums in a fixed tree through LDS.
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int64_t rows, int32_t f,
+                                                             float* __restrict__ out) {
+  __shared__ float4 s[128][2];
+  const int cl = threadIdx.x & 1, rg = threadIdx.x >> 1;
+  const int c = blockIdx.x * 8 + cl * 4;        // f % 4 == 0 (the caller's float4 epilogue wrote these rows)
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < f) {
+#pragma unroll 4
+    for (int64_t r = rg; r < rows; r += 128) {
+      const float4 v = *reinterpret_cast<const float4*>(part + r * f + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  s[rg][cl] = acc;
+  __syncthreads();
+  for (int off = 64; off > 0; off >>= 1) {
+    if (rg < off) {
+      const float4 o = s[rg + off][cl];
+      float4 m = s[rg][cl];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      s[rg][cl] = m;
+    }
+    __syncthreads();
+  }
+  if (rg == 0 && c < f) *reinterpret_cast<float4*>(out + c) = s[0][cl];
+}
+
+size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f) {
+  const size_t mine = (size_t)rows * f;
+  const size_t stage2 = (size_t)gcnx_cdiv(rows, kColsumRows) * f;
+  return (mine + stage2) * sizeof(float);
+}
+
+int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out) {
+  const float* part = (const float*)ctx->ws;
+  if (rows > kPartialsOneLaunch) return colsum_impl(ctx, part, f, rows, f, out, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (size_t)rows * f);
+  if (f % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0)
+    return colsum_impl(ctx, part, f, rows, f, out, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, (size_t)rows * f);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(gcnx_cdiv(f, 8)), dim3(256), 0, ctx->stream, part, rows, f, out);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
 int gcnx_colsum(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float* out) {
   return colsum_impl(ctx, x, ldx, n, f, out, nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
 }

@@ -287,7 +287,9 @@ def test_gemm_forward_parity(ctx, n, fi, fo):
 def test_gemm_backward_parity_and_fusions(ctx):
     from gcnx import device as D
     rng = np.random.default_rng(1)
-    for n, fi, fo in ((3000, 128, 128), (50000, 64, 96), (129, 10, 6)):
+    # db: (3000, 128) / (50000, 64) one-launch reduce of the epilogue's partial rows, (140001, 64) its two-stage form,
+    # (129, 10) the column-sum pass over dX (ragged width)
+    for n, fi, fo in ((3000, 128, 128), (50000, 64, 96), (129, 10, 6), (140001, 64, 32)):
         x = rng.standard_normal((n, fi), dtype=np.float32); dh = rng.standard_normal((n, fo), dtype=np.float32)
         w = rng.standard_normal((fi, fo), dtype=np.float32); ymask = rng.standard_normal((n, fi), dtype=np.float32)
         d_x, d_dh, d_w, d_m = (ctx.to_device(v) for v in (x, dh, w, ymask))
@@ -301,6 +303,9 @@ def test_gemm_backward_parity_and_fusions(ctx):
         D.gemm_dx(ctx, d_dh, d_w, dx, y_mask=d_m, db=db)                  # fused ReLU mask + BiasAddGrad
         refm = ref * (ymask > 0)
         assert rel_err(dx.numpy(), refm) < TIGHT and rel_err(db.numpy(), refm.sum(0)) < TIGHT
+        db2 = ctx.empty(fi)
+        D.gemm_dx(ctx, d_dh, d_w, dx, y_mask=d_m, db=db2)
+        assert np.array_equal(db.numpy(), db2.numpy())                     # fixed summation order
         base = rng.standard_normal((n, fi), dtype=np.float32)
         acc = ctx.to_device(base)
         D.gemm_dx(ctx, d_dh, d_w, acc, accumulate=True)                   # skip-connection gradient add
