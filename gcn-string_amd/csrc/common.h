@@ -38,6 +38,38 @@ extern thread_local std::string gcnx_tls_error;
 
 int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...);
 int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes);  // ensures ctx->ws has >= bytes
+#ifdef __HIPCC__
+// Column sums of a few hundred partial rows [rows][f] (f % 4 == 0): workgroup bx owns 8 columns (two float4 lanes)
+// x 128 row groups and folds the 128 partial sums in a fixed tree through LDS.  (colsum_kernel's 64 columns x 16 row
+// groups would leave config 2's 642 rows to 2 workgroups walking 40 dependent trips each: 22 us against 6.)
+// A device function so that it can share a launch with the split-K reduction (gemm.hip, gcnx_dense_bwd).
+__device__ __forceinline__ void gcnx_colpart_reduce_body(const float* __restrict__ part, int64_t rows, int32_t f,
+                                                         float* __restrict__ out, int bx, float4 (*s)[2]) {
+  const int cl = threadIdx.x & 1, rg = threadIdx.x >> 1;
+  const int c = bx * 8 + cl * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < f) {
+#pragma unroll 4
+    for (int64_t r = rg; r < rows; r += 128) {
+      const float4 v = *reinterpret_cast<const float4*>(part + r * f + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  s[rg][cl] = acc;
+  __syncthreads();
+  for (int off = 64; off > 0; off >>= 1) {
+    if (rg < off) {
+      const float4 o = s[rg + off][cl];
+      float4 m = s[rg][cl];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      s[rg][cl] = m;
+    }
+    __syncthreads();
+  }
+  if (rg == 0 && c < f) *reinterpret_cast<float4*>(out + c) = s[0][cl];
+}
+#endif
+
 // reduce.hip: out[f] = column sums of the `rows` partial rows [rows][f] that a producer kernel left at the START of
 // the workspace (fixed order).  gcnx_colsum_partials_ws = bytes to reserve BEFORE the producer runs (partials plus
 // this reduction's own second-stage scratch behind them).
@@ -48,8 +80,9 @@ int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out);
 // wgs_per_cu: first-stage workgroups per CU to aim for (2 for the stand-alone pool; 1 when the head's single
 // workgroup per 32 graphs reads the partials -- its one CU's bandwidth, ~4 us per 128 KB, is what they cost).
 int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs_per_cu);
+// cnt_part (may be NULL): per (slice, graph, column) the number of positive entries, same layout.
 int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t f,
-                       int mode, int nsplit, float* part);
+                       int mode, int nsplit, float* part, float* cnt_part);
 
 #define GCNX_CHECK_CTX(ctx) \
   do { if (!(ctx)) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "%s: ctx is NULL", __func__); } while (0)

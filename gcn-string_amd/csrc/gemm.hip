@@ -89,23 +89,21 @@ __device__ __forceinline__ void store_tile(float (*s)[LD], int tid, const float4
   }
 }
 
-// C[M,Nc] = op(A) op(B) over k in [kz*kchunk, min(K,(kz+1)*kchunk)); blockIdx.z = kz (split-K).
-// With split-K (gridDim.z > 1) the raw partial tile goes to c + kz*M*ldc (a [S][M][ldc] slab).
+// One 64x64 tile (bx, by) of C[M,Nc] = op(A) op(B) over k in [bz*kchunk, min(K,(bz+1)*kchunk)); bz = split-K slice
+// (of nz).  With split-K (nz > 1) the raw partial tile goes to c + bz*M*ldc (a [S][M][ldc] slab).
 template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, int64_t lda,
-                                                       const float* __restrict__ b, int64_t ldb,
-                                                       float* __restrict__ c, int64_t ldc, int64_t M, int32_t Nc,
-                                                       int64_t K, int64_t kchunk, Epilogue ep, int vec_a, int vec_b) {
-  // Two LDS images per operand: the registers of K step t+1 are written to the other image while the MFMAs of
-  // step t still read this one -- one barrier per K step instead of two, and the (transposing, up to 4-way
+__device__ __forceinline__ void gemm_f32_tile(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                              int64_t ldb, float* __restrict__ c, int64_t ldc, int64_t M, int32_t Nc,
+                                              int64_t K, int64_t kchunk, const Epilogue& ep, int vec_a, int vec_b,
+                                              int bx, int by, int bz, int nz, float (*As)[BK][LD], float (*Bs)[BK][LD]) {
+  // Two LDS images per operand (As[2], Bs[2]): the registers of K step t+1 are written to the other image while the
+  // MFMAs of step t still read this one -- one barrier per K step instead of two, and the (transposing, up to 4-way
   // conflicting) LDS stores overlap other waves' MFMAs instead of standing between barriers.
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int64_t n0 = (int64_t)blockIdx.x * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t m0 = (int64_t)by * BM;
+  const int64_t n0 = (int64_t)bx * BN;
+  const int64_t kbeg = (int64_t)bz * kchunk;
   const int64_t kend = min(K, kbeg + kchunk);
 
   f32x16 acc;
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   // from the accumulators that is 16 four-byte stores per lane.  With 16-byte-aligned rows each wave instead passes
   // its tile through LDS (the operand images are dead once every wave has left the K loop) and writes float4s:
   // 4 store instructions of 8 full 128-byte row segments each; bias / activation / mask / accumulate on the float4.
-  float* cz = c + (gridDim.z > 1 ? (int64_t)blockIdx.z * M * ldc : 0);
+  float* cz = c + (nz > 1 ? (int64_t)bz * M * ldc : 0);
   const int64_t tr0 = m0 + wm * 32, tc0 = n0 + wn * 32;
   if (ep.vec_c && tc0 + 31 < Nc) {               // uniform per wave; ragged right edge: the scalar path below
     __syncthreads();
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         csum.x += __shfl_xor(csum.x, off); csum.y += __shfl_xor(csum.y, off);
         csum.z += __shfl_xor(csum.z, off); csum.w += __shfl_xor(csum.w, off);
       }
-      if (lane < 8) *reinterpret_cast<float4*>(ep.colpart + ((int64_t)blockIdx.y * 2 + wm) * Nc + gcol) = csum;
+      if (lane < 8) *reinterpret_cast<float4*>(ep.colpart + ((int64_t)by * 2 + wm) * Nc + gcol) = csum;
     }
     return;
   }
@@ -216,14 +214,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+template <bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, int64_t lda,
+                                                       const float* __restrict__ b, int64_t ldb,
+                                                       float* __restrict__ c, int64_t ldc, int64_t M, int32_t Nc,
+                                                       int64_t K, int64_t kchunk, Epilogue ep, int vec_a, int vec_b) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  gemm_f32_tile<A_KCONTIG, B_KCONTIG>(a, lda, b, ldb, c, ldc, M, Nc, K, kchunk, ep, vec_a, vec_b, blockIdx.x, blockIdx.y,
+                                      blockIdx.z, gridDim.z, As, Bs);
+}
+
+// The backward of one Dense layer in ONE launch: workgroups [0, n_dx) are the tiles of dX = dH W^T (k-contiguous
+// operands, mask / column-sum epilogue), the rest the split-K tiles of dW = X^T dH.  Both products read dH; run as
+// two launches they either serialise (dW is a gradient leaf nobody downstream waits for) or need a second stream
+// whose fork/join costs more than dW itself on small batches.
+struct GemmJob {
+  const float* a; int64_t lda;
+  const float* b; int64_t ldb;
+  float* c; int64_t ldc;
+  int64_t M; int32_t Nc; int64_t K, kchunk;
+  Epilogue ep;
+  int vec_a, vec_b;
+  int gx, gy, gz;     // tile grid of this job
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_duo_kernel(GemmJob dx, GemmJob dw, int n_dx) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  int bid = blockIdx.x;                      // uniform per workgroup: the two branches below never mix in a wave
+  if (bid < n_dx) {
+    const int bx = bid % dx.gx, by = bid / dx.gx;
+    gemm_f32_tile<true, true>(dx.a, dx.lda, dx.b, dx.ldb, dx.c, dx.ldc, dx.M, dx.Nc, dx.K, dx.kchunk, dx.ep, dx.vec_a,
+                              dx.vec_b, bx, by, 0, 1, As, Bs);
+  } else {
+    bid -= n_dx;
+    const int bx = bid % dw.gx, t = bid / dw.gx;
+    gemm_f32_tile<false, false>(dw.a, dw.lda, dw.b, dw.ldb, dw.c, dw.ldc, dw.M, dw.Nc, dw.K, dw.kchunk, dw.ep, dw.vec_a,
+                                dw.vec_b, bx, t % dw.gy, t / dw.gy, dw.gz, As, Bs);
+  }
+}
+
 // Second stage of the deterministic split-K: out[i] = sum_s part[s][i].  Block = 64 outputs x 4
 // split groups; each group sums its splits in ascending order, the 4 group sums are combined in
 // a fixed order -- the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int64_t slab,
-                                                            int nsplit, float* __restrict__ out, int64_t total) {
-  __shared__ float s[4][64];
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ part, int64_t slab, int nsplit,
+                                                   float* __restrict__ out, int64_t total, int bx, float (*s)[64]) {
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + el;
+  const int64_t i = (int64_t)bx * 64 + el;
   float acc = 0.f;
   if (i < total) {
     const int per = (nsplit + 3) / 4;
@@ -234,6 +272,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   s[grp][el] = acc;
   __syncthreads();
   if (grp == 0 && i < total) out[i] = (s[0][el] + s[1][el]) + (s[2][el] + s[3][el]);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int64_t slab,
+                                                            int nsplit, float* __restrict__ out, int64_t total) {
+  __shared__ float s[4][64];
+  splitk_reduce_body(part, slab, nsplit, out, total, blockIdx.x, s);
+}
+
+// Both second stages of gcnx_dense_bwd in one launch: workgroups [0, n_c) fold the dX epilogue's partial column
+// sums into db, the rest the split-K slabs into dW.
+__global__ __launch_bounds__(256) void reduce_duo_kernel(const float* __restrict__ cpart, int64_t crows, int32_t cf,
+                                                         float* __restrict__ cout, int n_c,
+                                                         const float* __restrict__ part, int64_t slab, int nsplit,
+                                                         float* __restrict__ out, int64_t total) {
+  __shared__ float4 s4[128][2];
+  if ((int)blockIdx.x < n_c) gcnx_colpart_reduce_body(cpart, crows, cf, cout, blockIdx.x, s4);
+  else splitk_reduce_body(part, slab, nsplit, out, total, blockIdx.x - n_c, reinterpret_cast<float(*)[64]>(&s4[0][0]));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -572,6 +627,64 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
   GCNX_LAUNCH_OK(ctx);
   if (fused_db) return gcnx_colsum_partials(ctx, prow, fi, db);
   if (db) return gcnx_colsum(ctx, dx, lddx, n, fi, db);
+  return GCNX_OK;
+}
+
+int gcnx_dense_bwd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, const float* w, int64_t n,
+                   int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx, const float* y_mask, int64_t ldy,
+                   float* db_prev, float* dw) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_dense_bwd: negative size");
+  GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_dense_bwd: unknown precision %d", prec);
+  GCNX_REQUIRE(ctx, dx && dw, "gcnx_dense_bwd: dx and dw are both required (use gcnx_gemm_dx / gcnx_gemm_dw for one of them)");
+  const int64_t gy = gcnx_cdiv(n, BM);
+  const bool fused = prec == GCNX_PREC_F32 && n > 0 && fi > 0 && fo > 0 && x && dh && w && fi % BN == 0 && al16(dx) &&
+                     lddx % 4 == 0 && (!y_mask || (al16(y_mask) && ldy % 4 == 0)) && fo % 4 == 0 &&
+                     (!db_prev || (al16(db_prev) && 2 * gy <= 4096)) && gy * (fi / BN) < (1 << 30);
+  if (!fused) {   // bf16 paths, ragged widths, empty inputs: the two products as separate calls
+    int rc = gcnx_gemm_dx(ctx, dh, lddh, w, dx, lddx, n, fi, fo, prec, 0, y_mask, ldy, db_prev);
+    if (rc) return rc;
+    return gcnx_gemm_dw(ctx, x, ldx, dh, lddh, dw, n, fi, fo, prec);
+  }
+  GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo && lddx >= fi && (!y_mask || ldy >= fi), "gcnx_dense_bwd: leading dimension too small");
+  // dX tiles, then as many dW split-K slices as fill the rest of the resident-workgroup slots (4 per CU)
+  const int n_dx = (int)gy * (fi / BN);
+  const int tiles = gcnx_cdiv(fi, BM) * gcnx_cdiv(fo, BN);
+  const int slots = 4 * ctx->num_cus;
+  int spare = slots - n_dx % slots;
+  if (spare < slots / 4) spare += slots;
+  int nsplit = spare / tiles;
+  const int64_t ksteps = (n + BK - 1) / BK;
+  if (nsplit > ksteps) nsplit = (int)ksteps;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
+  nsplit = (int)((n + kchunk - 1) / kchunk);
+  // workspace: [dX column-sum partials (2 per row tile) | dW slabs]
+  const int64_t prow = db_prev ? 2 * gy : 0;
+  const size_t part_floats = ((size_t)prow * fi + 63) & ~(size_t)63;
+  const size_t slab_floats = nsplit > 1 ? (size_t)nsplit * fi * fo : 0;
+  if (part_floats + slab_floats) {
+    int rc = gcnx_ws_reserve(ctx, (part_floats + slab_floats) * sizeof(float));
+    if (rc) return rc;
+  }
+  float* colpart = db_prev ? (float*)ctx->ws : nullptr;
+  float* slabs = (float*)ctx->ws + part_floats;
+  GemmJob jx{dh, lddh, w, (int64_t)fo, dx, lddx, n, fi, (int64_t)fo, (int64_t)fo + BK,
+             Epilogue{nullptr, nullptr, y_mask, ldy, GCNX_ACT_NONE, 0, 1, colpart},
+             al16(dh) && lddh % 4 == 0, al16(w) && fo % 4 == 0, fi / BN, (int)gy, 1};
+  GemmJob jw{x, ldx, dh, lddh, nsplit > 1 ? slabs : dw, (int64_t)fo, (int64_t)fi, fo, n, kchunk,
+             Epilogue{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0, nsplit > 1 || al16(dw), nullptr},
+             al16(x) && ldx % 4 == 0, al16(dh) && lddh % 4 == 0, gcnx_cdiv(fo, BN), gcnx_cdiv(fi, BM), nsplit};
+  hipLaunchKernelGGL(gemm_f32_duo_kernel, dim3(n_dx + jw.gx * jw.gy * jw.gz), dim3(256), 0, ctx->stream, jx, jw, n_dx);
+  GCNX_LAUNCH_OK(ctx);
+  const int n_c = db_prev ? gcnx_cdiv(fi, 8) : 0;
+  const int64_t total = (int64_t)fi * fo;
+  const int n_s = nsplit > 1 ? gcnx_cdiv(total, 64) : 0;
+  if (n_c + n_s > 0) {
+    hipLaunchKernelGGL(reduce_duo_kernel, dim3(n_c + n_s), dim3(256), 0, ctx->stream, (const float*)colpart, prow, fi,
+                       db_prev, n_c, (const float*)slabs, total, nsplit, dw, total);
+    GCNX_LAUNCH_OK(ctx);
+  }
   return GCNX_OK;
 }
 

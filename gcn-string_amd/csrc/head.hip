@@ -29,6 +29,8 @@ struct PoolParts {
   float* pooled_out;        // [b, ldp]
   int32_t nsplit;
   int32_t avg;
+  const float* cnt_part;    // with db_relu: positives per (slice, graph, column), layout of part
+  float* db_relu;           // [h] or NULL: sum_g s_g * dPooled[g] * cnt[g]  (bias gradient of the ReLU layer under the pool)
 };
 
 template <bool STAGED, bool PARTS = false>
@@ -55,30 +57,44 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
   const int ps = h + 1;                           // padded row stride: column walks (dW) stay conflict-free
   float* s_p = s_dyn;
   float* s_w = s_dyn + kHeadRows * ps;
+  float* s_c = s_w + h * c;                       // PARTS with db_relu: positive counts [rows][h+1], then 4 x [h] partials
+  float* s_db = s_c + kHeadRows * ps;
+  __shared__ float s_sc[kHeadRows];               // AVG: 1 / rows of the graph
+  const bool want_db = PARTS && pp.db_relu != nullptr && dw != nullptr;
   if (y) for (int idx = tid; idx < rows * c; idx += 256) s_y[idx] = y[(int64_t)g0 * c + idx];
   if (staged) {
-    if (PARTS && (h & 3) == 0) {
-      // float4 lanes, four elements per thread and pass, the slice loop unrolled: all of a thread's loads (32 with
-      // 8 slices) are in flight together -- one memory latency for the whole combine at the E. coli shape
+    if (PARTS) {
+      // The split pool's partial row sums (and counts) are combined here, in slice order.  float4 lanes, four
+      // elements per thread and pass, the slice loop unrolled: a thread's loads are in flight together -- one
+      // memory latency for the whole combine at the E. coli shape.  (h % 4 == 0: checked by the host.)
+      if (tid < rows) {
+        const int cnt = pp.gp[g0 + tid + 1] - pp.gp[g0 + tid];
+        s_sc[tid] = (pp.avg && cnt > 0) ? 1.0f / (float)cnt : 1.0f;
+      }
       const int h4 = h >> 2, total = rows * h4;
       const int64_t zs = (int64_t)b * h;
       const bool st4 = (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(pp.pooled_out) & 15) == 0;
       for (int e0 = 0; e0 < total; e0 += 1024) {
-        float4 acc[4];
+        float4 acc[4], cacc[4];
         int ii[4], jj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int idx = min(e0 + u * 256 + tid, total - 1);       // clamped: loads stay in range, stores are guarded
           ii[u] = idx / h4;
           jj[u] = (idx - ii[u] * h4) * 4;
-          acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[u] = cacc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll 8
+#pragma unroll 4
         for (int z = 0; z < pp.nsplit; ++z) {                       // slice order, as pool_combine_kernel
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const float4 v = *reinterpret_cast<const float4*>(pp.part + z * zs + (int64_t)(g0 + ii[u]) * h + jj[u]);
+            const int64_t at = z * zs + (int64_t)(g0 + ii[u]) * h + jj[u];
+            const float4 v = *reinterpret_cast<const float4*>(pp.part + at);
             acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+            if (want_db) {
+              const float4 q = *reinterpret_cast<const float4*>(pp.cnt_part + at);
+              cacc[u].x += q.x; cacc[u].y += q.y; cacc[u].z += q.z; cacc[u].w += q.w;
+            }
           }
         }
 #pragma unroll
@@ -91,29 +107,19 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
           }
           float* sp = s_p + ii[u] * ps + jj[u];
           sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
+          if (want_db) {
+            float* sc = s_c + ii[u] * ps + jj[u];
+            sc[0] = cacc[u].x; sc[1] = cacc[u].y; sc[2] = cacc[u].z; sc[3] = cacc[u].w;
+          }
           float* po = pp.pooled_out + (int64_t)(g0 + ii[u]) * ldp + jj[u];
           if (st4) *reinterpret_cast<float4*>(po) = v;
           else { po[0] = v.x; po[1] = v.y; po[2] = v.z; po[3] = v.w; }
         }
       }
-    } else
-    for (int i = tid >> 6; i < rows; i += 4)             // one wave per row: no integer division in the loops
-      for (int j = tid & 63; j < h; j += 64) {
-        if (PARTS) {
-          const int64_t at = (int64_t)(g0 + i) * h + j, zs = (int64_t)b * h;
-          float v = 0.f;
-#pragma unroll 8
-          for (int z = 0; z < pp.nsplit; ++z) v += pp.part[z * zs + at];     // slice order, as pool_combine_kernel
-          if (pp.avg) {
-            const int cnt = pp.gp[g0 + i + 1] - pp.gp[g0 + i];
-            if (cnt > 0) v /= (float)cnt;
-          }
-          s_p[i * ps + j] = v;
-          pp.pooled_out[(int64_t)(g0 + i) * ldp + j] = v;
-        } else {
-          s_p[i * ps + j] = pooled[(int64_t)(g0 + i) * ldp + j];
-        }
-      }
+    } else {
+      for (int i = tid >> 6; i < rows; i += 4)             // one wave per row: no integer division in the loops
+        for (int j = tid & 63; j < h; j += 64) s_p[i * ps + j] = pooled[(int64_t)(g0 + i) * ldp + j];
+    }
     for (int idx = tid; idx < h * c; idx += 256) s_w[idx] = w[idx];
     __syncthreads();
   }
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
     __syncthreads();
   }
   const int nblk = gridDim.x;
-  const int npart = h * c + c + 2;                        // dW | db | loss sum, hits
+  const int npart = h * c + c + 2 + (want_db ? h : 0);    // dW | db | loss sum, hits | db_relu
   float* part = nblk > 1 ? slabs + (int64_t)blockIdx.x * npart : nullptr;
   if (tid == 0) {
     if (part) { part[h * c + c] = s_red[0][0]; part[h * c + c + 1] = s_red[1][0]; }
@@ -182,12 +188,16 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
     if (nblk == 1) return;
   } else {
     // dPooled[i, j] = sum_k dlogits[i,k] * w[j,k]
-    for (int i = tid >> 6; i < rows; i += 4)
-      for (int j = tid & 63; j < h; j += 64) {
+    for (int j = tid & 63; j < h; j += 64) {
+      float dbp = 0.f;                                    // db_relu: this wave's graphs (i = wave, wave + 4, ...)
+      for (int i = tid >> 6; i < rows; i += 4) {
         float acc = 0.f;
         for (int k = 0; k < c; ++k) acc = fmaf(s_z[i][k], W(j, k), acc);
         dpooled[(int64_t)(g0 + i) * lddp + j] = acc;
+        if (want_db) dbp = fmaf(acc * s_sc[i], s_c[i * ps + j], dbp);
       }
+      if (want_db) s_db[(tid >> 6) * h + j] = dbp;
+    }
     // dW[j, k] = sum_i pooled[i,j] * dlogits[i,k];  db[k] = sum_i dlogits[i,k]   (this workgroup's graphs)
     for (int idx = tid; idx < h * c; idx += 256) {
       const int j = idx / c, k = idx % c;
@@ -200,6 +210,13 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
       float acc = 0.f;
       for (int i = 0; i < rows; ++i) acc += s_z[i][tid];
       if (part) part[h * c + tid] = acc; else if (db) db[tid] = acc;
+    }
+    if (want_db) {                                        // the four waves' sums in wave order
+      __syncthreads();
+      for (int j = tid; j < h; j += 256) {
+        const float v = (s_db[j] + s_db[h + j]) + (s_db[2 * h + j] + s_db[3 * h + j]);
+        if (part) part[h * c + c + 2 + j] = v; else pp.db_relu[j] = v;
+      }
     }
     if (nblk == 1) return;
   }
@@ -217,7 +234,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
     if (idx < h * c) dw[idx] = acc;
     else if (idx < h * c + c) { if (db) db[idx - h * c] = acc; }
     else if (idx == h * c + c) loss_acc[0] = acc / denom;
-    else loss_acc[1] = acc;
+    else if (idx == h * c + c + 1) loss_acc[1] = acc;
+    else pp.db_relu[idx - (h * c + c + 2)] = acc;
   }
   if (tid == 0) *ticket = 0;                              // ready for the next launch (same stream: ordered)
 }
@@ -229,35 +247,43 @@ extern "C" {
 static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias, const float* y,
                      int32_t b, int32_t h, int32_t c, float denom, float* probs, float* loss_acc, float* dw, float* db,
                      float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
-                     float* pooled_out);
+                     float* pooled_out, float* db_relu);
+
+static size_t head_lds_floats(int32_t h, int32_t c, bool with_db_relu) {
+  return (size_t)kHeadRows * (h + 1) + (size_t)h * c + (with_db_relu ? (size_t)kHeadRows * (h + 1) + 4 * (size_t)h : 0);
+}
 
 int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias,
                            const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
                            float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp) {
   return head_impl(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, nullptr, nullptr,
-                   0, 0, nullptr);
+                   0, 0, nullptr, nullptr);
 }
 
 int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
                                 int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
                                 const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
-                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp) {
+                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp, float* db_relu) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_pool_dense_softmax_cce: bad shape");
   GCNX_REQUIRE(ctx, pool_mode >= GCNX_POOL_SUM && pool_mode <= GCNX_POOL_MAX, "gcnx_pool_dense_softmax_cce: unknown pool mode %d",
                pool_mode);
   GCNX_REQUIRE(ctx, b == 0 || h == 0 || (graph_ptr && x && pooled), "gcnx_pool_dense_softmax_cce: NULL pointer");
   GCNX_REQUIRE(ctx, ldx >= h && ldp >= h, "gcnx_pool_dense_softmax_cce: leading dimension too small");
-  const size_t need = (size_t)kHeadRows * (h + 1) + (size_t)h * c;
-  const bool fused = b > 0 && h > 0 && c <= kHeadMaxC && need <= (size_t)kHeadLdsFloats &&
-                     gcnx_pool_split(ctx, b, h, pool_mode, 1) > 1;
-  if (!fused) {   // MAX pooling, many graphs (no split), operands too large for LDS: the two calls as they are
+  GCNX_REQUIRE(ctx, !db_relu || (dw && pool_mode != GCNX_POOL_MAX),
+               "gcnx_pool_dense_softmax_cce: db_relu needs the gradient outputs and SUM / AVG pooling");
+  const bool fused = b > 0 && h > 0 && h % 4 == 0 && c <= kHeadMaxC &&
+                     head_lds_floats(h, c, db_relu != nullptr) <= (size_t)kHeadLdsFloats &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && gcnx_pool_split(ctx, b, h, pool_mode, 1) > 1;
+  if (!fused) {   // MAX pooling, many graphs (no split), operands too large for LDS: the separate calls as they are
     int rc = gcnx_segment_pool(ctx, graph_ptr, x, ldx, pooled, b, h, pool_mode, argmax);
     if (rc) return rc;
-    return gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp);
+    rc = gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp);
+    if (rc || !db_relu) return rc;
+    return gcnx_pool_bwd_colsum(ctx, graph_ptr, b, dpooled, lddp, x, ldx, h, pool_mode, db_relu);
   }
   return head_impl(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, graph_ptr, x, ldx,
-                   pool_mode, pooled);
+                   pool_mode, pooled, db_relu);
 }
 
 }  // extern "C"
@@ -265,7 +291,7 @@ int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const f
 static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias, const float* y,
                      int32_t b, int32_t h, int32_t c, float denom, float* probs, float* loss_acc, float* dw, float* db,
                      float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
-                     float* pooled_out) {
+                     float* pooled_out, float* db_relu) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_dense_softmax_cce: bad shape");
   GCNX_REQUIRE(ctx, c <= kHeadMaxC, "gcnx_dense_softmax_cce: at most %d classes (got %d); use gcnx_gemm + gcnx_softmax_cce",
@@ -281,22 +307,26 @@ static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const floa
   GCNX_REQUIRE(ctx, !y || (loss_acc && denom > 0.f), "gcnx_dense_softmax_cce: labels need loss_acc and a positive denom");
   GCNX_REQUIRE(ctx, !dw || (y && dpooled && lddp >= h), "gcnx_dense_softmax_cce: gradients need labels and dpooled");
   const int nblk = gcnx_cdiv(b, kHeadRows);
-  const size_t slab_floats = (nblk > 1 && y) ? (((size_t)nblk * ((size_t)h * c + c + 2) + 3) & ~(size_t)3) : 0;   // partials 16-B aligned
+  const bool want_db = pooled_out && db_relu && dw;
+  const size_t slab_floats =
+      (nblk > 1 && y) ? (((size_t)nblk * ((size_t)h * c + c + 2 + (want_db ? h : 0)) + 3) & ~(size_t)3) : 0;   // partials 16-B aligned
   const int nsplit = pooled_out ? gcnx_pool_split(ctx, b, h, pool_mode, 1) : 1;       // > 1 (checked by the caller)
-  const size_t part_floats = pooled_out ? (size_t)nsplit * b * h : 0;
+  const size_t one_part = pooled_out ? (size_t)nsplit * b * h : 0;
+  const size_t part_floats = one_part * (want_db ? 2 : 1);
   if (slab_floats + part_floats) {
     int rc = gcnx_ws_reserve(ctx, (slab_floats + part_floats) * sizeof(float));
     if (rc) return rc;
   }
   float* slabs = slab_floats ? (float*)ctx->ws : nullptr;
-  const size_t need = (size_t)kHeadRows * (h + 1) + (size_t)h * c;   // floats of the staged operands
+  const size_t need = head_lds_floats(h, c, want_db);   // floats of the staged operands
   const int staged = need <= (size_t)kHeadLdsFloats;
-  PoolParts pp{nullptr, nullptr, nullptr, 0, 0};
+  PoolParts pp{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
   if (pooled_out) {
     float* part = (float*)ctx->ws + slab_floats;
-    int rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, pool_mode, nsplit, part);
+    float* cnt_part = want_db ? part + one_part : nullptr;
+    int rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, pool_mode, nsplit, part, cnt_part);
     if (rc) return rc;
-    pp = PoolParts{part, graph_ptr, pooled_out, nsplit, pool_mode == GCNX_POOL_AVG ? 1 : 0};
+    pp = PoolParts{part, graph_ptr, pooled_out, nsplit, pool_mode == GCNX_POOL_AVG ? 1 : 0, cnt_part, want_db ? db_relu : nullptr};
     hipLaunchKernelGGL((head_kernel<true, true>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w,
                        bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
   } else if (staged) {

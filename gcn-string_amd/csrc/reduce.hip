@@ -82,9 +82,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // Pool forward: block = (column tile of 64, graph); 16 float4 column lanes x 16 row groups.
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict__ gp, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ pooled, int32_t f, int mode,
-                                                       int32_t* __restrict__ argmax, int vec, int nsplit) {
+                                                       int32_t* __restrict__ argmax, int vec, int nsplit,
+                                                       float* __restrict__ cnt) {
   // nsplit > 1 (sum/avg only): blockIdx.z owns a slice of the graph's rows and writes a partial
   // row sum to pooled + z*B*f (the caller's workspace); pool_combine_kernel adds them in order.
+  // cnt (sum/avg, may be NULL): the number of positive entries per (graph, column), same layout as pooled --
+  // what the bias gradient of a ReLU layer under the pool needs (gcnx_pool_dense_softmax_cce, db_relu).
   __shared__ float4 s[16][16];
   __shared__ int4 si[16][16];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
@@ -99,10 +102,12 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
     lo = min(hi, lo + (int)blockIdx.z * per);
     hi = min(hi, lo + per);
     pooled += (int64_t)blockIdx.z * gridDim.y * f;
+    if (cnt) cnt += (int64_t)blockIdx.z * gridDim.y * f;
   }
   const float init = (mode == GCNX_POOL_MAX) ? -INFINITY : 0.f;
   float4 acc = make_float4(init, init, init, init);
-  int4 arg = make_int4(lo, lo, lo, lo);
+  int4 arg = make_int4(lo, lo, lo, lo);                  // MAX: arg max rows; SUM / AVG: counts of positives
+  if (mode != GCNX_POOL_MAX) arg = make_int4(0, 0, 0, 0);
   if (valid > 0) {
 #pragma unroll 4
     for (int r = lo + rg; r < hi; r += 16) {
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
         if (v.w > acc.w) { acc.w = v.w; arg.w = r; }
       } else {
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        arg.x += v.x > 0.f; arg.y += v.y > 0.f; arg.z += v.z > 0.f; arg.w += v.w > 0.f;
       }
     }
   }
@@ -147,6 +153,10 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
       if (mode == GCNX_POOL_AVG && ghi > glo && nsplit <= 1) {
         const float inv = (float)(ghi - glo);
         o.x /= inv; o.y /= inv; o.z /= inv; o.w /= inv;
+      }
+      if (cnt) {
+        for (int q = 1; q < 16; ++q) { a.x += si[q][cl].x; a.y += si[q][cl].y; a.z += si[q][cl].z; a.w += si[q][cl].w; }
+        st4(cnt + (int64_t)g * f + c, make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w), false, valid);
       }
     }
     st4(pooled + (int64_t)g * f + c, o, false, valid);
@@ -383,11 +393,11 @@ int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs
 }
 
 int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t f,
-                       int mode, int nsplit, float* part) {
+                       int mode, int nsplit, float* part, float* cnt_part) {
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
   dim3 grid(gcnx_cdiv(f, 64), b, nsplit);
   hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, part, f, mode,
-                     (int32_t*)nullptr, vec, nsplit);
+                     (int32_t*)nullptr, vec, nsplit, cnt_part);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -401,28 +411,7 @@ constexpr int64_t kPartialsOneLaunch = 4096;   // partial rows one launch of the
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int64_t rows, int32_t f,
                                                              float* __restrict__ out) {
   __shared__ float4 s[128][2];
-  const int cl = threadIdx.x & 1, rg = threadIdx.x >> 1;
-  const int c = blockIdx.x * 8 + cl * 4;        // f % 4 == 0 (the caller's float4 epilogue wrote these rows)
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < f) {
-#pragma unroll 4
-    for (int64_t r = rg; r < rows; r += 128) {
-      const float4 v = *reinterpret_cast<const float4*>(part + r * f + c);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-  }
-  s[rg][cl] = acc;
-  __syncthreads();
-  for (int off = 64; off > 0; off >>= 1) {
-    if (rg < off) {
-      const float4 o = s[rg + off][cl];
-      float4 m = s[rg][cl];
-      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-      s[rg][cl] = m;
-    }
-    __syncthreads();
-  }
-  if (rg == 0 && c < f) *reinterpret_cast<float4*>(out + c) = s[0][cl];
+  gcnx_colpart_reduce_body(part, rows, f, out, blockIdx.x, s);
 }
 
 size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f) {
@@ -480,7 +469,7 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
   if (nsplit > 1) {
     int rc = gcnx_ws_reserve(ctx, (size_t)nsplit * b * f * sizeof(float));
     if (rc) return rc;
-    rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, f, mode, nsplit, (float*)ctx->ws);
+    rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, f, mode, nsplit, (float*)ctx->ws, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(pool_combine_kernel, dim3(gcnx_cdiv((int64_t)b * f, 256)), dim3(256), 0, ctx->stream,
                        (const float*)ctx->ws, graph_ptr, pooled, b, f, nsplit, mode);
@@ -488,7 +477,8 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
     return GCNX_OK;
   }
   dim3 grid(gcnx_cdiv(f, 64), b);
-  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec, 1);
+  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec, 1,
+                     (float*)nullptr);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

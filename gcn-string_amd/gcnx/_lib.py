@@ -66,10 +66,11 @@ SIGNATURES = {
     "gcnx_softmax_cce": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
     "gcnx_dense_softmax_cce": [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64],
     "gcnx_pool_dense_softmax_cce": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp,
-                                    _vp, _vp, _vp, _vp, _i64],
+                                    _vp, _vp, _vp, _vp, _i64, _vp],
     "gcnx_act_bias_grad": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp],
     "gcnx_gemm_dw": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int],
     "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],
+    "gcnx_dense_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp],
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
     "gcnx_spmm_csr_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int],
     "gcnx_pool_bwd_colsum": [_vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _int, _vp],

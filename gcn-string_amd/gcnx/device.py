@@ -383,15 +383,17 @@ def segment_pool_bwd(ctx, seg, dpooled, dx, mode="sum", argmax=None, y=None, db=
 
 
 def pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None,
-                           dpooled=None, mode="sum", argmax=None):
-    """segment_pool + dense_softmax_cce as one call (gcnx_pool_dense_softmax_cce): ``pooled`` is written as well."""
+                           dpooled=None, mode="sum", argmax=None, db_relu=None):
+    """segment_pool + dense_softmax_cce as one call (gcnx_pool_dense_softmax_cce): ``pooled`` is written as well;
+    ``db_relu`` = column sums of pool'(dpooled) * [x > 0] (the bias gradient of the ReLU layer that produced x)."""
     b, h = pooled.shape
     c = w.shape[1]
     assert x.shape[1] == h and seg.n_graphs == b
     ctx._ck(ctx.lib.gcnx_pool_dense_softmax_cce(ctx.h, seg.dev.ptr, _p(x), x.ld, L.POOLS[mode], _p(argmax), _p(pooled),
                                                 pooled.ld, _p(w), _p(bias), _p(y), b, h, c,
                                                 float(denom if denom else max(b, 1)), _p(probs), _p(loss_acc), _p(dw),
-                                                _p(db), _p(dpooled), dpooled.ld if dpooled is not None else 0))
+                                                _p(db), _p(dpooled), dpooled.ld if dpooled is not None else 0,
+                                                _p(db_relu)))
     return probs
 
 
@@ -449,6 +451,17 @@ def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
     assert w.shape[1] == fo and dx.shape == (n, fi)
     ctx._ck(ctx.lib.gcnx_gemm_dx(ctx.h, _p(dh), dh.ld, _p(w), _p(dx), dx.ld, n, fi, fo, L.PRECS[prec],
                                  1 if accumulate else 0, _p(y_mask), y_mask.ld if y_mask is not None else 0, _p(db)))
+    return dx
+
+
+def dense_bwd(ctx, x, dh, w, dx, dw, prec="f32", y_mask=None, db_prev=None):
+    """Backward of H = X W given dH in one call (gcnx_dense_bwd): dw = X^T dH, dx = dH W^T (* [y_mask > 0]),
+    db_prev = column sums of dx."""
+    n, fo = dh.shape
+    fi = w.shape[0]
+    assert w.shape[1] == fo and dx.shape == (n, fi) and x.shape == (n, fi) and dw.shape == (fi, fo) and w.contiguous
+    ctx._ck(ctx.lib.gcnx_dense_bwd(ctx.h, _p(x), x.ld, _p(dh), dh.ld, _p(w), n, fi, fo, L.PRECS[prec], _p(dx), dx.ld,
+                                   _p(y_mask), y_mask.ld if y_mask is not None else 0, _p(db_prev), _p(dw)))
     return dx
 
 

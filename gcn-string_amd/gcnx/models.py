@@ -198,8 +198,10 @@ class GCN2(_GraphRunner):
         # head also combines the pool's row-slice partial sums (gcnx_pool_dense_softmax_cce)
         head = dict(mode=self.pool, argmax=bufs["arg"])
         if with_loss == "grads":
+            # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
-                                     self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"], **head)
+                                     self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"],
+                                     db_relu=self.g["b2"] if self._fold(batch) else None, **head)
         elif with_loss:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, **head)
@@ -218,23 +220,34 @@ class GCN2(_GraphRunner):
             return self._backward_knob(batch, bufs, 0 if side == 0 else 7)
         # Batches without a tile plan (the latency regime): dZ2 = pool'(dPooled) * [Y2 > 0] is never materialised --
         # the aggregation gathers the mask from Y2 and scales by the row's dPooled vector, db2 counts the mask.
-        fold = (at.plan is None and self.pool in ("sum", "avg") and self.hidden % 4 == 0
-                and os.environ.get("GCNX_FOLD", "1") != "0")
+        fold = self._fold(batch)
         if fold:
             D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool)   # dH2 = A^T dZ2
         else:
             D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
             D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                       # dH2 = A^T dZ2
+        if fold and os.environ.get("GCNX_DUO", "1") != "0":
+            # db2 came out of the head, and dW2 shares dX's launch (gcnx_dense_bwd): one stream, no fork / join --
+            # the second stream's signalling cost 25 us of a 194 us step
+            D.dense_bwd(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], prec=prec, y_mask=bufs["y1"],
+                        db_prev=g["b1"])                                       # dW2, dZ1, db1
+            D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                     # dH1 = A^T dZ1
+            D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)            # dW1 = X^T dH1
+            return
         with ctx.side():
-            if fold:
-                D.pool_bwd_colsum(ctx, batch.seg, bufs["dpooled"], bufs["y2"], g["b2"], self.pool)   # db2 = colsum(dZ2)
-            else:
+            if not fold:                                                       # (folded: db2 came out of the head)
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
         D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
         D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1
         D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)                # dW1 = X^T dH1
         ctx.join()
+
+    def _fold(self, batch):
+        """Batches without a tile plan (the latency regime) and SUM / AVG pooling: pool' and the ReLU mask fold into
+        the backward aggregation and db2 into the head."""
+        return (batch.a.plan is None and self.pool in ("sum", "avg") and self.hidden % 4 == 0
+                and os.environ.get("GCNX_FOLD", "1") != "0" and int(os.environ.get("GCNX_SIDE", "1")) == 1)
 
     def _backward_knob(self, batch, bufs, side):
         """The same backward with individual side sections switched off (GCNX_SIDE bits; measurement only)."""

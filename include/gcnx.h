@@ -185,11 +185,16 @@ GCNX_API int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t 
  * row slices (few graphs: SUM / AVG) the head combines the partial sums itself while staging its operand, so the
  * pair runs as 2 launches instead of 3 (with half as many row slices: the head's workgroup reads them all).
  * Otherwise exactly gcnx_segment_pool + gcnx_dense_softmax_cce.  Results equal those of the two calls up to the
- * fp32 summation order of the pool; deterministic.  argmax: as gcnx_segment_pool (MAX only). */
+ * fp32 summation order of the pool; deterministic.  argmax: as gcnx_segment_pool (MAX only).
+ * db_relu (may be NULL; needs dw and SUM / AVG): float[h] = what gcnx_pool_bwd_colsum(dpooled, y = x) returns, the
+ * bias gradient of the layer that produced x through a ReLU (GCNConv, gcn.py:317) -- on the combined path the pool
+ * counts the positive entries per (graph, column) in the pass it makes anyway and the head finishes
+ * sum_g s_g * dPooled[g] * count[g], so that gradient costs no launch of its own. */
 GCNX_API int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
                                 int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
                                 const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
-                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp);
+                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp,
+                                float* db_relu);
 
 /* ---- backward (what tape.gradient, gcn.py:337, generates) -------------------------------- */
 /* dZ = dY * act'(Y) (mask taken from the saved output Y; PReLU uses the saved pre-activation
@@ -208,6 +213,16 @@ GCNX_API int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const floa
 GCNX_API int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx,
                  int64_t lddx, int64_t n, int32_t fi, int32_t fo, int prec, int accumulate,
                  const float* y_mask, int64_t ldy, float* db);
+/* The backward of one Dense / GCNConv kernel product H = X W given dH, as one call:
+ *   dW[fi,fo] = X^T dH   (gcnx_gemm_dw)   and   dX[n,fi] = dH W^T (* [y_mask > 0]), db_prev = colsum(dX)   (gcnx_gemm_dx)
+ * -- the two matmul gradients tape.gradient (gcn.py:337) emits for every `x @ kernel` (Spektral GCNConv.call).
+ * Both read dH; fp32 with 64-column-aligned fi runs them as ONE launch (the dX tiles, and the dW split-K tiles in
+ * the otherwise idle workgroup slots) plus ONE reduction launch (db_prev partials and dW slabs together): dW is a
+ * gradient leaf, so on small batches it disappears behind dX instead of costing a launch pair or a second stream.
+ * Other precisions / shapes: exactly the two calls.  Deterministic; y_mask / db_prev may be NULL. */
+GCNX_API int gcnx_dense_bwd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, const float* w,
+                   int64_t n, int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx, const float* y_mask,
+                   int64_t ldy, float* db_prev, float* dw);
 /* Gradient of the global pool: SUM dX[r] = dP[g(r)]; AVG /n_g; MAX routed to argmax rows.
  * If y (saved ReLU output of the last conv layer) is given its mask is fused:
  * dX[r] *= (y[r] > 0).  db (may be NULL): column sums of dX (BiasAddGrad of that layer). */

@@ -319,6 +319,35 @@ def test_gemm_backward_parity_and_fusions(ctx):
     assert np.array_equal(a1.numpy(), a2.numpy())
 
 
+@pytest.mark.parametrize("n,fi,fo,prec", [(20498, 128, 128, "f32"), (3000, 64, 96, "f32"), (70, 128, 4, "f32"),
+                                          (129, 10, 6, "f32"), (1000, 128, 128, "bf16x3")])
+def test_dense_bwd_equals_gemm_dx_plus_gemm_dw(ctx, n, fi, fo, prec):
+    """gcnx_dense_bwd (dX tiles + dW split-K tiles in one launch, both reductions in a second) against the oracle
+    products and against the separate calls; ragged / bf16 shapes take the two calls inside."""
+    from gcnx import device as D
+    rng = np.random.default_rng(n + fo)
+    x = rng.standard_normal((n, fi), dtype=np.float32); dh = rng.standard_normal((n, fo), dtype=np.float32)
+    w = rng.standard_normal((fi, fo), dtype=np.float32)
+    d_x, d_dh, d_w = ctx.to_device(x), ctx.to_device(dh), ctx.to_device(w)
+    tol = TIGHT if prec == "f32" else TOL
+    for masked in (True, False):
+        dx, dw, db = ctx.empty((n, fi)), ctx.empty((fi, fo)), ctx.empty(fi)
+        D.dense_bwd(ctx, d_x, d_dh, d_w, dx, dw, prec=prec, y_mask=d_x if masked else None, db_prev=db if masked else None)
+        rdx = dh.astype(np.float64) @ w.astype(np.float64).T * ((x > 0) if masked else 1.0)
+        assert rel_err(dx.numpy(), rdx) < tol
+        assert rel_err(dw.numpy(), x.astype(np.float64).T @ dh.astype(np.float64)) < tol
+        if masked:
+            assert rel_err(db.numpy(), rdx.sum(0)) < tol
+        dx2, dw2, db2 = ctx.empty((n, fi)), ctx.empty((fi, fo)), ctx.empty(fi)
+        D.gemm_dx(ctx, d_dh, d_w, dx2, prec=prec, y_mask=d_x if masked else None, db=db2 if masked else None)
+        D.gemm_dw(ctx, d_x, d_dh, dw2, prec=prec)
+        assert np.array_equal(dx.numpy(), dx2.numpy())                 # same tile arithmetic
+        assert rel_err(dw.numpy(), dw2.numpy()) < TIGHT               # (split-K slices differ: summation order)
+        dx3, dw3, db3 = ctx.empty((n, fi)), ctx.empty((fi, fo)), ctx.empty(fi)
+        D.dense_bwd(ctx, d_x, d_dh, d_w, dx3, dw3, prec=prec, y_mask=d_x if masked else None, db_prev=db3 if masked else None)
+        assert np.array_equal(dw.numpy(), dw3.numpy()) and (not masked or np.array_equal(db.numpy(), db3.numpy()))
+
+
 def _bf16_round(x):
     """Round-to-nearest-even fp32 -> bf16 -> fp32 on the host (what v_cvt_pk_bf16_f32 does)."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
@@ -514,14 +543,17 @@ def test_pool_dense_softmax_cce_equals_the_two_calls(ctx, b, h, c, mode):
     for fused in (False, True, "again"):
         pooled, probs, la = ctx.zeros((b, h)), ctx.empty((b, c)), ctx.zeros(2)
         dw_, db_, dp = ctx.empty((h, c)), ctx.empty(c), ctx.empty((b, h))
+        dbr = ctx.zeros(h)
         arg = ctx.empty((b, h), np.int32) if mode == "max" else None
         if fused:
             D.pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, la, float(b), dw=dw_, db=db_, dpooled=dp,
-                                     mode=mode, argmax=arg)
+                                     mode=mode, argmax=arg, db_relu=None if mode == "max" else dbr)
         else:
             D.segment_pool(ctx, seg, x, pooled, mode, arg)
             D.dense_softmax_cce(ctx, pooled, w, bias, y, probs, la, float(b), dw=dw_, db=db_, dpooled=dp)
-        out[fused] = [a.numpy() for a in (pooled, probs, la, dw_, db_, dp)]
+            if mode != "max":
+                D.pool_bwd_colsum(ctx, seg, dp, x, dbr, mode)
+        out[fused] = [a.numpy() for a in (pooled, probs, la, dw_, db_, dp, dbr)]
     for a0, a1, a2 in zip(out[False], out[True], out["again"]):
         assert rel_err(a1, a0) < TIGHT and np.array_equal(a1, a2)
     assert out[True][2][1] == out[False][2][1]                       # hit count
