@@ -82,7 +82,7 @@ int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out);
 int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs_per_cu);
 // cnt_part (may be NULL): per (slice, graph, column) the number of positive entries, same layout.
 int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t f,
-                       int mode, int nsplit, float* part, float* cnt_part);
+                       int mode, int nsplit, float* part, float* cnt_part, int wide);   // wide: 1024-thread workgroups
 
 #define GCNX_CHECK_CTX(ctx) \
   do { if (!(ctx)) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "%s: ctx is NULL", __func__); } while (0)

@@ -33,15 +33,19 @@ struct PoolParts {
   float* db_relu;           // [h] or NULL: sum_g s_g * dPooled[g] * cnt[g]  (bias gradient of the ReLU layer under the pool)
 };
 
-template <bool STAGED, bool PARTS = false>
+// CT > 0: the number of classes as a compile-time constant (2 for the reference's binary labels).  With c a run-time
+// value every per-class loop is a chain of scalar branches and dependent LDS reads executed by a single workgroup
+// with nothing to hide them behind: the dPooled phase alone was 3.3 us of a 15 us kernel.
+template <bool STAGED, bool PARTS = false, int CT = 0>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ pooled, int64_t ldp,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                   const float* __restrict__ y, int32_t b, int32_t h, int32_t c,
+                                                   const float* __restrict__ y, int32_t b, int32_t h, int32_t c_rt,
                                                    float denom, float* __restrict__ probs,
                                                    float* __restrict__ loss_acc, float* __restrict__ dw,
                                                    float* __restrict__ db, float* __restrict__ dpooled, int64_t lddp,
                                                    float* __restrict__ slabs, int* __restrict__ ticket, PoolParts pp) {
   static_assert(STAGED || !PARTS, "partials are combined into the LDS copy");
+  const int c = CT > 0 ? CT : c_rt;
   constexpr bool staged = STAGED;
   __shared__ float s_z[kHeadRows][kHeadMaxC + 1];   // logits, then dlogits
   __shared__ float s_y[kHeadRows * kHeadMaxC];      // labels of this workgroup's graphs, [rows][c] packed
@@ -61,28 +65,33 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
   float* s_db = s_c + kHeadRows * ps;
   __shared__ float s_sc[kHeadRows];               // AVG: 1 / rows of the graph
   const bool want_db = PARTS && pp.db_relu != nullptr && dw != nullptr;
-  if (y) for (int idx = tid; idx < rows * c; idx += 256) s_y[idx] = y[(int64_t)g0 * c + idx];
+  // One workgroup, nothing to hide a memory round trip behind: every independent load of the staging phase is
+  // issued before the first result is consumed -- the first 256 labels and W entries and the graph sizes sit in
+  // registers under the partial-sum loads instead of each costing a load -> wait -> LDS store trip of its own.
+  const bool y_now = y && tid < rows * c, w_now = staged && tid < h * c;
+  const float y_first = y_now ? y[(int64_t)g0 * c + tid] : 0.f;
+  const float w_first = w_now ? w[tid] : 0.f;
+  if (y) for (int idx = tid + 256; idx < rows * c; idx += 256) s_y[idx] = y[(int64_t)g0 * c + idx];
   if (staged) {
     if (PARTS) {
       // The split pool's partial row sums (and counts) are combined here, in slice order.  float4 lanes, four
       // elements per thread and pass, the slice loop unrolled: a thread's loads are in flight together -- one
       // memory latency for the whole combine at the E. coli shape.  (h % 4 == 0: checked by the host.)
-      if (tid < rows) {
-        const int cnt = pp.gp[g0 + tid + 1] - pp.gp[g0 + tid];
-        s_sc[tid] = (pp.avg && cnt > 0) ? 1.0f / (float)cnt : 1.0f;
-      }
+      int n_first = 1;
+      if (tid < rows) n_first = pp.gp[g0 + tid + 1] - pp.gp[g0 + tid];
       const int h4 = h >> 2, total = rows * h4;
       const int64_t zs = (int64_t)b * h;
       const bool st4 = (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(pp.pooled_out) & 15) == 0;
       for (int e0 = 0; e0 < total; e0 += 1024) {
         float4 acc[4], cacc[4];
-        int ii[4], jj[4];
+        int ii[4], jj[4], nn[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int idx = min(e0 + u * 256 + tid, total - 1);       // clamped: loads stay in range, stores are guarded
           ii[u] = idx / h4;
           jj[u] = (idx - ii[u] * h4) * 4;
           acc[u] = cacc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          nn[u] = pp.avg ? pp.gp[g0 + ii[u] + 1] - pp.gp[g0 + ii[u]] : 1;
         }
 #pragma unroll 4
         for (int z = 0; z < pp.nsplit; ++z) {                       // slice order, as pool_combine_kernel
@@ -101,10 +110,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
         for (int u = 0; u < 4; ++u) {
           if (e0 + u * 256 + tid >= total) continue;
           float4 v = acc[u];
-          if (pp.avg) {
-            const int cnt = pp.gp[g0 + ii[u] + 1] - pp.gp[g0 + ii[u]];
-            if (cnt > 0) { v.x /= (float)cnt; v.y /= (float)cnt; v.z /= (float)cnt; v.w /= (float)cnt; }
-          }
+          if (pp.avg && nn[u] > 0) { v.x /= (float)nn[u]; v.y /= (float)nn[u]; v.z /= (float)nn[u]; v.w /= (float)nn[u]; }
           float* sp = s_p + ii[u] * ps + jj[u];
           sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = v.w;
           if (want_db) {
@@ -116,13 +122,16 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
           else { po[0] = v.x; po[1] = v.y; po[2] = v.z; po[3] = v.w; }
         }
       }
+      if (tid < rows) s_sc[tid] = (pp.avg && n_first > 0) ? 1.0f / (float)n_first : 1.0f;
     } else {
       for (int i = tid >> 6; i < rows; i += 4)             // one wave per row: no integer division in the loops
         for (int j = tid & 63; j < h; j += 64) s_p[i * ps + j] = pooled[(int64_t)(g0 + i) * ldp + j];
     }
-    for (int idx = tid; idx < h * c; idx += 256) s_w[idx] = w[idx];
+    if (w_now) s_w[tid] = w_first;
+    for (int idx = tid + 256; idx < h * c; idx += 256) s_w[idx] = w[idx];
     __syncthreads();
   }
+  if (y_now) s_y[tid] = y_first;                  // read after the barrier that closes the logits phase
   auto P = [&](int i, int j) { return staged ? s_p[i * ps + j] : pooled[(int64_t)(g0 + i) * ldp + j]; };
   auto W = [&](int j, int k) { return staged ? s_w[j * c + k] : w[(int64_t)j * c + k]; };
 
@@ -137,7 +146,6 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
     if (q == 0) s_z[i][k] = acc + (bias ? bias[k] : 0.f);
   }
   __syncthreads();
-
   // per graph: softmax, clipped CCE, accuracy, dlogits (same arithmetic as softmax_cce_kernel in reduce.hip)
   float loss = 0.f, hit = 0.f;
   if (tid < rows) {
@@ -324,14 +332,16 @@ static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const floa
   if (pooled_out) {
     float* part = (float*)ctx->ws + slab_floats;
     float* cnt_part = want_db ? part + one_part : nullptr;
-    int rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, pool_mode, nsplit, part, cnt_part);
+    int rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, pool_mode, nsplit, part, cnt_part, 1);
     if (rc) return rc;
     pp = PoolParts{part, graph_ptr, pooled_out, nsplit, pool_mode == GCNX_POOL_AVG ? 1 : 0, cnt_part, want_db ? db_relu : nullptr};
-    hipLaunchKernelGGL((head_kernel<true, true>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w,
-                       bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
+#define GCNX_HEAD(S, P, C)                                                                                                 \
+    hipLaunchKernelGGL((head_kernel<S, P, C>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w, bias, \
+                       y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp)
+    if (c == 2) GCNX_HEAD(true, true, 2); else GCNX_HEAD(true, true, 0);
   } else if (staged) {
-    hipLaunchKernelGGL((head_kernel<true, false>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w,
-                       bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
+    if (c == 2) GCNX_HEAD(true, false, 2); else GCNX_HEAD(true, false, 0);
+#undef GCNX_HEAD
   } else {
     hipLaunchKernelGGL((head_kernel<false, false>), dim3(nblk), dim3(256), 0, ctx->stream, pooled, ldp, w, bias, y, b, h, c,
                        denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);

@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // Pool forward: block = (column tile of 64, graph); 16 float4 column lanes x 16 row groups.
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict__ gp, const float* __restrict__ x,
+// RG = row groups per workgroup (16 x RG threads).  16 for the stand-alone pool; 64 (1024 threads, four times the
+// loads in flight per workgroup) where the slice count is kept low for the consumer's sake (the head reads them).
+template <int RG>
+__global__ __launch_bounds__(16 * RG) void pool_fwd_kernel(const int32_t* __restrict__ gp, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ pooled, int32_t f, int mode,
                                                        int32_t* __restrict__ argmax, int vec, int nsplit,
                                                        float* __restrict__ cnt) {
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
   // row sum to pooled + z*B*f (the caller's workspace); pool_combine_kernel adds them in order.
   // cnt (sum/avg, may be NULL): the number of positive entries per (graph, column), same layout as pooled --
   // what the bias gradient of a ReLU layer under the pool needs (gcnx_pool_dense_softmax_cce, db_relu).
-  __shared__ float4 s[16][16];
-  __shared__ int4 si[16][16];
+  __shared__ float4 s[RG][16];
+  __shared__ int4 si[RG][16];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cl * 4;
   const int valid = f - c;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
   if (mode != GCNX_POOL_MAX) arg = make_int4(0, 0, 0, 0);
   if (valid > 0) {
 #pragma unroll 4
-    for (int r = lo + rg; r < hi; r += 16) {
+    for (int r = lo + rg; r < hi; r += RG) {
       const float4 v = ld4(x + (int64_t)r * ldx + c, v4, valid);
       if (mode == GCNX_POOL_MAX) {
         if (v.x > acc.x) { acc.x = v.x; arg.x = r; }
@@ -126,6 +129,19 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const int32_t* __restrict
   s[rg][cl] = acc;
   si[rg][cl] = arg;
   __syncthreads();
+  if (RG > 16) {   // SUM / AVG only (the launcher): fold groups rg, rg + 16, ... first, then the 16 as below
+    if (rg < 16) {
+      float4 o = s[rg][cl];
+      int4 a = si[rg][cl];
+      for (int q = rg + 16; q < RG; q += 16) {
+        o.x += s[q][cl].x; o.y += s[q][cl].y; o.z += s[q][cl].z; o.w += s[q][cl].w;
+        a.x += si[q][cl].x; a.y += si[q][cl].y; a.z += si[q][cl].z; a.w += si[q][cl].w;
+      }
+      s[rg][cl] = o;
+      si[rg][cl] = a;
+    }
+    __syncthreads();
+  }
   if (rg == 0 && valid > 0) {
     float4 o = s[0][cl];
     int4 a = si[0][cl];
@@ -393,11 +409,15 @@ int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs
 }
 
 int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t f,
-                       int mode, int nsplit, float* part, float* cnt_part) {
+                       int mode, int nsplit, float* part, float* cnt_part, int wide) {
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
   dim3 grid(gcnx_cdiv(f, 64), b, nsplit);
-  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, part, f, mode,
-                     (int32_t*)nullptr, vec, nsplit, cnt_part);
+  if (wide)
+    hipLaunchKernelGGL(pool_fwd_kernel<64>, grid, dim3(1024), 0, ctx->stream, graph_ptr, x, ldx, part, f, mode,
+                       (int32_t*)nullptr, vec, nsplit, cnt_part);
+  else
+    hipLaunchKernelGGL(pool_fwd_kernel<16>, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, part, f, mode,
+                       (int32_t*)nullptr, vec, nsplit, cnt_part);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -469,7 +489,7 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
   if (nsplit > 1) {
     int rc = gcnx_ws_reserve(ctx, (size_t)nsplit * b * f * sizeof(float));
     if (rc) return rc;
-    rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, f, mode, nsplit, (float*)ctx->ws, nullptr);
+    rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, f, mode, nsplit, (float*)ctx->ws, nullptr, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(pool_combine_kernel, dim3(gcnx_cdiv((int64_t)b * f, 256)), dim3(256), 0, ctx->stream,
                        (const float*)ctx->ws, graph_ptr, pooled, b, f, nsplit, mode);
@@ -477,7 +497,7 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
     return GCNX_OK;
   }
   dim3 grid(gcnx_cdiv(f, 64), b);
-  hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec, 1,
+  hipLaunchKernelGGL(pool_fwd_kernel<16>, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode, argmax, vec, 1,
                      (float*)nullptr);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
