@@ -280,6 +280,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   splitk_reduce_body(part, slab, nsplit, out, total, blockIdx.x, s);
 }
 
+// The last gradient and the optimizer step in one launch (gcnx_gemm_dw_sgd): workgroups [0, n_s) fold the split-K
+// slabs into dW -- an interval [off, off + total) of the flat gradient buffer -- and update those parameters;
+// the rest apply p -= lr * g to the other parameters, 256 per workgroup.
+__global__ __launch_bounds__(256) void reduce_sgd_kernel(const float* __restrict__ part, int64_t slab, int nsplit,
+                                                         int64_t total, int n_s, float* __restrict__ params,
+                                                         float* __restrict__ grads, int64_t off, int64_t n_params,
+                                                         float lr) {
+  __shared__ float s[4][64];
+  if ((int)blockIdx.x < n_s) {
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    float acc = 0.f;
+    if (i < total) {
+      const int per = (nsplit + 3) / 4;
+      const int z0 = grp * per, z1 = min(nsplit, z0 + per);
+#pragma unroll 4
+      for (int z = z0; z < z1; ++z) acc += part[(int64_t)z * slab + i];
+    }
+    s[grp][el] = acc;
+    __syncthreads();
+    if (grp == 0 && i < total) {
+      const float g = (s[0][el] + s[1][el]) + (s[2][el] + s[3][el]);      // the order of splitk_reduce_kernel
+      grads[off + i] = g;
+      params[off + i] = params[off + i] - lr * g;
+    }
+    return;
+  }
+  // the parameters outside [off, off + total): indices [0, off) then [off + total, n_params)
+  int64_t i = (int64_t)(blockIdx.x - n_s) * 256 + threadIdx.x;
+  if (i >= off) i += total;
+  if (i < n_params) params[i] = params[i] - lr * grads[i];
+}
+
 // Both second stages of gcnx_dense_bwd in one launch: workgroups [0, n_c) fold the dX epilogue's partial column
 // sums into db, the rest the split-K slabs into dW.
 __global__ __launch_bounds__(256) void reduce_duo_kernel(const float* __restrict__ cpart, int64_t crows, int32_t cf,
@@ -762,6 +795,49 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
                        (const float*)ctx->ws, total, nsplit, dw, total);
     GCNX_LAUNCH_OK(ctx);
   }
+  return GCNX_OK;
+}
+
+int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n,
+                     int32_t fi, int32_t fo, int prec, float* params, float* grads, int64_t n_params, float lr) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0 && n_params >= 0, "gcnx_gemm_dw_sgd: negative size");
+  GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dw_sgd: unknown precision %d", prec);
+  GCNX_REQUIRE(ctx, n_params == 0 || (params && grads), "gcnx_gemm_dw_sgd: NULL pointer");
+  const int64_t total = (int64_t)fi * fo;
+  GCNX_REQUIRE(ctx, total == 0 || (dw >= grads && dw + total <= grads + n_params),
+               "gcnx_gemm_dw_sgd: dw must lie inside the flat gradient buffer");
+  // split-K as gcnx_gemm_dw (the same slices, so the same dW bits)
+  int nsplit = 1;
+  int64_t kchunk = 0;
+  if (prec == GCNX_PREC_F32 && n > 0 && total > 0) {
+    const int tiles = gcnx_cdiv(fi, BM) * gcnx_cdiv(fo, BN);
+    nsplit = (int)((4LL * ctx->num_cus + tiles - 1) / tiles);
+    const int64_t ksteps = (n + BK - 1) / BK;
+    if (nsplit > ksteps) nsplit = (int)ksteps;
+    if (nsplit < 1) nsplit = 1;
+    kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
+    nsplit = (int)((n + kchunk - 1) / kchunk);
+  }
+  if (nsplit <= 1 || fo % 4 != 0) {   // nothing to reduce (or bf16 / ragged): the two calls
+    int rc = gcnx_gemm_dw(ctx, x, ldx, dh, lddh, dw, n, fi, fo, prec);
+    if (rc) return rc;
+    return gcnx_sgd(ctx, params, grads, n_params, lr);
+  }
+  GCNX_REQUIRE(ctx, x && dh, "gcnx_gemm_dw_sgd: NULL pointer");
+  GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo, "gcnx_gemm_dw_sgd: leading dimension too small");
+  int rc = gcnx_ws_reserve(ctx, (size_t)nsplit * total * sizeof(float));
+  if (rc) return rc;
+  Epilogue ep{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0, 1};
+  const int va = al16(x) && ldx % 4 == 0, vb = al16(dh) && lddh % 4 == 0;
+  dim3 grid(gcnx_cdiv(fo, BN), gcnx_cdiv(fi, BM), nsplit);
+  hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, ctx->stream, x, ldx, dh, lddh, (float*)ctx->ws,
+                     (int64_t)fo, (int64_t)fi, fo, n, kchunk, ep, va, vb);
+  GCNX_LAUNCH_OK(ctx);
+  const int n_s = gcnx_cdiv(total, 64), n_o = gcnx_cdiv(n_params - total, 256);
+  hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + n_o), dim3(256), 0, ctx->stream, (const float*)ctx->ws, total, nsplit,
+                     total, n_s, params, grads, (int64_t)(dw - grads), n_params, lr);
+  GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
 

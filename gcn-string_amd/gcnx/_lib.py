@@ -83,6 +83,7 @@ SIGNATURES = {
     "gcnx_bn_act_bwd_stats": [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp],
     "gcnx_bn_act_bwd_apply": [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _int, _vp, _vp, _f32, _int, _vp, _i64],
     "gcnx_sgd": [_vp, _vp, _vp, _i64, _f32],
+    "gcnx_gemm_dw_sgd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp, _i64, _f32],
     "gcnx_comm_unique_id": [C.c_char_p],
     "gcnx_comm_init_rank": [_vp, C.c_char_p, _int, _int, C.POINTER(_vp)],
     "gcnx_comm_destroy": [_vp],

@@ -454,6 +454,16 @@ def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
     return dx
 
 
+def gemm_dw_sgd(ctx, x, dh, dw, params, grads, lr, prec="f32"):
+    """dw = X^T dH (a view into the flat ``grads``), then params -= lr * grads over the whole flat buffers
+    (gcnx_gemm_dw_sgd: the split-K reduction launch applies the update)."""
+    n, fi = x.shape
+    fo = dh.shape[1]
+    assert dh.shape[0] == n and dw.shape == (fi, fo) and dw.contiguous and params.size == grads.size
+    ctx._ck(ctx.lib.gcnx_gemm_dw_sgd(ctx.h, _p(x), x.ld, _p(dh), dh.ld, _p(dw), n, fi, fo, L.PRECS[prec], _p(params),
+                                     _p(grads), params.size, float(lr)))
+
+
 def dense_bwd(ctx, x, dh, w, dx, dw, prec="f32", y_mask=None, db_prev=None):
     """Backward of H = X W given dH in one call (gcnx_dense_bwd): dw = X^T dH, dx = dH W^T (* [y_mask > 0]),
     db_prev = column sums of dx."""

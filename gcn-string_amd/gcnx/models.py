@@ -208,7 +208,8 @@ class GCN2(_GraphRunner):
         else:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], None, bufs["probs"], **head)
 
-    def _backward(self, batch, bufs):
+    def _backward(self, batch, bufs, lr=None):
+        """All gradients; with ``lr`` (single process) the SGD step too -- returns True if it was applied here."""
         ctx, p, g, prec = self.ctx, self.p, self.g, self.prec
         at = batch.a.transpose()
         # The gradient leaves of layer 2 (db2, dW2: nothing later in the backward pass reads them) run in ONE side
@@ -232,8 +233,12 @@ class GCN2(_GraphRunner):
             D.dense_bwd(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], prec=prec, y_mask=bufs["y1"],
                         db_prev=g["b1"])                                       # dW2, dZ1, db1
             D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                     # dH1 = A^T dZ1
-            D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)            # dW1 = X^T dH1
-            return
+            if lr is None:
+                D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)        # dW1 = X^T dH1
+                return False
+            # the last gradient: its split-K reduction launch also applies the SGD step to every parameter
+            D.gemm_dw_sgd(ctx, batch.x, bufs["h2"], g["w1"], self.flat_p, self.flat_g.flat(0, self.n_params), lr, prec=prec)
+            return True
         with ctx.side():
             if not fold:                                                       # (folded: db2 came out of the head)
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
@@ -298,7 +303,8 @@ class GCN2(_GraphRunner):
 
         def seq():
             self._forward(batch, bufs, "grads", denom)
-            self._backward(batch, bufs)
+            if self._backward(batch, bufs, None if multi else _lr):
+                return
             if _lr is not None and not multi:
                 # single process: the update rides in the same captured graph (one graph launch per step)
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)

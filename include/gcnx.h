@@ -290,6 +290,13 @@ GCNX_API int gcnx_bn_act_bwd_apply(gcnx_ctx* ctx, const float* dy, int64_t lddy,
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);
+/* The last gradient of a step and the optimizer apply as one call: gcnx_gemm_dw (dw = X^T dH, written into the flat
+ * gradient buffer: grads <= dw, dw + fi*fo <= grads + n_params) followed by gcnx_sgd over all n_params parameters
+ * (gcn.py:337-338: tape.gradient, then optimizer.apply_gradients).  Where dW is a split-K product its reduction
+ * launch also applies the update (one launch instead of two); same dW and parameter bits as the two calls. */
+GCNX_API int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw,
+                     int64_t n, int32_t fi, int32_t fo, int prec, float* params, float* grads, int64_t n_params,
+                     float lr);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new capability) ---- */
 GCNX_API int gcnx_comm_unique_id(char id[GCNX_UNIQUE_ID_BYTES]);

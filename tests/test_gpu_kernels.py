@@ -348,6 +348,35 @@ def test_dense_bwd_equals_gemm_dx_plus_gemm_dw(ctx, n, fi, fo, prec):
         assert np.array_equal(dw.numpy(), dw3.numpy()) and (not masked or np.array_equal(db.numpy(), db3.numpy()))
 
 
+@pytest.mark.parametrize("n,fi,fo,prec", [(20498, 128, 128, "f32"), (3000, 64, 96, "f32"), (10, 6, 4, "f32"),
+                                          (129, 10, 6, "f32"), (1000, 128, 128, "bf16x3")])
+def test_gemm_dw_sgd_equals_gemm_dw_then_sgd_bitwise(ctx, n, fi, fo, prec):
+    """gcnx_gemm_dw_sgd: dW lands in the middle of a flat gradient buffer and every parameter is updated; the same
+    bits as gcnx_gemm_dw + gcnx_sgd (same split-K slices, same update arithmetic)."""
+    from gcnx import device as D
+    rng = np.random.default_rng(fi * fo)
+    x = ctx.to_device(rng.standard_normal((n, fi), dtype=np.float32))
+    dh = ctx.to_device(rng.standard_normal((n, fo), dtype=np.float32))
+    before, off, tail = 300, 300, 517                        # parameters in front of and behind dW
+    n_params = before + fi * fo + tail
+    p0 = rng.standard_normal(n_params).astype(np.float32); g0 = rng.standard_normal(n_params).astype(np.float32)
+    out = []
+    for fused in (False, True):
+        params, grads = ctx.to_device(p0), ctx.to_device(g0)
+        dw = grads.flat(off, fi * fo, (fi, fo))
+        if fused:
+            D.gemm_dw_sgd(ctx, x, dh, dw, params, grads, 0.05, prec=prec)
+        else:
+            D.gemm_dw(ctx, x, dh, dw, prec=prec)
+            D.sgd(ctx, params, grads, 0.05)
+        out.append((params.numpy(), grads.numpy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert not np.array_equal(out[1][0], p0)
+    from gcnx._lib import GcnxError
+    with pytest.raises(GcnxError, match="inside the flat gradient buffer"):
+        D.gemm_dw_sgd(ctx, x, dh, ctx.empty((fi, fo)), ctx.to_device(p0), ctx.to_device(g0), 0.05, prec=prec)
+
+
 def _bf16_round(x):
     """Round-to-nearest-even fp32 -> bf16 -> fp32 on the host (what v_cvt_pk_bf16_f32 does)."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
