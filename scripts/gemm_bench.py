@@ -21,10 +21,12 @@ for sh in args.shapes.split(","):
     x = ctx.to_device(rng.standard_normal((n, fi), dtype=np.float32))
     w = ctx.to_device((rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32))
     dh = ctx.to_device(rng.standard_normal((n, fo), dtype=np.float32))
-    out, dx, dw = ctx.empty((n, fo)), ctx.empty((n, fi)), ctx.empty((fi, fo))
+    out, dx, dw, dbv = ctx.empty((n, fo)), ctx.empty((n, fi)), ctx.empty((fi, fo)), ctx.empty(fi)
     res = []
     for name, fn in (("fwd", lambda: D.gemm(ctx, x, w, None, out, prec=args.prec)),
                      ("dx", lambda: D.gemm_dx(ctx, dh, w, dx, prec=args.prec)),
+                     ("dx+mask", lambda: D.gemm_dx(ctx, dh, w, dx, prec=args.prec, y_mask=x)),
+                     ("dx+mask+db", lambda: D.gemm_dx(ctx, dh, w, dx, prec=args.prec, y_mask=x, db=dbv)),
                      ("dw", lambda: D.gemm_dw(ctx, x, dh, dw, prec=args.prec))):
         for _ in range(3): fn()
         e0 = ctx.event().record()
