@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -42,14 +43,23 @@ constexpr int kStageCap = 2048;      // CSR entries staged in LDS per chunk (ove
 constexpr int kLongRowSmall = 256;    // rows with more entries are split over the workgroup's four waves: 8-row chunks
 constexpr int kLongRowLarge = 32;     // (latency regime: a chunk below the limit skips the hub phase outright) / 32-row chunks
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of fp32 per instruction at full rate).  The row gather
+// is not pure memory time: at config 2 each launch issues ~150 k wave-level float4 loads, and with one VALU
+// instruction per component the accumulation alone was >1 us of the kernel (the folded backward's mask: 3 us).
 __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
-  a.x = fmaf(v, h.x, a.x); a.y = fmaf(v, h.y, a.y); a.z = fmaf(v, h.z, a.z); a.w = fmaf(v, h.w, a.w);
-  return a;
+  const f32x2 w = {v, v};
+  const f32x2 lo = __builtin_elementwise_fma(w, f32x2{h.x, h.y}, f32x2{a.x, a.y});
+  const f32x2 hi = __builtin_elementwise_fma(w, f32x2{h.z, h.w}, f32x2{a.z, a.w});
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
 __device__ __forceinline__ float4 f4_step(float4 a) {   // [a > 0]
   return make_float4(a.x > 0.f ? 1.f : 0.f, a.y > 0.f ? 1.f : 0.f, a.z > 0.f ? 1.f : 0.f, a.w > 0.f ? 1.f : 0.f);
 }
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  const f32x2 lo = f32x2{a.x, a.y} + f32x2{b.x, b.y}, hi = f32x2{a.z, a.w} + f32x2{b.z, b.w};
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
 
 // Pool' + ReLU' folded into the backward aggregation (FOLD): with dZ[j] = dPooled[graph(j)] * [y[j] > 0] and a
 // block-diagonal operator, (A^T dZ)[i] = dPooled[graph(i)] * sum_j A^T[i,j] [y[j] > 0] -- the gather reads the saved
@@ -156,7 +166,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
     if (FOLD && col_ok && r < r1) {
       const int gi = s_g[r - r0] - s_g[0];
-      d = gi < 2 ? s_d[gi][sub] : *reinterpret_cast<const float4*>(fo.dp + (int64_t)s_g[r - r0] * fo.lddp + c);
+      d = s_d[min(gi, 1)][sub];            // (two statements: a select between an LDS and a global address trips hipcc)
+      if (gi >= 2) d = *reinterpret_cast<const float4*>(fo.dp + (int64_t)s_g[r - r0] * fo.lddp + c);
       const float sc = s_sc[r - r0];
       d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
     }
@@ -185,6 +196,16 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   };
   constexpr int kLongRow = RPC <= 8 ? kLongRowSmall : kLongRowLarge;
   bool saw_long = false;
+  // Two instances of the row loop: chunks whose entries all fit the LDS stage (every chunk but those with hub rows)
+  // take the one WITHOUT the global-index fallback.  With the fallback in the loop, hipcc's wait-count pass must
+  // assume a pending index load on every trip and puts s_waitcnt vmcnt(0) after each gather load -- the trip's four
+  // loads ran one after the other instead of together.
+  auto rows_pass = [&](auto all_staged) {
+  constexpr bool kAllStaged = decltype(all_staged)::value;
+  auto entry_of = [&](int e, int& cidx, float& v) {
+    if (kAllStaged) { cidx = s_col[e]; v = WEIGHTED ? s_val[e] : 1.0f; }
+    else entry(e, cidx, v);
+  };
   for (int r = r0 + wave; r < r1; r += 8) {
     const int rB = r + 4;                                          // second row of this trip (may be past the chunk)
     int aA = s_rp[r - r0] - e0, bA = s_rp[r - r0 + 1] - e0;        // chunk-relative entry ranges
@@ -196,6 +217,33 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
     if (col_ok) {
       int eA = aA + g, eB = aB + g;
+      if (kAllStaged) {
+        // Full trips first: 2G entries of both rows, no conditions -- four gather loads issued back to back and one
+        // wait.  (The conditional trip below is what remains for the row tails: each of its loads sits in a branch
+        // of its own, and hipcc ends every such branch with a wait or a register copy.)
+        const int nfull = min(bA - aA, bB - aB) / (2 * G);        // uniform per wave
+        for (int t = 0; t < nfull; ++t) {
+          const int cA0 = s_col[eA], cA1 = s_col[eA + G], cB0 = s_col[eB], cB1 = s_col[eB + G];
+          const float4 hA0 = *reinterpret_cast<const float4*>(h + (int64_t)cA0 * ldh + c);
+          const float4 hA1 = *reinterpret_cast<const float4*>(h + (int64_t)cA1 * ldh + c);
+          const float4 hB0 = *reinterpret_cast<const float4*>(h + (int64_t)cB0 * ldh + c);
+          const float4 hB1 = *reinterpret_cast<const float4*>(h + (int64_t)cB1 * ldh + c);
+          if (WEIGHTED) {
+            const float wA0 = s_val[eA], wA1 = s_val[eA + G], wB0 = s_val[eB], wB1 = s_val[eB + G];
+            accA = f4_fma(wA0, FOLD ? f4_step(hA0) : hA0, accA);
+            accB = f4_fma(wB0, FOLD ? f4_step(hB0) : hB0, accB);
+            accA = f4_fma(wA1, FOLD ? f4_step(hA1) : hA1, accA);
+            accB = f4_fma(wB1, FOLD ? f4_step(hB1) : hB1, accB);
+          } else {
+            accA = f4_add(accA, FOLD ? f4_step(hA0) : hA0);
+            accB = f4_add(accB, FOLD ? f4_step(hB0) : hB0);
+            accA = f4_add(accA, FOLD ? f4_step(hA1) : hA1);
+            accB = f4_add(accB, FOLD ? f4_step(hB1) : hB1);
+          }
+          eA += 2 * G;
+          eB += 2 * G;
+        }
+      }
       while (eA < bA || eB < bB) {                                 // wave-divergent only in the tails
         float4 hA[2], hB[2];
         float vA[2], vB[2];
@@ -204,14 +252,15 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
           int cA = 0, cB = 0;
           vA[u] = vB[u] = 0.f;
           hA[u] = hB[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (eA + u * G < bA) { entry(eA + u * G, cA, vA[u]); hA[u] = *reinterpret_cast<const float4*>(h + (int64_t)cA * ldh + c); }
-          if (eB + u * G < bB) { entry(eB + u * G, cB, vB[u]); hB[u] = *reinterpret_cast<const float4*>(h + (int64_t)cB * ldh + c); }
+          if (eA + u * G < bA) { entry_of(eA + u * G, cA, vA[u]); hA[u] = *reinterpret_cast<const float4*>(h + (int64_t)cA * ldh + c); }
+          if (eB + u * G < bB) { entry_of(eB + u * G, cB, vB[u]); hB[u] = *reinterpret_cast<const float4*>(h + (int64_t)cB * ldh + c); }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          if (FOLD) { hA[u] = f4_step(hA[u]); hB[u] = f4_step(hB[u]); }
-          if (eA + u * G < bA) accA = WEIGHTED ? f4_fma(vA[u], hA[u], accA) : f4_add(accA, hA[u]);
-          if (eB + u * G < bB) accB = WEIGHTED ? f4_fma(vB[u], hB[u], accB) : f4_add(accB, hB[u]);
+          // (FOLD: the mask is taken here, next to the accumulation -- applied where the value is loaded it made
+          // hipcc wait after every load instead of after the trip's four)
+          if (eA + u * G < bA) { const float4 t = FOLD ? f4_step(hA[u]) : hA[u]; accA = WEIGHTED ? f4_fma(vA[u], t, accA) : f4_add(accA, t); }
+          if (eB + u * G < bB) { const float4 t = FOLD ? f4_step(hB[u]) : hB[u]; accB = WEIGHTED ? f4_fma(vB[u], t, accB) : f4_add(accB, t); }
         }
         eA += 2 * G;
         eB += 2 * G;
@@ -220,6 +269,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     finish(accA, longA ? r1 : r);               // r1: outside the chunk = no store (the merge shuffles still run)
     finish(accB, longB ? r1 : rB);
   }
+  };
+  if (e1 - e0 <= kStageCap) rows_pass(std::true_type{}); else rows_pass(std::false_type{});   // uniform per workgroup
   // Hub rows (power-law batches: one row of a chunk can hold thousands of entries).  Walked by a single wave such a
   // row alone set the kernel's duration (config 5: a 4096-entry row = 2 ms); here every wave of the workgroup takes
   // a quarter of its entries and the four partial sums are combined in wave order (deterministic).
@@ -346,7 +397,6 @@ __device__ __forceinline__ void tile_load_entries(const int32_t* __restrict__ co
     fetch_entries<WEIGHTED, SCALE>(colidx, vals, a[t], threadIdx.x & 3, b[t], row0, pad, last4, mc[t], mv[t]);
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Tile DMA with a uniform 64-bit base (SGPR pair) and a 32-bit per-lane element offset: one register per piece
 // instead of a 64-bit pointer (hoisted 64-bit row addresses were spilled, and each reload put a vmcnt(0) in
