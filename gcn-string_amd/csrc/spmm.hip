@@ -243,8 +243,30 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
           eA += 2 * G;
           eB += 2 * G;
         }
+        // The tails, branch-free as well: a missing entry reads row 0 and is discarded by selects (not by a zero
+        // weight: 0 * inf would poison the sum), so both rows' loads are issued together here too.
+        const int rem = max(bA - aA, bB - aB) - nfull * 2 * G;     // uniform per wave
+        const int last = max(staged - 1, 0);
+        if (RPC > 8)                                               // (8-row chunks: the conditional loop below measured 5 % faster)
+        for (int t = 0; t < rem; t += G) {                         // G entries of both rows per step
+          const bool okA = eA < bA, okB = eB < bB;
+          const int cA = okA ? s_col[min(eA, last)] : 0, cB = okB ? s_col[min(eB, last)] : 0;
+          float4 hA = *reinterpret_cast<const float4*>(h + (int64_t)cA * ldh + c);
+          float4 hB = *reinterpret_cast<const float4*>(h + (int64_t)cB * ldh + c);
+          float wA = 1.f, wB = 1.f;
+          if (WEIGHTED) { wA = s_val[min(eA, last)]; wB = s_val[min(eB, last)]; }
+          if (FOLD) { hA = f4_step(hA); hB = f4_step(hB); }
+          hA.x = okA ? hA.x : 0.f; hA.y = okA ? hA.y : 0.f; hA.z = okA ? hA.z : 0.f; hA.w = okA ? hA.w : 0.f;   // per component:
+          hB.x = okB ? hB.x : 0.f; hB.y = okB ? hB.y : 0.f; hB.z = okB ? hB.z : 0.f; hB.w = okB ? hB.w : 0.f;   // a float4 select goes through scratch
+          wA = okA ? wA : 0.f; wB = okB ? wB : 0.f;
+          if (WEIGHTED) { accA = f4_fma(wA, hA, accA); accB = f4_fma(wB, hB, accB); }
+          else { accA = f4_add(accA, hA); accB = f4_add(accB, hB); }
+          eA += G;
+          eB += G;
+        }
       }
-      while (eA < bA || eB < bB) {                                 // wave-divergent only in the tails
+      if (!kAllStaged || RPC <= 8)
+      while (eA < bA || eB < bB) {                                 // (the instance with the global-index fallback)
         float4 hA[2], hB[2];
         float vA[2], vB[2];
 #pragma unroll
