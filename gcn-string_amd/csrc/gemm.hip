@@ -74,6 +74,25 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ p, int64_t 
   }
 }
 
+// Interior tiles (checked once per workgroup: aligned operands, no ragged edge, whole K steps): plain float4 loads, one
+// value at a time.  fetch_tile puts every load behind per-thread bounds tests with a scalar fallback, and hipcc ends
+// each such conditional load with its own s_waitcnt vmcnt(0): the four loads of a K step -- and with them the
+// prefetch of step t+1 under the MFMAs of step t -- ran one after the other (load and MFMA time were additive).
+template <bool KCONTIG>
+__device__ __forceinline__ float4 fetch_one(const float* __restrict__ p, int64_t ld, int64_t i0, int64_t k0, int idx) {
+  if (KCONTIG) return *reinterpret_cast<const float4*>(p + (i0 + (idx >> 3)) * ld + k0 + (idx & 7) * 4);
+  return *reinterpret_cast<const float4*>(p + (k0 + (idx >> 4)) * ld + i0 + (idx & 15) * 4);
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void store_one(float (*s)[LD], int idx, float4 v) {
+  if (KCONTIG) {
+    const int i = idx >> 3, k = (idx & 7) * 4;
+    s[k + 0][i] = v.x; s[k + 1][i] = v.y; s[k + 2][i] = v.z; s[k + 3][i] = v.w;
+  } else {
+    *reinterpret_cast<float4*>(&s[idx >> 4][(idx & 15) * 4]) = v;
+  }
+}
+
 template <bool KCONTIG>
 __device__ __forceinline__ void store_tile(float (*s)[LD], int tid, const float4 (&v)[2]) {
 #pragma unroll
@@ -111,6 +130,36 @@ __device__ __forceinline__ void gemm_f32_tile(const float* __restrict__ a, int64
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
+  const bool interior = vec_a && vec_b && m0 + BM <= M && n0 + BN <= Nc && kbeg < kend && (kend - kbeg) % BK == 0;
+  if (interior) {            // uniform per workgroup
+    float4 a0 = fetch_one<A_KCONTIG>(a, lda, m0, kbeg, tid), a1 = fetch_one<A_KCONTIG>(a, lda, m0, kbeg, tid + 256);
+    float4 b0 = fetch_one<B_KCONTIG>(b, ldb, n0, kbeg, tid), b1 = fetch_one<B_KCONTIG>(b, ldb, n0, kbeg, tid + 256);
+    store_one<A_KCONTIG>(As[0], tid, a0); store_one<A_KCONTIG>(As[0], tid + 256, a1);
+    store_one<B_KCONTIG>(Bs[0], tid, b0); store_one<B_KCONTIG>(Bs[0], tid + 256, b1);
+    if (kbeg + BK < kend) {
+      a0 = fetch_one<A_KCONTIG>(a, lda, m0, kbeg + BK, tid); a1 = fetch_one<A_KCONTIG>(a, lda, m0, kbeg + BK, tid + 256);
+      b0 = fetch_one<B_KCONTIG>(b, ldb, n0, kbeg + BK, tid); b1 = fetch_one<B_KCONTIG>(b, ldb, n0, kbeg + BK, tid + 256);
+    }
+    int cur = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+      __syncthreads();
+      if (k0 + BK < kend) {
+        store_one<A_KCONTIG>(As[cur ^ 1], tid, a0); store_one<A_KCONTIG>(As[cur ^ 1], tid + 256, a1);
+        store_one<B_KCONTIG>(Bs[cur ^ 1], tid, b0); store_one<B_KCONTIG>(Bs[cur ^ 1], tid + 256, b1);
+        if (k0 + 2 * BK < kend) {
+          a0 = fetch_one<A_KCONTIG>(a, lda, m0, k0 + 2 * BK, tid); a1 = fetch_one<A_KCONTIG>(a, lda, m0, k0 + 2 * BK, tid + 256);
+          b0 = fetch_one<B_KCONTIG>(b, ldb, n0, k0 + 2 * BK, tid); b1 = fetch_one<B_KCONTIG>(b, ldb, n0, k0 + 2 * BK, tid + 256);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const float av = As[cur][2 * kk + fk][wm * 32 + fr];
+        const float bv = Bs[cur][2 * kk + fk][wn * 32 + fr];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+  } else {
   float4 ra[2], rb[2];
   if (kbeg < kend) {
     fetch_tile<A_KCONTIG>(a, lda, m0, M, kbeg, kend, tid, vec_a, ra);
@@ -140,6 +189,7 @@ __device__ __forceinline__ void gemm_f32_tile(const float* __restrict__ a, int64
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
     cur ^= 1;
+  }
   }
 
   // Epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5): stored
