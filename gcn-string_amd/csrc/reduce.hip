@@ -111,7 +111,26 @@ __global__ __launch_bounds__(16 * RG) void pool_fwd_kernel(const int32_t* __rest
   float4 acc = make_float4(init, init, init, init);
   int4 arg = make_int4(lo, lo, lo, lo);                  // MAX: arg max rows; SUM / AVG: counts of positives
   if (mode != GCNX_POOL_MAX) arg = make_int4(0, 0, 0, 0);
-  if (valid > 0) {
+  // SUM / AVG over 16-byte-aligned full column tiles (uniform per workgroup): four plain float4 loads in flight per
+  // step.  In the generic loop below every load sits behind ld4's vector-or-scalar test and hipcc closes each with
+  // its own wait -- the "unroll 4" there is four dependent round trips, not four loads in flight.
+  const bool fast = vec && mode != GCNX_POOL_MAX && (int)blockIdx.x * 64 + 64 <= f;
+  if (fast) {
+    const float* px = x + c;
+    int r = lo + rg;
+    auto add = [&](const float4& v) {
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      arg.x += v.x > 0.f; arg.y += v.y > 0.f; arg.z += v.z > 0.f; arg.w += v.w > 0.f;
+    };
+    for (; r + 3 * RG < hi; r += 4 * RG) {
+      const float4 v0 = *reinterpret_cast<const float4*>(px + (int64_t)r * ldx);
+      const float4 v1 = *reinterpret_cast<const float4*>(px + (int64_t)(r + RG) * ldx);
+      const float4 v2 = *reinterpret_cast<const float4*>(px + (int64_t)(r + 2 * RG) * ldx);
+      const float4 v3 = *reinterpret_cast<const float4*>(px + (int64_t)(r + 3 * RG) * ldx);
+      add(v0); add(v1); add(v2); add(v3);               // row order, as the generic loop
+    }
+    for (; r < hi; r += RG) add(*reinterpret_cast<const float4*>(px + (int64_t)r * ldx));
+  } else if (valid > 0) {
 #pragma unroll 4
     for (int r = lo + rg; r < hi; r += RG) {
       const float4 v = ld4(x + (int64_t)r * ldx + c, v4, valid);
