@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgcnx.so")
+LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "libgcnx.so")   # GCNX_LIB: another build of the same ABI (measurement)
 
 # enums of include/gcnx.h
 OK = 0

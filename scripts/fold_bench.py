@@ -5,9 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gcn-string_amd"))
 import numpy as np
 import gcnx
-if os.environ.get("GCNX_LIB_OVERRIDE"):     # measurement builds (build_variants/*.so)
-    import gcnx._lib as _L
-    _L.LIB_PATH = os.path.abspath(os.environ["GCNX_LIB_OVERRIDE"])
 from gcnx import device as D, synth
 from gcnx.device import DeviceCSR, Segments
 hb = synth.ecoli_batch(); f = 128
