@@ -43,7 +43,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
   const int64_t r1 = min(n, r0 + rows_per_chunk);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc_a = acc;
-  if (valid > 0) {
+  if (!FUSE_ACT && vec && (int)blockIdx.x * 64 + 64 <= f) {
+    // plain column sums over aligned full tiles: four float4 loads in flight per step (the generic loop's loads each
+    // sit behind ld4's vector-or-scalar test and are waited for one by one); same row order, same sums
+    const float* px = x + c;
+    int64_t r = r0 + rg;
+    for (; r + 48 < r1; r += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(px + r * ldx);
+      const float4 v1 = *reinterpret_cast<const float4*>(px + (r + 16) * ldx);
+      const float4 v2 = *reinterpret_cast<const float4*>(px + (r + 32) * ldx);
+      const float4 v3 = *reinterpret_cast<const float4*>(px + (r + 48) * ldx);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(px + r * ldx);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  } else if (valid > 0) {
     float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
     if (FUSE_ACT && act == GCNX_ACT_PRELU) al = ld4(alpha + c, false, valid);
 #pragma unroll 4
