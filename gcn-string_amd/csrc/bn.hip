@@ -11,6 +11,8 @@
 //             dz = gamma*inv*(dzb - s1/n - xhat*s2/n)     2 reads + 1 write
 // xhat and zb are recomputed from z and the saved (mu, inv): nothing but z itself is kept for
 // the backward pass.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -38,8 +40,11 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 
 // NS running column sums per lane; each comes out of `terms(row values) -> float4[NS]`.
 // part layout: [chunk][NS][f].
+// `fast` (uniform per workgroup: 16-byte-aligned operands, a full 64-column tile) selects the instance whose `terms`
+// loads are plain float4 loads, two rows at a time: behind ld4g's vector-or-scalar test every load is waited for on
+// its own (hipcc), so the generic loop has one load in flight where this one has all of two rows'.
 template <int NS, class F>
-__device__ __forceinline__ void colsums(int64_t n, int32_t f, float* __restrict__ part, F terms) {
+__device__ __forceinline__ void colsums(int64_t n, int32_t f, float* __restrict__ part, bool fast, F terms) {
   __shared__ float4 s[NS][16][16];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cl * 4;
@@ -49,11 +54,26 @@ __device__ __forceinline__ void colsums(int64_t n, int32_t f, float* __restrict_
   float4 acc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) acc[k] = f4(0.f);
-  if (valid > 0) {
+  if (fast) {
+    int64_t r = r0 + rg;
+    for (; r + 16 < r1; r += 32) {
+      float4 t0[NS], t1[NS];
+      terms(r, c, 4, t0, std::true_type{});
+      terms(r + 16, c, 4, t1, std::true_type{});
+#pragma unroll
+      for (int k = 0; k < NS; ++k) acc[k] = add4(add4(acc[k], t0[k]), t1[k]);      // row order, as below
+    }
+    for (; r < r1; r += 16) {
+      float4 t[NS];
+      terms(r, c, 4, t, std::true_type{});
+#pragma unroll
+      for (int k = 0; k < NS; ++k) acc[k] = add4(acc[k], t[k]);
+    }
+  } else if (valid > 0) {
 #pragma unroll 2
     for (int64_t r = r0 + rg; r < r1; r += 16) {
       float4 t[NS];
-      terms(r, c, valid, t);
+      terms(r, c, valid, t, std::false_type{});
 #pragma unroll
       for (int k = 0; k < NS; ++k) acc[k] = add4(acc[k], t[k]);
     }
@@ -73,8 +93,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const int c0 = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
   float4 sh = f4(0.f);
   if (shift && f - c0 > 0) sh = ld4g(shift + c0, false, f - c0);
-  colsums<2>(n, f, part, [&](int64_t r, int c, int valid, float4 (&t)[2]) {
-    float4 v = ld4g(z + r * ldz + c, vec && valid >= 4, valid);
+  colsums<2>(n, f, part, vec && (int)blockIdx.x * 64 + 64 <= f, [&](int64_t r, int c, int valid, float4 (&t)[2], auto fast) {
+    float4 v = ld4g(z + r * ldz + c, decltype(fast)::value || (vec && valid >= 4), valid);
     v = make_float4(v.x - sh.x, v.y - sh.y, v.z - sh.z, v.w - sh.w);
     t[0] = v;
     t[1] = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
@@ -191,14 +211,24 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z
   float4 al = f4(0.f);
   if (act == GCNX_ACT_PRELU) al = ld4g(alpha + c, false, valid);
   const float4 sc = make_float4(ga.x * iv.x, ga.y * iv.y, ga.z * iv.z, ga.w * iv.w);
-  for (int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.y * 4) {
-    const float4 v = ld4g(z + r * ldz + c, v4, valid);
+  auto apply = [&](float4 v) {
     float4 o = make_float4((v.x - mu.x) * sc.x + be.x, (v.y - mu.y) * sc.y + be.y, (v.z - mu.z) * sc.z + be.z,
                            (v.w - mu.w) * sc.w + be.w);
     if (act == GCNX_ACT_RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     else if (act == GCNX_ACT_PRELU) o = make_float4(prelu(o.x, al.x), prelu(o.y, al.y), prelu(o.z, al.z), prelu(o.w, al.w));
-    st4g(y + r * ldy + c, o, v4, valid);
+    return o;
+  };
+  const int64_t step = (int64_t)gridDim.y * 4;
+  int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (vec && (int)blockIdx.x * 256 + 256 <= f) {           // aligned full tile (uniform): two rows' loads in flight
+    for (; r + step < n; r += 2 * step) {
+      const float4 v0 = *reinterpret_cast<const float4*>(z + r * ldz + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(z + (r + step) * ldz + c);
+      *reinterpret_cast<float4*>(y + r * ldy + c) = apply(v0);
+      *reinterpret_cast<float4*>(y + (r + step) * ldy + c) = apply(v1);
+    }
   }
+  for (; r < n; r += step) st4g(y + r * ldy + c, apply(ld4g(z + r * ldz + c, v4, valid)), v4, valid);
 }
 
 struct BnCols { float4 mu, iv, ga, be, al; };
@@ -233,8 +263,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
   const int valid0 = f - c;
   BnCols q{};
   if (valid0 > 0) q = bn_cols(mean, inv, gamma, beta, alpha, act, c, valid0);
-  colsums<3>(n, f, part, [&](int64_t r, int cc, int valid, float4 (&t)[3]) {
-    const bool v4 = vec && valid >= 4;
+  colsums<3>(n, f, part, vec && (int)blockIdx.x * 64 + 64 <= f, [&](int64_t r, int cc, int valid, float4 (&t)[3], auto fast) {
+    const bool v4 = decltype(fast)::value || (vec && valid >= 4);
     const float4 d = ld4g(dy + r * lddy + cc, v4, valid), zz = ld4g(z + r * ldz + cc, v4, valid);
     float4 xh;
     bn_bwd_terms(d.x, zz.x, q.mu.x, q.iv.x, q.ga.x, q.be.x, q.al.x, act, t[0].x, xh.x, t[2].x);
@@ -267,8 +297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     s1 = make_float4(s1.x * ic, s1.y * ic, s1.z * ic, s1.w * ic);
     s2 = make_float4(s2.x * ic, s2.y * ic, s2.z * ic, s2.w * ic);
   }
-  for (int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.y * 4) {
-    const float4 d = ld4g(dy + r * lddy + c, v4, valid), zz = ld4g(z + r * ldz + c, v4, valid);
+  auto grad = [&](float4 d, float4 zz) {
     float4 g, xh, unused;
     bn_bwd_terms(d.x, zz.x, q.mu.x, q.iv.x, q.ga.x, q.be.x, q.al.x, act, g.x, xh.x, unused.x);
     bn_bwd_terms(d.y, zz.y, q.mu.y, q.iv.y, q.ga.y, q.be.y, q.al.y, act, g.y, xh.y, unused.y);
@@ -279,8 +308,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     o.y = q.ga.y * q.iv.y * (g.y - s1.y - xh.y * s2.y);
     o.z = q.ga.z * q.iv.z * (g.z - s1.z - xh.z * s2.z);
     o.w = q.ga.w * q.iv.w * (g.w - s1.w - xh.w * s2.w);
-    st4g(dz + r * lddz + c, o, v4, valid);
+    return o;
+  };
+  const int64_t step = (int64_t)gridDim.y * 4;
+  int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (vec && (int)blockIdx.x * 256 + 256 <= f) {           // aligned full tile (uniform): two rows' loads in flight
+    for (; r + step < n; r += 2 * step) {
+      const float4 d0 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+      const float4 z0 = *reinterpret_cast<const float4*>(z + r * ldz + c);
+      const float4 d1 = *reinterpret_cast<const float4*>(dy + (r + step) * lddy + c);
+      const float4 z1 = *reinterpret_cast<const float4*>(z + (r + step) * ldz + c);
+      *reinterpret_cast<float4*>(dz + r * lddz + c) = grad(d0, z0);
+      *reinterpret_cast<float4*>(dz + (r + step) * lddz + c) = grad(d1, z1);
+    }
   }
+  for (; r < n; r += step)
+    st4g(dz + r * lddz + c, grad(ld4g(dy + r * lddy + c, v4, valid), ld4g(z + r * ldz + c, v4, valid)), v4, valid);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
