@@ -364,24 +364,35 @@ struct __attribute__((aligned(4))) I2u { int x, y; };
 // fetched entry instead of once per lane that consumes the broadcast.
 __device__ __forceinline__ int tile_off(int row, int scale) { return row * scale; }
 
+// The two index arrays as raw buffer resources (base, size in bytes): buffer loads are range-checked per dword by
+// the memory pipeline -- a lane whose slot is past the row end is given an out-of-range offset and reads zeros
+// WITHOUT a fetch and without a branch, and a dwordx4 that straddles the end of the array returns its valid dwords.
+struct EntryBufs {
+  __amdgpu_buffer_rsrc_t col, val;
+};
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ EntryBufs entry_bufs(const int32_t* colidx, const float* vals, int nnz) {
+  EntryBufs r;
+  r.col = __builtin_amdgcn_make_buffer_rsrc((void*)colidx, (short)0, nnz * 4, 0x00020000);
+  r.val = __builtin_amdgcn_make_buffer_rsrc((void*)(vals ? (const void*)vals : (const void*)colidx), (short)0, nnz * 4, 0x00020000);
+  return r;
+}
+
 template <bool WEIGHTED, int SCALE = 1>
-__device__ __forceinline__ void fetch_entries(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-                                              int e0, int slot, int b, int row0, int pad, int last4, int (&mc)[4],
-                                              float (&mv)[4]) {
-  // (A branch-free variant -- clamped address, select afterwards -- measured 10 % slower end to end: it also
-  // fetches for the slots past the row end.)
+__device__ __forceinline__ void fetch_entries(const EntryBufs& eb, int e0, int slot, int b, int row0, int pad,
+                                              int (&mc)[4], float (&mv)[4]) {
+  // Branch-free: with each load inside `if (slot has entries)` hipcc closed every one of a unit's 2 x NI index
+  // loads with its own s_waitcnt vmcnt(0) -- ten dependent round trips per unit where one is needed.  (Clamping the
+  // address instead measured 10 % slower: the slots past the row end then fetch too; out-of-range buffer lanes don't.)
   const int e = e0 + 4 * slot;
-  int c0 = pad, c1 = pad, c2 = pad, c3 = pad;
+  const unsigned off = e < b ? (unsigned)e * 4u : 0xFFFFFFF0u;
+  const i32x4 c = __builtin_amdgcn_raw_buffer_load_b128(eb.col, off, 0, 0);
+  const int c0 = c.x, c1 = c.y, c2 = c.z, c3 = c.w;
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  if (e < b) {
-    if (e <= last4) {
-      const I4u c = *reinterpret_cast<const I4u*>(colidx + e);
-      c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
-      if (WEIGHTED) { const F4u v = *reinterpret_cast<const F4u*>(vals + e); v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w; }
-    } else {  // the last three entries of the whole matrix
-      c0 = colidx[e]; if (e + 1 < b) c1 = colidx[e + 1]; if (e + 2 < b) c2 = colidx[e + 2];
-      if (WEIGHTED) { v0 = vals[e]; if (e + 1 < b) v1 = vals[e + 1]; if (e + 2 < b) v2 = vals[e + 2]; }
-    }
+  if (WEIGHTED) {
+    const i32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(eb.val, off, 0, 0);
+    v0 = __int_as_float(vb.x); v1 = __int_as_float(vb.y); v2 = __int_as_float(vb.z); v3 = __int_as_float(vb.w);
   }
   mc[0] = tile_off(e + 0 < b ? c0 - row0 : pad, SCALE);  mv[0] = e + 0 < b ? v0 : 0.f;
   mc[1] = tile_off(e + 1 < b ? c1 - row0 : pad, SCALE);  mv[1] = e + 1 < b ? v1 : 0.f;
@@ -411,12 +422,11 @@ __device__ __forceinline__ void tile_load_rowptr(const int32_t* __restrict__ row
 
 // Part 2: the first 16 entries of each of those rows.
 template <int NI, bool WEIGHTED, int SCALE>
-__device__ __forceinline__ void tile_load_entries(const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-                                                  int row0, int pad, int last4, const int (&a)[NI], const int (&b)[NI],
-                                                  int (&mc)[NI][4], float (&mv)[NI][4]) {
+__device__ __forceinline__ void tile_load_entries(const EntryBufs& eb, int row0, int pad, const int (&a)[NI],
+                                                  const int (&b)[NI], int (&mc)[NI][4], float (&mv)[NI][4]) {
 #pragma unroll
   for (int t = 0; t < NI; ++t)
-    fetch_entries<WEIGHTED, SCALE>(colidx, vals, a[t], threadIdx.x & 3, b[t], row0, pad, last4, mc[t], mv[t]);
+    fetch_entries<WEIGHTED, SCALE>(eb, a[t], threadIdx.x & 3, b[t], row0, pad, mc[t], mv[t]);
 }
 
 
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
   int u = unit_of(0);
   if (u >= nunits) return;                      // uniform per workgroup
   if (tid < FT) lds[CAP * FT + tid] = 0.f;      // the all-zero row padding entries point at
-  const int last4 = rowptr[n] - 4;
+  const EntryBufs ebufs = entry_bufs(colidx, vals, rowptr[n]);
 
   int2 g = graphs[u / upg];
   for (int round = 0;; ++round) {
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
     {
       int a[NI], b[NI];
       tile_load_rowptr<NI, SPAN, LPR>(rowptr, g.x, g.y, a, b);
-      if (!(dbg & 8)) tile_load_entries<NI, WEIGHTED, RB>(colidx, vals, g.x, CAP, last4, a, b, mc, mv);
+      if (!(dbg & 8)) tile_load_entries<NI, WEIGHTED, RB>(ebufs, g.x, CAP, a, b, mc, mv);
     }
     for (int s = 0; s < sg; ++s) {
       const int c0 = cbase + s * FT;
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           while (__builtin_amdgcn_ballot_w64(base < bt) != 0) {   // rows longer than 16 entries (2 % at degree 10)
             int xc[4];
             float xv[4];
-            fetch_entries<WEIGHTED, RB>(colidx, vals, base, slot, bt, g.x, CAP, last4, xc, xv);
+            fetch_entries<WEIGHTED, RB>(ebufs, base, slot, bt, g.x, CAP, xc, xv);
             GCNX_DSTEP4(0, xc, xv, base, bt)
             GCNX_DSTEP4(1, xc, xv, base, bt)
             GCNX_DSTEP4(2, xc, xv, base, bt)
