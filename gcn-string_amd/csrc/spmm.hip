@@ -44,6 +44,8 @@ constexpr int kLongRowSmall = 256;    // rows with more entries are split over t
 constexpr int kLongRowLarge = 32;     // (latency regime: a chunk below the limit skips the hub phase outright) / 32-row chunks
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 // Packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of fp32 per instruction at full rate).  The row gather
 // is not pure memory time: at config 2 each launch issues ~150 k wave-level float4 loads, and with one VALU
 // instruction per component the accumulation alone was >1 us of the kernel (the folded backward's mask: 3 us).
@@ -195,6 +197,11 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     }
   };
   constexpr int kLongRow = RPC <= 8 ? kLongRowSmall : kLongRowLarge;
+  // h as a raw buffer resource (range-checked loads for the row tails); usable while byte offsets fit 32 bits
+  const bool use_buf = (uint64_t)n * (uint64_t)ldh * 4u < 0xFFFFFF00ull;
+  const __amdgpu_buffer_rsrc_t hbuf =
+      __builtin_amdgcn_make_buffer_rsrc((void*)h, (short)0, use_buf ? (int)((uint64_t)n * (uint64_t)ldh * 4u) : 0, 0x00020000);
+  const unsigned ld32 = (unsigned)ldh;
   bool saw_long = false;
   // Two instances of the row loop: chunks whose entries all fit the LDS stage (every chunk but those with hub rows)
   // take the one WITHOUT the global-index fallback.  With the fallback in the loop, hipcc's wait-count pass must
@@ -243,29 +250,42 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
           eA += 2 * G;
           eB += 2 * G;
         }
-        // The tails, branch-free as well: a missing entry reads row 0 and is discarded by selects (not by a zero
-        // weight: 0 * inf would poison the sum), so both rows' loads are issued together here too.
+        // The row tails, branch-free: h is read through a raw buffer resource, a missing entry gets an
+        // out-of-range offset and comes back as zeros -- no fetch, no branch, nothing to discard -- so the tail's
+        // loads (2 rows x 2 neighbour groups) are issued together like a full trip's.
         const int rem = max(bA - aA, bB - aB) - nfull * 2 * G;     // uniform per wave
         const int last = max(staged - 1, 0);
-        if (RPC > 8)                                               // (8-row chunks: the conditional loop below measured 5 % faster)
-        for (int t = 0; t < rem; t += G) {                         // G entries of both rows per step
-          const bool okA = eA < bA, okB = eB < bB;
-          const int cA = okA ? s_col[min(eA, last)] : 0, cB = okB ? s_col[min(eB, last)] : 0;
-          float4 hA = *reinterpret_cast<const float4*>(h + (int64_t)cA * ldh + c);
-          float4 hB = *reinterpret_cast<const float4*>(h + (int64_t)cB * ldh + c);
-          float wA = 1.f, wB = 1.f;
-          if (WEIGHTED) { wA = s_val[min(eA, last)]; wB = s_val[min(eB, last)]; }
-          if (FOLD) { hA = f4_step(hA); hB = f4_step(hB); }
-          hA.x = okA ? hA.x : 0.f; hA.y = okA ? hA.y : 0.f; hA.z = okA ? hA.z : 0.f; hA.w = okA ? hA.w : 0.f;   // per component:
-          hB.x = okB ? hB.x : 0.f; hB.y = okB ? hB.y : 0.f; hB.z = okB ? hB.z : 0.f; hB.w = okB ? hB.w : 0.f;   // a float4 select goes through scratch
-          wA = okA ? wA : 0.f; wB = okB ? wB : 0.f;
-          if (WEIGHTED) { accA = f4_fma(wA, hA, accA); accB = f4_fma(wB, hB, accB); }
-          else { accA = f4_add(accA, hA); accB = f4_add(accB, hB); }
-          eA += G;
-          eB += G;
+        if (use_buf)
+        for (int t = 0; t < rem; t += 2 * G) {
+          const bool okA0 = eA < bA, okA1 = eA + G < bA, okB0 = eB < bB, okB1 = eB + G < bB;
+          const unsigned oA0 = okA0 ? ((unsigned)s_col[min(eA, last)] * ld32 + (unsigned)c) * 4u : 0xFFFFFFF0u;
+          const unsigned oA1 = okA1 ? ((unsigned)s_col[min(eA + G, last)] * ld32 + (unsigned)c) * 4u : 0xFFFFFFF0u;
+          const unsigned oB0 = okB0 ? ((unsigned)s_col[min(eB, last)] * ld32 + (unsigned)c) * 4u : 0xFFFFFFF0u;
+          const unsigned oB1 = okB1 ? ((unsigned)s_col[min(eB + G, last)] * ld32 + (unsigned)c) * 4u : 0xFFFFFFF0u;
+          const f32x4v rA0 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hbuf, oA0, 0, 0));
+          const f32x4v rA1 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hbuf, oA1, 0, 0));
+          const f32x4v rB0 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hbuf, oB0, 0, 0));
+          const f32x4v rB1 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hbuf, oB1, 0, 0));
+          float wA0 = 1.f, wA1 = 1.f, wB0 = 1.f, wB1 = 1.f;
+          if (WEIGHTED) {
+            wA0 = s_val[min(eA, last)]; wA1 = s_val[min(eA + G, last)];
+            wB0 = s_val[min(eB, last)]; wB1 = s_val[min(eB + G, last)];
+          }
+          float4 hA0 = make_float4(rA0.x, rA0.y, rA0.z, rA0.w), hA1 = make_float4(rA1.x, rA1.y, rA1.z, rA1.w);
+          float4 hB0 = make_float4(rB0.x, rB0.y, rB0.z, rB0.w), hB1 = make_float4(rB1.x, rB1.y, rB1.z, rB1.w);
+          if (FOLD) { hA0 = f4_step(hA0); hA1 = f4_step(hA1); hB0 = f4_step(hB0); hB1 = f4_step(hB1); }
+          if (WEIGHTED) {
+            accA = f4_fma(wA0, hA0, accA); accB = f4_fma(wB0, hB0, accB);
+            accA = f4_fma(wA1, hA1, accA); accB = f4_fma(wB1, hB1, accB);
+          } else {
+            accA = f4_add(accA, hA0); accB = f4_add(accB, hB0);
+            accA = f4_add(accA, hA1); accB = f4_add(accB, hB1);
+          }
+          eA += 2 * G;
+          eB += 2 * G;
         }
       }
-      if (!kAllStaged || RPC <= 8)
+      if (!kAllStaged || !use_buf)
       while (eA < bA || eB < bB) {                                 // (the instance with the global-index fallback)
         float4 hA[2], hB[2];
         float vA[2], vB[2];
@@ -370,8 +390,6 @@ __device__ __forceinline__ int tile_off(int row, int scale) { return row * scale
 struct EntryBufs {
   __amdgpu_buffer_rsrc_t col, val;
 };
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ EntryBufs entry_bufs(const int32_t* colidx, const float* vals, int nnz) {
   EntryBufs r;
   r.col = __builtin_amdgcn_make_buffer_rsrc((void*)colidx, (short)0, nnz * 4, 0x00020000);
