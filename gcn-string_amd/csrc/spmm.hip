@@ -318,13 +318,45 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   // a quarter of its entries and the four partial sums are combined in wave order (deterministic).
   if (e1 - e0 <= kLongRow) return;               // no row of this chunk can be that long (uniform)
   if (!__syncthreads_or(saw_long)) return;       // ... and none was (one barrier; the scan below costs more)
+  const int nnz_all = rowptr[n];
   for (int r = r0; r < r1; ++r) {                // uniform over the workgroup
     const int a = s_rp[r - r0] - e0, b = s_rp[r - r0 + 1] - e0;
     if (b - a <= kLongRow) continue;
     const int per = (b - a + 3) / 4;
     const int wa = a + wave * per, wb = min(b, wa + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col_ok) {
+    if (RPC > 8 && col_ok && use_buf) {          // (not in the 8-row instance: its registers are spoken for)
+      // Branch-free through range-checked buffer loads (indices straight from the CSR arrays, then the feature
+      // rows): a slot past this wave's share gets out-of-range offsets and contributes zeros.  HU entries per
+      // lane group and trip, so HU index loads and then HU gathers are in flight -- as conditional loads they
+      // ran one by one, and a 4096-entry row is 128+ trips.
+      const __amdgpu_buffer_rsrc_t cbuf = __builtin_amdgcn_make_buffer_rsrc((void*)colidx, (short)0, nnz_all * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t vbuf =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(WEIGHTED ? (const void*)vals : (const void*)colidx), (short)0, nnz_all * 4, 0x00020000);
+      constexpr int HU = LPR == 64 ? 8 : 4;          // entries per lane group and trip (register budget)
+      for (int e = wa + g; e < wb; e += HU * G) {
+        int ci[HU];
+        float wv[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+          const unsigned off = e + u * G < wb ? (unsigned)(e0 + e + u * G) * 4u : 0xFFFFFFF0u;
+          ci[u] = __builtin_amdgcn_raw_buffer_load_b32(cbuf, off, 0, 0);
+          wv[u] = WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f;
+        }
+        f32x4v hv[HU];
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+          const unsigned off = e + u * G < wb ? ((unsigned)ci[u] * ld32 + (unsigned)c) * 4u : 0xFFFFFFF0u;
+          hv[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hbuf, off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+          float4 t = make_float4(hv[u].x, hv[u].y, hv[u].z, hv[u].w);
+          if (FOLD) t = f4_step(t);
+          acc = WEIGHTED ? f4_fma(wv[u], t, acc) : f4_add(acc, t);
+        }
+      }
+    } else if (col_ok) {
       for (int e = wa + g; e < wb; e += 4 * G) {      // four neighbours in flight per lane
         float4 hv[4];
         float vv[4];
