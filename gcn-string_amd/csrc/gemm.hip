@@ -330,37 +330,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   splitk_reduce_body(part, slab, nsplit, out, total, blockIdx.x, s);
 }
 
-// The last gradient and the optimizer step in one launch (gcnx_gemm_dw_sgd): workgroups [0, n_s) fold the split-K
-// slabs into dW -- an interval [off, off + total) of the flat gradient buffer -- and update those parameters;
-// the rest apply p -= lr * g to the other parameters, 256 per workgroup.
+// The last gradient and the optimizer step in one launch (gcnx_gemm_dw_sgd).  Workgroups, in order:
+//   [0, n_s)        fold this call's split-K slabs into dW (an interval of the flat gradient buffer) and update it;
+//   [.., + n_pc)    fold a PENDING column-sum reduction (gcnx_dense_bwd_deferred) and update its parameters;
+//   [.., + n_ps)    fold a PENDING split-K reduction and update its parameters;
+//   the rest        p -= lr * g for every parameter outside those three intervals, 256 per workgroup.
+struct SgdPending {
+  const float* cpart; int64_t crows; int32_t cf; int64_t coff;      // partial rows -> grads[coff, coff + cf)
+  const float* slabs; int64_t total; int32_t nsplit; int64_t soff;  // slabs -> grads[soff, soff + total)
+  int n_pc, n_ps;
+};
+
+__device__ __forceinline__ float splitk_sum(const float* __restrict__ part, int64_t slab, int nsplit, int64_t i,
+                                            int64_t total, float (*s)[64]) {
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (i < total) {
+    const int per = (nsplit + 3) / 4;
+    const int z0 = grp * per, z1 = min(nsplit, z0 + per);
+#pragma unroll 4
+    for (int z = z0; z < z1; ++z) acc += part[(int64_t)z * slab + i];
+  }
+  s[grp][el] = acc;
+  __syncthreads();
+  return (s[0][el] + s[1][el]) + (s[2][el] + s[3][el]);              // the order of splitk_reduce_kernel
+}
+
 __global__ __launch_bounds__(256) void reduce_sgd_kernel(const float* __restrict__ part, int64_t slab, int nsplit,
                                                          int64_t total, int n_s, float* __restrict__ params,
                                                          float* __restrict__ grads, int64_t off, int64_t n_params,
-                                                         float lr) {
-  __shared__ float s[4][64];
-  if ((int)blockIdx.x < n_s) {
-    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + el;
-    float acc = 0.f;
-    if (i < total) {
-      const int per = (nsplit + 3) / 4;
-      const int z0 = grp * per, z1 = min(nsplit, z0 + per);
-#pragma unroll 4
-      for (int z = z0; z < z1; ++z) acc += part[(int64_t)z * slab + i];
-    }
-    s[grp][el] = acc;
-    __syncthreads();
-    if (grp == 0 && i < total) {
-      const float g = (s[0][el] + s[1][el]) + (s[2][el] + s[3][el]);      // the order of splitk_reduce_kernel
-      grads[off + i] = g;
-      params[off + i] = params[off + i] - lr * g;
+                                                         float lr, SgdPending pd) {
+  __shared__ float4 s4[128][2];
+  float (*s)[64] = reinterpret_cast<float(*)[64]>(&s4[0][0]);
+  int bid = blockIdx.x;
+  if (bid < n_s) {
+    const int64_t i = (int64_t)bid * 64 + (threadIdx.x & 63);
+    const float g = splitk_sum(part, slab, nsplit, i, total, s);
+    if ((threadIdx.x >> 6) == 0 && i < total) { grads[off + i] = g; params[off + i] = params[off + i] - lr * g; }
+    return;
+  }
+  bid -= n_s;
+  if (bid < pd.n_pc) {
+    gcnx_colpart_reduce_body(pd.cpart, pd.crows, pd.cf, grads + pd.coff, bid, s4);       // writes grads (all threads sync inside)
+    const int cl = threadIdx.x & 1, c = bid * 8 + cl * 4;
+    if ((threadIdx.x >> 1) == 0 && c < pd.cf) {
+      const float4 g = s4[0][cl];
+      float* p = params + pd.coff + c;
+      p[0] -= lr * g.x; p[1] -= lr * g.y; p[2] -= lr * g.z; p[3] -= lr * g.w;
     }
     return;
   }
-  // the parameters outside [off, off + total): indices [0, off) then [off + total, n_params)
-  int64_t i = (int64_t)(blockIdx.x - n_s) * 256 + threadIdx.x;
-  if (i >= off) i += total;
-  if (i < n_params) params[i] = params[i] - lr * grads[i];
+  bid -= pd.n_pc;
+  if (bid < pd.n_ps) {
+    const int64_t i = (int64_t)bid * 64 + (threadIdx.x & 63);
+    const float g = splitk_sum(pd.slabs, pd.total, pd.nsplit, i, pd.total, s);
+    if ((threadIdx.x >> 6) == 0 && i < pd.total) { grads[pd.soff + i] = g; params[pd.soff + i] = params[pd.soff + i] - lr * g; }
+    return;
+  }
+  bid -= pd.n_ps;
+  const int64_t i = (int64_t)bid * 256 + threadIdx.x;
+  if (i >= n_params) return;
+  if (i >= off && i < off + total) return;
+  if (pd.n_pc && i >= pd.coff && i < pd.coff + pd.cf) return;
+  if (pd.n_ps && i >= pd.soff && i < pd.soff + pd.total) return;
+  params[i] = params[i] - lr * grads[i];
 }
 
 // Both second stages of gcnx_dense_bwd in one launch: workgroups [0, n_c) fold the dX epilogue's partial column
@@ -718,10 +751,60 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
   return GCNX_OK;
 }
 
+}  // extern "C"
+
+// nsplit / kchunk of the dW part of the fused dense backward (shared by the sizing helper and the launcher)
+static int dense_bwd_split(const gcnx_ctx* ctx, int64_t n, int32_t fi, int32_t fo, int64_t* kchunk_out) {
+  const int64_t gy = gcnx_cdiv(n, BM);
+  const int n_dx = (int)gy * (fi / BN);
+  const int tiles = gcnx_cdiv(fi, BM) * gcnx_cdiv(fo, BN);
+  const int slots = 4 * ctx->num_cus;
+  int spare = slots - n_dx % slots;
+  if (spare < slots / 4) spare += slots;
+  int nsplit = spare / tiles;
+  const int64_t ksteps = (n + BK - 1) / BK;
+  if (nsplit > ksteps / kMinSliceSteps) nsplit = (int)(ksteps / kMinSliceSteps);
+  if (nsplit < 1) nsplit = 1;
+  const int64_t kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
+  if (kchunk_out) *kchunk_out = kchunk;
+  return (int)((n + kchunk - 1) / kchunk);
+}
+
+static int dense_bwd_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, const float* w, int64_t n,
+                          int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx, const float* y_mask, int64_t ldy,
+                          float* db_prev, float* dw, float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending);
+
+extern "C" {
+
 int gcnx_dense_bwd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, const float* w, int64_t n,
                    int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx, const float* y_mask, int64_t ldy,
                    float* db_prev, float* dw) {
+  return dense_bwd_impl(ctx, x, ldx, dh, lddh, w, n, fi, fo, prec, dx, lddx, y_mask, ldy, db_prev, dw, nullptr, 0, nullptr);
+}
+
+int64_t gcnx_dense_bwd_scratch_floats(gcnx_ctx* ctx, int64_t n, int32_t fi, int32_t fo) {
+  if (!ctx || n <= 0 || fi <= 0 || fo <= 0 || fi % BN != 0) return 0;
+  const int nsplit = dense_bwd_split(ctx, n, fi, fo, nullptr);
+  return ((2 * (int64_t)gcnx_cdiv(n, BM) * fi + 63) & ~(int64_t)63) + (int64_t)nsplit * fi * fo;
+}
+
+int gcnx_dense_bwd_deferred(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, const float* w,
+                            int64_t n, int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx, const float* y_mask,
+                            int64_t ldy, float* db_prev, float* dw, float* scratch, int64_t scratch_floats,
+                            gcnx_pending_reduce* pending) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, pending != nullptr, "gcnx_dense_bwd_deferred: pending is NULL");
+  return dense_bwd_impl(ctx, x, ldx, dh, lddh, w, n, fi, fo, prec, dx, lddx, y_mask, ldy, db_prev, dw, scratch, scratch_floats,
+                        pending);
+}
+
+}  // extern "C"
+
+static int dense_bwd_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, const float* w, int64_t n,
+                          int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx, const float* y_mask, int64_t ldy,
+                          float* db_prev, float* dw, float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending) {
+  GCNX_CHECK_CTX(ctx);
+  if (pending) *pending = gcnx_pending_reduce{nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr};
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_dense_bwd: negative size");
   GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_dense_bwd: unknown precision %d", prec);
   GCNX_REQUIRE(ctx, dx && dw, "gcnx_dense_bwd: dx and dw are both required (use gcnx_gemm_dx / gcnx_gemm_dw for one of them)");
@@ -737,26 +820,25 @@ int gcnx_dense_bwd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, 
   GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo && lddx >= fi && (!y_mask || ldy >= fi), "gcnx_dense_bwd: leading dimension too small");
   // dX tiles, then as many dW split-K slices as fill the rest of the resident-workgroup slots (4 per CU)
   const int n_dx = (int)gy * (fi / BN);
-  const int tiles = gcnx_cdiv(fi, BM) * gcnx_cdiv(fo, BN);
-  const int slots = 4 * ctx->num_cus;
-  int spare = slots - n_dx % slots;
-  if (spare < slots / 4) spare += slots;
-  int nsplit = spare / tiles;
-  const int64_t ksteps = (n + BK - 1) / BK;
-  if (nsplit > ksteps / kMinSliceSteps) nsplit = (int)(ksteps / kMinSliceSteps);
-  if (nsplit < 1) nsplit = 1;
-  const int64_t kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
-  nsplit = (int)((n + kchunk - 1) / kchunk);
-  // workspace: [dX column-sum partials (2 per row tile) | dW slabs]
+  int64_t kchunk = 0;
+  const int nsplit = dense_bwd_split(ctx, n, fi, fo, &kchunk);
+  // partial results: [dX column-sum partials (2 per row tile) | dW slabs] -- in the ctx workspace, or (deferred
+  // reduction) in the caller's scratch, where they stay until gcnx_gemm_dw_sgd folds them
   const int64_t prow = db_prev ? 2 * gy : 0;
   const size_t part_floats = ((size_t)prow * fi + 63) & ~(size_t)63;
   const size_t slab_floats = nsplit > 1 ? (size_t)nsplit * fi * fo : 0;
-  if (part_floats + slab_floats) {
-    int rc = gcnx_ws_reserve(ctx, (part_floats + slab_floats) * sizeof(float));
-    if (rc) return rc;
+  const bool defer = pending && scratch && al16(scratch) && (size_t)scratch_floats >= part_floats + slab_floats &&
+                     (prow > 0 || nsplit > 1);
+  float* base = scratch;
+  if (!defer) {
+    if (part_floats + slab_floats) {
+      int rc = gcnx_ws_reserve(ctx, (part_floats + slab_floats) * sizeof(float));
+      if (rc) return rc;
+    }
+    base = (float*)ctx->ws;
   }
-  float* colpart = db_prev ? (float*)ctx->ws : nullptr;
-  float* slabs = (float*)ctx->ws + part_floats;
+  float* colpart = db_prev ? base : nullptr;
+  float* slabs = base + part_floats;
   GemmJob jx{dh, lddh, w, (int64_t)fo, dx, lddx, n, fi, (int64_t)fo, (int64_t)fo + BK,
              Epilogue{nullptr, nullptr, y_mask, ldy, GCNX_ACT_NONE, 0, 1, colpart},
              al16(dh) && lddh % 4 == 0, al16(w) && fo % 4 == 0, fi / BN, (int)gy, 1};
@@ -768,6 +850,11 @@ int gcnx_dense_bwd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, 
   const int n_c = db_prev ? gcnx_cdiv(fi, 8) : 0;
   const int64_t total = (int64_t)fi * fo;
   const int n_s = nsplit > 1 ? gcnx_cdiv(total, 64) : 0;
+  if (defer) {
+    *pending = gcnx_pending_reduce{colpart, prow, db_prev ? fi : 0, db_prev, nsplit > 1 ? slabs : nullptr,
+                                   nsplit > 1 ? total : 0, nsplit > 1 ? nsplit : 0, nsplit > 1 ? dw : nullptr};
+    return GCNX_OK;
+  }
   if (n_c + n_s > 0) {
     hipLaunchKernelGGL(reduce_duo_kernel, dim3(n_c + n_s), dim3(256), 0, ctx->stream, (const float*)colpart, prow, fi,
                        db_prev, n_c, (const float*)slabs, total, nsplit, dw, total);
@@ -775,6 +862,8 @@ int gcnx_dense_bwd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, 
   }
   return GCNX_OK;
 }
+
+extern "C" {
 
 int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n,
                  int32_t fi, int32_t fo, int prec) {
@@ -853,9 +942,29 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   return GCNX_OK;
 }
 
+// Runs a pending reduction on its own (the fallback paths of gcnx_gemm_dw_sgd).
+static int flush_pending(gcnx_ctx* ctx, const gcnx_pending_reduce* pd) {
+  if (!pd || (!pd->colpart && !pd->slabs)) return GCNX_OK;
+  const int n_c = pd->colpart ? gcnx_cdiv(pd->cf, 8) : 0;
+  const int n_s = pd->slabs ? gcnx_cdiv(pd->total, 64) : 0;
+  hipLaunchKernelGGL(reduce_duo_kernel, dim3(n_c + n_s), dim3(256), 0, ctx->stream, pd->colpart, pd->crows, pd->cf, pd->cout,
+                     n_c, pd->slabs, pd->total, pd->nsplit, pd->out, pd->total);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
 int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n,
-                     int32_t fi, int32_t fo, int prec, float* params, float* grads, int64_t n_params, float lr) {
+                     int32_t fi, int32_t fo, int prec, float* params, float* grads, int64_t n_params, float lr,
+                     const gcnx_pending_reduce* pending) {
   GCNX_CHECK_CTX(ctx);
+  if (pending && !pending->colpart && !pending->slabs) pending = nullptr;
+  if (pending) {
+    GCNX_REQUIRE(ctx, !pending->colpart || (pending->cout >= grads && pending->cout + pending->cf <= grads + n_params &&
+                                            pending->cf % 4 == 0 && al16(pending->cout)),
+                 "gcnx_gemm_dw_sgd: the pending column sums must land (16-byte aligned) inside the flat gradient buffer");
+    GCNX_REQUIRE(ctx, !pending->slabs || (pending->out >= grads && pending->out + pending->total <= grads + n_params),
+                 "gcnx_gemm_dw_sgd: the pending split-K result must land inside the flat gradient buffer");
+  }
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0 && n_params >= 0, "gcnx_gemm_dw_sgd: negative size");
   GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dw_sgd: unknown precision %d", prec);
   GCNX_REQUIRE(ctx, n_params == 0 || (params && grads), "gcnx_gemm_dw_sgd: NULL pointer");
@@ -874,8 +983,10 @@ int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh
     kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
     nsplit = (int)((n + kchunk - 1) / kchunk);
   }
-  if (nsplit <= 1 || fo % 4 != 0) {   // nothing to reduce (or bf16 / ragged): the two calls
-    int rc = gcnx_gemm_dw(ctx, x, ldx, dh, lddh, dw, n, fi, fo, prec);
+  if (nsplit <= 1 || fo % 4 != 0) {   // nothing to reduce (or bf16 / ragged): the separate calls
+    int rc = flush_pending(ctx, pending);
+    if (rc) return rc;
+    rc = gcnx_gemm_dw(ctx, x, ldx, dh, lddh, dw, n, fi, fo, prec);
     if (rc) return rc;
     return gcnx_sgd(ctx, params, grads, n_params, lr);
   }
@@ -889,9 +1000,16 @@ int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh
   hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, ctx->stream, x, ldx, dh, lddh, (float*)ctx->ws,
                      (int64_t)fo, (int64_t)fi, fo, n, kchunk, ep, va, vb);
   GCNX_LAUNCH_OK(ctx);
-  const int n_s = gcnx_cdiv(total, 64), n_o = gcnx_cdiv(n_params - total, 256);
-  hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + n_o), dim3(256), 0, ctx->stream, (const float*)ctx->ws, total, nsplit,
-                     total, n_s, params, grads, (int64_t)(dw - grads), n_params, lr);
+  SgdPending pd{nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0, 0};
+  if (pending) {
+    if (pending->colpart) { pd.cpart = pending->colpart; pd.crows = pending->crows; pd.cf = pending->cf;
+                            pd.coff = pending->cout - grads; pd.n_pc = gcnx_cdiv(pending->cf, 8); }
+    if (pending->slabs) { pd.slabs = pending->slabs; pd.total = pending->total; pd.nsplit = pending->nsplit;
+                          pd.soff = pending->out - grads; pd.n_ps = gcnx_cdiv(pending->total, 64); }
+  }
+  const int n_s = gcnx_cdiv(total, 64), n_o = gcnx_cdiv(n_params, 256);
+  hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
+                     total, nsplit, total, n_s, params, grads, (int64_t)(dw - grads), n_params, lr, pd);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -83,13 +83,22 @@ SIGNATURES = {
     "gcnx_bn_act_bwd_stats": [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp],
     "gcnx_bn_act_bwd_apply": [_vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _int, _vp, _vp, _f32, _int, _vp, _i64],
     "gcnx_sgd": [_vp, _vp, _vp, _i64, _f32],
-    "gcnx_gemm_dw_sgd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp, _i64, _f32],
+    "gcnx_gemm_dw_sgd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp, _i64, _f32, _vp],
+    "gcnx_dense_bwd_scratch_floats": [_vp, _i64, _i32, _i32],
+    "gcnx_dense_bwd_deferred": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                _i64, _vp],
     "gcnx_comm_unique_id": [C.c_char_p],
     "gcnx_comm_init_rank": [_vp, C.c_char_p, _int, _int, C.POINTER(_vp)],
     "gcnx_comm_destroy": [_vp],
     "gcnx_allreduce_f32": [_vp, _vp, _vp, _i64, _int],
 }
-_RESTYPE = {"gcnx_last_error": C.c_char_p}
+_RESTYPE = {"gcnx_last_error": C.c_char_p, "gcnx_dense_bwd_scratch_floats": C.c_int64}
+
+
+class PendingReduce(C.Structure):
+    """gcnx_pending_reduce (include/gcnx.h): a reduction gcnx_dense_bwd_deferred left for gcnx_gemm_dw_sgd."""
+    _fields_ = [("colpart", C.c_void_p), ("crows", C.c_int64), ("cf", C.c_int32), ("cout", C.c_void_p),
+                ("slabs", C.c_void_p), ("total", C.c_int64), ("nsplit", C.c_int32), ("out", C.c_void_p)]
 
 _lib = None
 

@@ -454,14 +454,32 @@ def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
     return dx
 
 
-def gemm_dw_sgd(ctx, x, dh, dw, params, grads, lr, prec="f32"):
+def gemm_dw_sgd(ctx, x, dh, dw, params, grads, lr, prec="f32", pending=None):
     """dw = X^T dH (a view into the flat ``grads``), then params -= lr * grads over the whole flat buffers
-    (gcnx_gemm_dw_sgd: the split-K reduction launch applies the update)."""
+    (gcnx_gemm_dw_sgd: the split-K reduction launch applies the update, and finishes a ``pending`` reduction left
+    by dense_bwd_deferred)."""
     n, fi = x.shape
     fo = dh.shape[1]
     assert dh.shape[0] == n and dw.shape == (fi, fo) and dw.contiguous and params.size == grads.size
     ctx._ck(ctx.lib.gcnx_gemm_dw_sgd(ctx.h, _p(x), x.ld, _p(dh), dh.ld, _p(dw), n, fi, fo, L.PRECS[prec], _p(params),
-                                     _p(grads), params.size, float(lr)))
+                                     _p(grads), params.size, float(lr), C.byref(pending) if pending is not None else None))
+
+
+def dense_bwd_scratch_floats(ctx, n, fi, fo):
+    return int(ctx.lib.gcnx_dense_bwd_scratch_floats(ctx.h, n, fi, fo))
+
+
+def dense_bwd_deferred(ctx, x, dh, w, dx, dw, scratch, prec="f32", y_mask=None, db_prev=None):
+    """dense_bwd whose reductions (db_prev, dw) are left in ``scratch`` for the step's last launch; returns the
+    PendingReduce to hand to gemm_dw_sgd (all zeros if the fused form did not apply: results are then final)."""
+    n, fo = dh.shape
+    fi = w.shape[0]
+    assert w.shape[1] == fo and dx.shape == (n, fi) and x.shape == (n, fi) and dw.shape == (fi, fo) and w.contiguous
+    pend = L.PendingReduce()
+    ctx._ck(ctx.lib.gcnx_dense_bwd_deferred(ctx.h, _p(x), x.ld, _p(dh), dh.ld, _p(w), n, fi, fo, L.PRECS[prec], _p(dx), dx.ld,
+                                            _p(y_mask), y_mask.ld if y_mask is not None else 0, _p(db_prev), _p(dw),
+                                            _p(scratch), scratch.size if scratch is not None else 0, C.byref(pend)))
+    return pend
 
 
 def dense_bwd(ctx, x, dh, w, dx, dw, prec="f32", y_mask=None, db_prev=None):

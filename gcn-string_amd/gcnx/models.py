@@ -230,14 +230,19 @@ class GCN2(_GraphRunner):
         if fold and os.environ.get("GCNX_DUO", "1") != "0":
             # db2 came out of the head, and dW2 shares dX's launch (gcnx_dense_bwd): one stream, no fork / join --
             # the second stream's signalling cost 25 us of a 194 us step
-            D.dense_bwd(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], prec=prec, y_mask=bufs["y1"],
-                        db_prev=g["b1"])                                       # dW2, dZ1, db1
-            D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                     # dH1 = A^T dZ1
             if lr is None:
+                D.dense_bwd(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], prec=prec, y_mask=bufs["y1"],
+                            db_prev=g["b1"])                                   # dW2, dZ1, db1
+                D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                 # dH1 = A^T dZ1
                 D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)        # dW1 = X^T dH1
                 return False
-            # the last gradient: its split-K reduction launch also applies the SGD step to every parameter
-            D.gemm_dw_sgd(ctx, batch.x, bufs["h2"], g["w1"], self.flat_p, self.flat_g.flat(0, self.n_params), lr, prec=prec)
+            # With the update in the same step, the reductions that finish the leaves dW2 / db1 wait for the last
+            # launch: the split-K reduction of dW1 folds them in and applies the SGD step to every parameter.
+            pend = D.dense_bwd_deferred(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], self._defer_scratch(batch),
+                                        prec=prec, y_mask=bufs["y1"], db_prev=g["b1"])
+            D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                     # dH1 = A^T dZ1
+            D.gemm_dw_sgd(ctx, batch.x, bufs["h2"], g["w1"], self.flat_p, self.flat_g.flat(0, self.n_params), lr, prec=prec,
+                          pending=pend)
             return True
         with ctx.side():
             if not fold:                                                       # (folded: db2 came out of the head)
@@ -247,6 +252,14 @@ class GCN2(_GraphRunner):
         D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1
         D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)                # dW1 = X^T dH1
         ctx.join()
+
+    def _defer_scratch(self, batch):
+        """Device buffer that holds the deferred partial results of layer 2's dense backward (grow-only)."""
+        need = D.dense_bwd_scratch_floats(self.ctx, batch.n, self.hidden, self.hidden)
+        cur = getattr(self, "_defer_buf", None)
+        if cur is None or cur.size < need:
+            self._defer_buf = self.ctx.empty(max(need, 4))
+        return self._defer_buf
 
     def _fold(self, batch):
         """Batches without a tile plan (the latency regime) and SUM / AVG pooling: pool' and the ReLU mask fold into

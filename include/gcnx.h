@@ -290,13 +290,34 @@ GCNX_API int gcnx_bn_act_bwd_apply(gcnx_ctx* ctx, const float* dy, int64_t lddy,
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);
+/* A reduction that gcnx_dense_bwd_deferred left undone: column-sum partial rows -> cout[cf] and split-K slabs ->
+ * out[total], both still in the caller's scratch buffer.  All zeros = nothing pending.  Plain data, no ownership. */
+typedef struct gcnx_pending_reduce {
+  const float* colpart; int64_t crows; int32_t cf; float* cout;
+  const float* slabs; int64_t total; int32_t nsplit; float* out;
+} gcnx_pending_reduce;
+
+/* gcnx_dense_bwd with its second launch (the reductions that finish db_prev and dw) left to the caller: both are
+ * gradient LEAVES that only the optimizer reads, so the step's last launch (gcnx_gemm_dw_sgd, `pending`) can fold
+ * them in -- one launch fewer on the critical path of a small batch.  The partial results stay in `scratch`
+ * (>= gcnx_dense_bwd_scratch_floats(ctx, n, fi, fo) floats, 16-byte aligned, untouched until then); db_prev / dw
+ * are NOT valid until that call.  If the fused form does not apply (precision, shapes, scratch too small) this is
+ * exactly gcnx_dense_bwd and *pending comes back all zeros. */
+GCNX_API int64_t gcnx_dense_bwd_scratch_floats(gcnx_ctx* ctx, int64_t n, int32_t fi, int32_t fo);
+GCNX_API int gcnx_dense_bwd_deferred(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh,
+                            const float* w, int64_t n, int32_t fi, int32_t fo, int prec, float* dx, int64_t lddx,
+                            const float* y_mask, int64_t ldy, float* db_prev, float* dw, float* scratch,
+                            int64_t scratch_floats, gcnx_pending_reduce* pending);
+
 /* The last gradient of a step and the optimizer apply as one call: gcnx_gemm_dw (dw = X^T dH, written into the flat
  * gradient buffer: grads <= dw, dw + fi*fo <= grads + n_params) followed by gcnx_sgd over all n_params parameters
  * (gcn.py:337-338: tape.gradient, then optimizer.apply_gradients).  Where dW is a split-K product its reduction
- * launch also applies the update (one launch instead of two); same dW and parameter bits as the two calls. */
+ * launch also applies the update (one launch instead of two); same dW and parameter bits as the two calls.
+ * pending (may be NULL): a reduction left by gcnx_dense_bwd_deferred whose results lie in the same flat gradient
+ * buffer; it is finished -- and its parameters updated -- by the same launch. */
 GCNX_API int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw,
                      int64_t n, int32_t fi, int32_t fo, int prec, float* params, float* grads, int64_t n_params,
-                     float lr);
+                     float lr, const gcnx_pending_reduce* pending);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new capability) ---- */
 GCNX_API int gcnx_comm_unique_id(char id[GCNX_UNIQUE_ID_BYTES]);

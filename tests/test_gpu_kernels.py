@@ -377,6 +377,42 @@ def test_gemm_dw_sgd_equals_gemm_dw_then_sgd_bitwise(ctx, n, fi, fo, prec):
         D.gemm_dw_sgd(ctx, x, dh, ctx.empty((fi, fo)), ctx.to_device(p0), ctx.to_device(g0), 0.05, prec=prec)
 
 
+@pytest.mark.parametrize("n,fi,fo,prec", [(20498, 128, 128, "f32"), (3000, 64, 96, "f32"), (129, 10, 6, "f32"),
+                                          (1000, 128, 128, "bf16x3")])
+def test_dense_bwd_deferred_then_gemm_dw_sgd_equals_the_separate_calls(ctx, n, fi, fo, prec):
+    """gcnx_dense_bwd_deferred leaves db_prev / dW of one layer unreduced in the caller's scratch; gcnx_gemm_dw_sgd
+    (pending=...) finishes them, reduces its own dW and updates every parameter -- the same bits as gcnx_dense_bwd +
+    gcnx_gemm_dw + gcnx_sgd.  Ragged / bf16 shapes: the deferred call degenerates to gcnx_dense_bwd (pending empty)."""
+    from gcnx import device as D
+    rng = np.random.default_rng(n + fi)
+    x1 = ctx.to_device(rng.standard_normal((n, fi), dtype=np.float32))       # layer input (also the ReLU mask source)
+    dh = ctx.to_device(rng.standard_normal((n, fo), dtype=np.float32))
+    w = ctx.to_device(rng.standard_normal((fi, fo), dtype=np.float32))
+    x0 = ctx.to_device(rng.standard_normal((n, 64), dtype=np.float32))       # the previous layer's input
+    # flat buffers: [w0 (64 x fi) | b_prev (fi) | w (fi x fo) | tail]
+    o_w0, o_b, o_w = 0, 64 * fi, 64 * fi + ((fi + 3) // 4) * 4
+    n_params = o_w + fi * fo + 37
+    p0 = rng.standard_normal(n_params).astype(np.float32); g0 = rng.standard_normal(n_params).astype(np.float32)
+    out = []
+    for deferred in (False, True):
+        params, grads = ctx.to_device(p0), ctx.to_device(g0)
+        gw0, gb, gw = grads.flat(o_w0, 64 * fi, (64, fi)), grads.flat(o_b, fi), grads.flat(o_w, fi * fo, (fi, fo))
+        dx = ctx.empty((n, fi))
+        if deferred:
+            scratch = ctx.empty(max(D.dense_bwd_scratch_floats(ctx, n, fi, fo), 4))
+            pend = D.dense_bwd_deferred(ctx, x1, dh, w, dx, gw, scratch, prec=prec, y_mask=x1, db_prev=gb)
+            assert (pend.colpart is not None) == (prec == "f32" and fi % 64 == 0)
+            D.gemm_dw_sgd(ctx, x0, dx, gw0, params, grads, 0.05, prec=prec, pending=pend)
+        else:
+            D.dense_bwd(ctx, x1, dh, w, dx, gw, prec=prec, y_mask=x1, db_prev=gb)
+            D.gemm_dw(ctx, x0, dx, gw0, prec=prec)
+            D.sgd(ctx, params, grads, 0.05)
+        out.append((params.numpy(), grads.numpy(), dx.numpy()))
+    for a0, a1 in zip(out[0], out[1]):
+        assert np.array_equal(a0, a1)
+    assert not np.array_equal(out[1][0], p0)
+
+
 def _bf16_round(x):
     """Round-to-nearest-even fp32 -> bf16 -> fp32 on the host (what v_cvt_pk_bf16_f32 does)."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)

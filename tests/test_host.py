@@ -14,7 +14,7 @@ from oracle import gcn_oracle as O
 def test_abi_exports_every_declared_symbol():
     from gcnx import _lib
     hdr = open(os.path.join(ROOT, "include", "gcnx.h")).read()
-    declared = set(re.findall(r"GCNX_API\s+(?:const\s+char\s*\*|int)\s+(gcnx_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"GCNX_API\s+(?:const\s+char\s*\*|int64_t|int)\s+(gcnx_\w+)\s*\(", hdr))
     assert len(declared) >= 35
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
