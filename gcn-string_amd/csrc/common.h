@@ -77,9 +77,10 @@ size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f);
 int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out);
 // reduce.hip: the split global pool (sum / avg).  gcnx_pool_split = slices per graph worth launching (1: none);
 // gcnx_pool_partials writes the partial row sums [nsplit][b][f] (row stride f) to `part`.
-// wgs_per_cu: first-stage workgroups per CU to aim for (2 for the stand-alone pool; 1 when the head's single
-// workgroup per 32 graphs reads the partials -- its one CU's bandwidth, ~4 us per 128 KB, is what they cost).
-int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs_per_cu);
+// half_wgs_per_cu: first-stage workgroups to aim for, in halves per CU: 4 (= 2 per CU) for the stand-alone pool; 1
+// (= one 1024-thread workgroup per two CUs) when the head's single workgroup per 32 graphs reads the partials -- its
+// one CU pulls them at ~30 GB/s, so every slice costs the head ~1.5 us per 32 KB (config 2: 2 slices beat 4 by 2.5 us).
+int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int half_wgs_per_cu);
 // cnt_part (may be NULL): per (slice, graph, column) the number of positive entries, same layout.
 int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t f,
                        int mode, int nsplit, float* part, float* cnt_part, int wide);   // wide: 1024-thread workgroups

@@ -434,11 +434,11 @@ int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f
 // Few graphs (an E. coli batch has 32) cannot fill 256 CUs with one workgroup per (graph, column tile): each
 // graph's rows are sliced over blockIdx.z (first stage, below) and the partial sums combined in workgroup order --
 // by pool_combine_kernel, or by the classifier head while it stages its operand (gcnx_pool_dense_softmax_cce).
-int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int wgs_per_cu) {
+int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int half_wgs_per_cu) {
   const int base_wgs = gcnx_cdiv(f, 64) * b;
   int nsplit = 1;
   if (mode != GCNX_POOL_MAX && base_wgs < 2 * ctx->num_cus) {
-    nsplit = (wgs_per_cu * ctx->num_cus + base_wgs - 1) / base_wgs;
+    nsplit = (half_wgs_per_cu * ctx->num_cus / 2 + base_wgs - 1) / base_wgs;
     if (nsplit < 2) nsplit = 2;
     if (nsplit > 16) nsplit = 16;
     if (const char* e = getenv("GCNX_POOL_SPLIT")) { const int v = atoi(e); if (v >= 2 && v <= 16) nsplit = v; }   // tuning knob
@@ -523,7 +523,7 @@ int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, i
   GCNX_REQUIRE(ctx, ldx >= f, "gcnx_segment_pool: leading dimension too small");
   GCNX_REQUIRE(ctx, mode != GCNX_POOL_MAX || argmax, "gcnx_segment_pool: MAX needs an argmax buffer");
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
-  const int nsplit = gcnx_pool_split(ctx, b, f, mode, 2);
+  const int nsplit = gcnx_pool_split(ctx, b, f, mode, 4);
   if (nsplit > 1) {
     int rc = gcnx_ws_reserve(ctx, (size_t)nsplit * b * f * sizeof(float));
     if (rc) return rc;
