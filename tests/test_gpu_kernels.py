@@ -185,6 +185,55 @@ def test_new_entry_points_zero_sizes_and_argument_errors(ctx):
     assert "values in and out" in _lib.last_error(h)
 
 
+def test_fused_step_entry_points_zero_sizes_and_argument_errors(ctx):
+    """Edge cases of the single-stream step's entry points (pool+head, dense backward, deferred reductions, last
+    gradient + SGD): empty inputs are no-ops that still leave defined outputs, bad arguments are GCNX_ERR_INVALID."""
+    import ctypes as C
+    from gcnx import _lib, device as D
+    from gcnx.device import Segments
+    lib, h = ctx.lib, ctx.h
+    # pool + head with no graphs: loss and the head gradients are zeroed, db_relu too (through the fallback chain)
+    buf = ctx.zeros((4, 4)); la = ctx.to_device(np.array([5.0, 5.0], np.float32)); dw = ctx.to_device(np.ones((4, 2), np.float32))
+    dbr = ctx.to_device(np.ones(4, np.float32)); gp0 = ctx.zeros(1, np.int32)
+    assert lib.gcnx_pool_dense_softmax_cce(h, gp0.ptr, buf.ptr, 4, 0, None, buf.ptr, 4, buf.ptr, None, buf.ptr, 0, 4, 2, 1.0, buf.ptr,
+                                           la.ptr, dw.ptr, None, buf.ptr, 4, dbr.ptr) == 0
+    assert not la.numpy().any() and not dw.numpy().any() and not dbr.numpy().any()
+    # db_relu needs the gradient outputs and SUM / AVG pooling
+    assert lib.gcnx_pool_dense_softmax_cce(h, gp0.ptr, buf.ptr, 4, 2, None, buf.ptr, 4, buf.ptr, None, buf.ptr, 1, 4, 2, 1.0, buf.ptr,
+                                           la.ptr, dw.ptr, None, buf.ptr, 4, dbr.ptr) == 1
+    assert "db_relu needs" in _lib.last_error(h)
+    # dense backward with no rows: dW is zeroed, dX untouched; both outputs are required
+    x0 = ctx.empty((0, 64)); dh0 = ctx.empty((0, 8)); w = ctx.zeros((64, 8)); dx0 = ctx.empty((0, 64))
+    dwz = ctx.to_device(np.ones((64, 8), np.float32)); dbz = ctx.to_device(np.ones(64, np.float32))
+    D.dense_bwd(ctx, x0, dh0, w, dx0, dwz, db_prev=dbz)
+    assert not dwz.numpy().any() and not dbz.numpy().any()
+    assert lib.gcnx_dense_bwd(h, None, 64, None, 8, w.ptr, 0, 64, 8, 0, None, 64, None, 0, None, dwz.ptr) == 1
+    assert "dx and dw are both required" in _lib.last_error(h)
+    # deferred form: scratch too small -> plain gcnx_dense_bwd, nothing pending; pending must not be NULL
+    rng = np.random.default_rng(0)
+    x = ctx.to_device(rng.standard_normal((300, 64), dtype=np.float32)); dh = ctx.to_device(rng.standard_normal((300, 8), dtype=np.float32))
+    dx, dw1, dw2, db1, db2 = ctx.empty((300, 64)), ctx.empty((64, 8)), ctx.empty((64, 8)), ctx.empty(64), ctx.empty(64)
+    pend = D.dense_bwd_deferred(ctx, x, dh, w, dx, dw1, ctx.empty(4), y_mask=x, db_prev=db1)
+    assert pend.colpart is None and pend.slabs is None
+    D.dense_bwd(ctx, x, dh, w, dx, dw2, y_mask=x, db_prev=db2)
+    assert np.array_equal(dw1.numpy(), dw2.numpy()) and np.array_equal(db1.numpy(), db2.numpy())
+    assert D.dense_bwd_scratch_floats(ctx, 300, 64, 8) > 0 and D.dense_bwd_scratch_floats(ctx, 300, 10, 8) == 0
+    assert lib.gcnx_dense_bwd_deferred(h, x.ptr, 64, dh.ptr, 8, w.ptr, 300, 64, 8, 0, dx.ptr, 64, None, 0, None, dw1.ptr, None, 0, None) == 1
+    assert "pending is NULL" in _lib.last_error(h)
+    # last gradient + SGD: dW outside the flat gradient buffer, and a pending result outside it, are refused
+    params, grads = ctx.zeros(64 * 8 + 10), ctx.zeros(64 * 8 + 10)
+    with pytest.raises(_lib.GcnxError, match="inside the flat gradient buffer"):
+        D.gemm_dw_sgd(ctx, x, dh, ctx.empty((64, 8)), params, grads, 0.1)
+    bad = _lib.PendingReduce(colpart=x.ptr, crows=4, cf=64, cout=db1.ptr, slabs=None, total=0, nsplit=0, out=None)
+    with pytest.raises(_lib.GcnxError, match="pending column sums must land"):
+        D.gemm_dw_sgd(ctx, x, dh, grads.flat(0, 64 * 8, (64, 8)), params, grads, 0.1, pending=bad)
+    # n == 0 with a valid layout: dW zeroed, every parameter still updated with its (other) gradients
+    g0 = np.arange(64 * 8 + 10, dtype=np.float32); grads = ctx.to_device(g0); params = ctx.zeros(64 * 8 + 10)
+    D.gemm_dw_sgd(ctx, x0, dh0, grads.flat(0, 64 * 8, (64, 8)), params, grads, 0.5)
+    exp = g0.copy(); exp[:64 * 8] = 0
+    assert np.array_equal(grads.numpy(), exp) and np.array_equal(params.numpy(), -0.5 * exp)
+
+
 def test_device_collate_single_graph_and_repeated_selection(ctx):
     """gcnx_collate with a one-graph batch, and with the same graph selected twice (sampling with replacement):
     the copies are re-based independently."""
