@@ -550,10 +550,14 @@ class GeneralGNN(_GraphRunner):
             D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
                          alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
                          dalpha=L.get("g_alpha"))
-        D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=self.prec)
         D.act_bias_grad(ctx, dz, None, dz, None, db=L["g_bias"])
-        if dx is not None:
-            D.gemm_dx(ctx, dz, L["kernel"], dx, prec=self.prec, accumulate=accumulate)
+        if dx is not None and not accumulate:
+            # both products of the layer in one launch pair (gcnx_dense_bwd; falls back inside for ragged widths)
+            D.dense_bwd(ctx, x, dz, L["kernel"], dx, L["g_kernel"], prec=self.prec)
+        else:
+            D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=self.prec)
+            if dx is not None:
+                D.gemm_dx(ctx, dz, L["kernel"], dx, prec=self.prec, accumulate=accumulate)
 
     def _backward(self, batch, bufs, training=True):
         h, mp = self.hidden, self.mp
