@@ -55,8 +55,17 @@ __device__ __forceinline__ float4 f4_fma(float v, float4 h, float4 a) {
   const f32x2 hi = __builtin_elementwise_fma(w, f32x2{h.z, h.w}, f32x2{a.z, a.w});
   return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
-__device__ __forceinline__ float4 f4_step(float4 a) {   // [a > 0]
-  return make_float4(a.x > 0.f ? 1.f : 0.f, a.y > 0.f ? 1.f : 0.f, a.z > 0.f ? 1.f : 0.f, a.w > 0.f ? 1.f : 0.f);
+// [a > 0] for a >= 0 (a saved ReLU output): clamp01(a * 2^127 * 2^127) -- 0 stays 0, every positive value down to the
+// smallest denormal (2^-149 -> 2^105) saturates to 1.  Two packed multiplies per two components (the second with the
+// VOP3P clamp bit) instead of a compare + select per component.
+__device__ __forceinline__ float4 f4_step(float4 a) {
+  const f32x2 big = {0x1p127f, 0x1p127f};
+  f32x2 lo = {a.x, a.y}, hi = {a.z, a.w}, t0, t1;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(lo), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(hi), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(t0), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(t1), "v"(big));
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   const f32x2 lo = f32x2{a.x, a.y} + f32x2{b.x, b.y}, hi = f32x2{a.z, a.w} + f32x2{b.z, b.w};
