@@ -67,6 +67,10 @@ __device__ __forceinline__ float4 f4_step(float4 a) {
   asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(t1), "v"(big));
   return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
+__device__ __forceinline__ float4 buf4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const f32x4v r = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+  return make_float4(r.x, r.y, r.z, r.w);
+}
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   const f32x2 lo = f32x2{a.x, a.y} + f32x2{b.x, b.y}, hi = f32x2{a.z, a.w} + f32x2{b.z, b.w};
   return make_float4(lo[0], lo[1], hi[0], hi[1]);
@@ -240,10 +244,11 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
         const int nfull = min(bA - aA, bB - aB) / (2 * G);        // uniform per wave
         for (int t = 0; t < nfull; ++t) {
           const int cA0 = s_col[eA], cA1 = s_col[eA + G], cB0 = s_col[eB], cB1 = s_col[eB + G];
-          const float4 hA0 = *reinterpret_cast<const float4*>(h + (int64_t)cA0 * ldh + c);
-          const float4 hA1 = *reinterpret_cast<const float4*>(h + (int64_t)cA1 * ldh + c);
-          const float4 hB0 = *reinterpret_cast<const float4*>(h + (int64_t)cB0 * ldh + c);
-          const float4 hB1 = *reinterpret_cast<const float4*>(h + (int64_t)cB1 * ldh + c);
+          // (32-bit offsets from a scalar base: a third of the address arithmetic of 64-bit pointers, no pointer VGPRs)
+          const float4 hA0 = buf4(hbuf, ((unsigned)cA0 * ld32 + (unsigned)c) * 4u);
+          const float4 hA1 = buf4(hbuf, ((unsigned)cA1 * ld32 + (unsigned)c) * 4u);
+          const float4 hB0 = buf4(hbuf, ((unsigned)cB0 * ld32 + (unsigned)c) * 4u);
+          const float4 hB1 = buf4(hbuf, ((unsigned)cB1 * ld32 + (unsigned)c) * 4u);
           if (WEIGHTED) {
             const float wA0 = s_val[eA], wA1 = s_val[eA + G], wB0 = s_val[eB], wB1 = s_val[eB + G];
             accA = f4_fma(wA0, FOLD ? f4_step(hA0) : hA0, accA);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     finish(accB, longB ? r1 : rB);
   }
   };
-  if (e1 - e0 <= kStageCap) rows_pass(std::true_type{}); else rows_pass(std::false_type{});   // uniform per workgroup
+  if (e1 - e0 <= kStageCap && use_buf) rows_pass(std::true_type{}); else rows_pass(std::false_type{});   // uniform per workgroup
   // Hub rows (power-law batches: one row of a chunk can hold thousands of entries).  Walked by a single wave such a
   // row alone set the kernel's duration (config 5: a 4096-entry row = 2 ms); here every wave of the workgroup takes
   // a quarter of its entries and the four partial sums are combined in wave order (deterministic).
