@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     if (fl < r1 - r0) {
       const int r = r0 + fl;
       int gq = f_base;
-      while (f_nxt <= r) { ++gq; f_nxt = fo.gp[gq + 1]; }   // gp[b] = n > r: terminates inside the array
+      while (f_nxt <= r && gq + 1 < fo.b) { ++gq; f_nxt = fo.gp[gq + 1]; }   // gp[b] = n > r ends it; the guard keeps a
+                                                                             // malformed graph_ptr from walking off the array
       s_g[fl] = gq;
       s_sc[fl] = fo.avg ? 1.0f / (float)(f_nxt - fo.gp[gq]) : 1.0f;
     }
