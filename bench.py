@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- graphs/sec (fwd+bwd+SGD) of the GCN hot path on N MI355X GPUs, one JSON line.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts one rank process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one train_step (src/scripts/gcn.py:330-340: forward, CCE loss, every gradient, SGD
 apply) of the BN-free 2-layer GCNConv model of BASELINE.md section 3 over one synthetic
-DisjointLoader batch that is already resident in HBM.  torch is never imported: the launcher
+DisjointLoader batch that is already resident in HBM.  torch is never imported: either launcher
 only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*; the data path is libgcnx + RCCL.
 
 Workloads (BASELINE.json configs):
   ecoli    config 2: B=32 E. coli-shaped graphs per GPU, F=128, fp32 (the metric's own config)
-  block1m  config 3/4: 1M nodes / 10M entries / F=256 disjoint batch (strong scaling: sharded)
+  block1m  config 3/4: 1M nodes / 10M entries / F=256 disjoint batch (strong scaling: sharded),
+           bf16 MFMA weight GEMMs (--prec bf16x3 by default: split-bf16, fp32-grade results)
   powerlaw config 5: power-law degrees, max degree 4096
 """
 from __future__ import annotations
@@ -20,6 +21,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,46 +33,143 @@ for _p in (ROOT, os.path.join(ROOT, "gcn-string_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+CONFIG_PREC = {"ecoli": "f32", "block1m": "bf16x3", "powerlaw": "bf16x3"}   # config 2 is quoted in fp32; config 3 names the bf16 MFMA GEMM
 
 
-def make_global_batch(workload, world, scaling):
-    from gcnx import synth
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` started plainly spawns the N rank processes itself
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Starts one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / GCNX_RUN_ID in the environment, like
+    torch.distributed.run would, plus a fresh run id for the RCCL rendezvous file) BEFORE this process has touched the
+    GPU -- it never does.  Rank 0's stdout (the JSON line) is passed through; exits non-zero if any rank does."""
+    import socket
+    import uuid
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    run_id = uuid.uuid4().hex
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GCNX_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = None
+    rc = 0
+    deadline = time.time() + float(os.environ.get("GCNX_BENCH_TIMEOUT", "3000"))
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            p = procs[r]
+            if r == 0 and out0 is None and p.poll() is not None:
+                out0 = p.stdout.read()
+            code = p.poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        if time.time() > deadline and pending:
+            print("bench.py: ranks still running at the launcher's time limit; stopping them", file=sys.stderr)
+            for q in pending:
+                procs[q].kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    if out0 is None:
+        out0 = procs[0].stdout.read() or b""
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def launcher_selftest(rank, world):
+    """CPU-only plumbing check of the launcher + rendezvous (tests/test_host.py): the ranks exchange a fake 128-byte
+    id through the rendezvous file the real Communicator uses; rank 0 prints one JSON line."""
+    from gcnx import comm as gcomm
+    raw = gcomm.exchange_unique_id(rank, world, timeout_s=60.0, make_id=lambda: bytes(range(128)))
+    ok = raw == bytes(range(128))
+    # every rank reports through a file so that rank 0 can confirm all of them arrived
+    base = gcomm._rendezvous_path() + ".selftest"
+    with open(f"{base}.{rank}", "w") as fh:
+        fh.write("ok" if ok else "bad")
+    if rank == 0:
+        t0 = time.time()
+        seen = 0
+        while time.time() - t0 < 60 and seen < world:
+            seen = sum(os.path.exists(f"{base}.{r}") for r in range(world))
+            time.sleep(0.02)
+        good = all(open(f"{base}.{r}").read() == "ok" for r in range(world)) if seen == world else False
+        for r in range(world):
+            try:
+                os.remove(f"{base}.{r}")
+            except OSError:
+                pass
+        try:
+            os.remove(gcomm._rendezvous_path())
+        except OSError:
+            pass
+        print(json.dumps({"selftest": "launcher", "world": world, "ranks_seen": seen, "ok": bool(good),
+                          "run_id": os.environ.get("GCNX_RUN_ID")}), flush=True)
+        return 0 if good else 1
+    return 0 if ok else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads: every rank builds only its own shard (graph g comes from its own random stream)
+# ---------------------------------------------------------------------------------------------------------------
+def make_shard(workload, rank, world, scaling):
+    """This rank's graphs of the global batch + the global graph count.  Sizes of ALL graphs are generated everywhere
+    (cheap; the cost-balanced partition needs them), edges / features only for the rank's own range."""
+    from gcnx import shard, synth
     if workload == "ecoli":
         b = 32 * (world if scaling == "weak" else 1)
-        hb = synth.ecoli_batch(b, 128, seed=1)
+        sizes = synth.ecoli_sizes(b, seed=1)
+        # cost model of shard.partition_graphs with the entry count estimated from the size (mean degree ~ 15)
+        bounds = shard.partition_by_cost(sizes * 16.0, world)
+        hb = synth.ecoli_shard(int(bounds[rank]), int(bounds[rank + 1]), 128, seed=1)
         hidden = 128
     elif workload == "block1m":
         mult = world if scaling == "weak" else 1
-        hb = synth.block_diag_batch(1_000_000 * mult, 10_000_000 * mult, 256, seed=2)
-        hidden = 256
+        sizes, pairs = synth.block_diag_plan(1_000_000 * mult, 10_000_000 * mult, seed=2)
+        bounds = shard.partition_by_cost(sizes + 2 * pairs + sizes, world)       # nnz_g + n_g
+        hb = synth.block_diag_shard(int(bounds[rank]), int(bounds[rank + 1]), sizes, pairs, 256, seed=2)
+        b, hidden = len(sizes), 256
     elif workload == "powerlaw":
-        hb = synth.power_law_batch(122 * (world if scaling == "weak" else 1), 8192, 256, seed=3)
+        b = 122 * (world if scaling == "weak" else 1)
+        bounds = shard.partition_by_cost(np.ones(b), world)                      # same-size graphs
+        hb = synth.power_law_batch(int(bounds[rank + 1] - bounds[rank]), 8192, 256, seed=3, first_graph=int(bounds[rank]))
         hidden = 256
     else:
         raise SystemExit(f"unknown workload {workload}")
     hb.vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)      # GCNConv.preprocess (weighted SpMM)
-    return hb, hidden
+    return hb, hidden, b
 
 
 def pmc_traffic(workload):
     """HBM bytes per SpMM call from the committed rocprofv3 PMC passes (profiles/rNN/spmm_pmc.json, collected in
     separate --pmc runs as MI355X_MICROARCH.md prescribes): 2 x FETCH_SIZE (gfx950 counts a wide coalesced read
-    at half its bytes) + WRITE_SIZE, KiB -> bytes, summed over the kernels of one gcnx_spmm_csr call."""
+    at half its bytes) + WRITE_SIZE, KiB -> bytes, summed over the kernels of one gcnx_spmm_csr call.  A committed
+    figure of an earlier profiling run of the same kernels, NOT measured in this run: see `traffic_source`."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "spmm_pmc.json")))
     if not files:
-        return None
+        return None, None
     try:
         tab = json.load(open(files[-1])).get(workload)
         if not tab:
-            return None
+            return None, None
         tot = 0.0
         for counters in tab.values():
             tot += 2.0 * counters.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0)
             tot += counters.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0)
-        return tot * 1024.0
+        return tot * 1024.0, os.path.relpath(files[-1], ROOT) + " (static: committed rocprofv3 --pmc passes, not this run)"
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(hb, hidden, params_flat, budget_s):
@@ -93,18 +192,67 @@ def cpu_baseline(hb, hidden, params_flat, budget_s):
                       f"F={hb.f}) in {el:.1f} s; C/OpenMP fp32 restatement, not Spektral/TF (absent)"}
 
 
+def cpu_baseline_scipy(hb, hidden, params_flat, budget_s):
+    """the NumPy/SciPy restatement of the same step (scipy.sparse CSR @ dense for the
+    aggregation, NumPy/BLAS GEMMs), fp32, the threads NumPy's BLAS takes by itself.  A second CPU reference next to
+    the C/OpenMP port; never the optimisation target."""
+    import scipy.sparse as sp
+    f, h, c = hb.f, hidden, 2
+    a = sp.csr_matrix((hb.vals.astype(np.float32), hb.colidx, hb.rowptr), shape=(hb.n, hb.n))
+    off = 0
+    p = {}
+    for k, shp in (("w1", (f, h)), ("b1", (h,)), ("w2", (h, h)), ("b2", (h,)), ("w3", (h, c)), ("b3", (c,))):
+        n = int(np.prod(shp)); p[k] = params_flat[off:off + n].reshape(shp).astype(np.float32).copy(); off += n
+    seg = np.repeat(np.arange(hb.n_graphs), np.diff(hb.graph_ptr))
+    pool = sp.csr_matrix((np.ones(hb.n, np.float32), (seg, np.arange(hb.n))), shape=(hb.n_graphs, hb.n))
+    x, y = hb.x, hb.y
+
+    def step(lr):
+        y1 = np.maximum(a @ (x @ p["w1"]) + p["b1"], 0)
+        y2 = np.maximum(a @ (y1 @ p["w2"]) + p["b2"], 0)
+        pooled = pool @ y2
+        z = pooled @ p["w3"] + p["b3"]
+        z = z - z.max(1, keepdims=True)
+        pr = np.exp(z); pr /= pr.sum(1, keepdims=True)
+        dl = (pr - y) / np.float32(hb.n_graphs)
+        g = {"w3": pooled.T @ dl, "b3": dl.sum(0)}
+        dz = (pool.T @ (dl @ p["w3"].T)) * (y2 > 0)
+        g["b2"] = dz.sum(0); dh = a.T @ dz
+        g["w2"] = y1.T @ dh
+        dz = (dh @ p["w2"].T) * (y1 > 0)
+        g["b1"] = dz.sum(0); dh = a.T @ dz
+        g["w1"] = x.T @ dh
+        for k in p:
+            p[k] -= np.float32(lr) * g[k].astype(np.float32)
+    step(0.0002)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        step(0.0002); steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 500:
+            break
+    return {"value": hb.n_graphs * steps / el, "unit": "graphs/s", "kind": "port (NumPy/SciPy, BASELINE.md C2)",
+            "sample": f"{steps} train steps in {el:.1f} s; scipy.sparse csr @ dense + NumPy BLAS, fp32"}
+
+
+def env_knobs():
+    """GCNX_* tuning knobs present in the environment (diagnostics: some change kernel selection)."""
+    allowed = {"GCNX_RUN_ID", "GCNX_CPU_THREADS", "GCNX_BENCH_TIMEOUT", "GCNX_LIB"}
+    return {k: v for k, v in os.environ.items() if k.startswith("GCNX_") and k not in allowed}
+
+
 def bench_generalgnn(ctx, args):
     """Secondary line: the reference's live model (GeneralGNN defaults, NetSurfP-width inputs F_in = 16,
-    gcn_utills.py:293-300) on the E. coli-shaped batch; forward + CCE + all gradients + SGD, eager launches."""
+    gcn_utills.py:293-300) on the E. coli-shaped batch; forward + CCE + all gradients + SGD."""
     from gcnx import synth
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch, GeneralGNN
     assert args.gpus == 1, "this secondary line is single-GPU; the sync-BN multi-GPU step is exercised by tests/ (world_size 2)"
-    hb = synth.ecoli_batch(32, 16, seed=1) if args.workload == "ecoli" else synth.block_diag_batch(1_000_000, 10_000_000, 16, seed=2)
+    hb = synth.ecoli_shard(0, 32, 16, seed=1) if args.workload == "ecoli" else synth.block_diag_batch(1_000_000, 10_000_000, 16, seed=2)
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
     model = GeneralGNN(ctx, 2, activation="softmax", prec=args.prec)
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(args.warmup, 3)):
         model.train_step(batch, None, lr=0.0002, fetch=False)
     ctx.sync()
     t0 = time.perf_counter()
@@ -121,6 +269,17 @@ def bench_generalgnn(ctx, args):
     ctx.close()
 
 
+def time_spmm(ctx, D, a, h, bias, out, iters):
+    for _ in range(5):
+        D.spmm(ctx, a, h, bias, out, act="relu")
+    ctx.sync()
+    e0 = ctx.event().record()
+    for _ in range(iters):
+        D.spmm(ctx, a, h, bias, out, act="relu")
+    e1 = ctx.event().record()
+    return e1.elapsed_ms_since(e0) / iters
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,32 +287,50 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="ecoli", choices=["ecoli", "block1m", "powerlaw"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
-    ap.add_argument("--prec", default="f32", choices=["f32", "bf16", "bf16x3"])
+    ap.add_argument("--prec", default=None, choices=["f32", "bf16", "bf16x3"],
+                    help="GEMM arithmetic; default per workload: ecoli f32 (config 2 is an fp32 config), block1m / powerlaw "
+                         "bf16x3 (config 3's bf16 MFMA weight GEMM as split-bf16: three MFMA passes, fp32-grade results)")
     ap.add_argument("--model", default="gcn2", choices=["gcn2", "generalgnn"],
                     help="gcn2 = the BN-free 2-layer GCNConv model of BASELINE.md (default, the metric's model); "
-                         "generalgnn = the reference's live model gcn.py:320 (F_in=16, hidden=256; single GPU, eager)")
+                         "generalgnn = the reference's live model gcn.py:320 (F_in=16, hidden=256; single GPU)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--scipy-seconds", type=float, default=4.0, help="budget of the NumPy/SciPy baseline C2 (0 = skip)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra config-3 SpMM roofline reading")
     ap.add_argument("--spmm-iters", type=int, default=0, help="SpMM-only launches for the roofline (default 4*steps)")
+    ap.add_argument("--allow-knobs", action="store_true", help="run although GCNX_* tuning knobs are set (they are recorded)")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.prec is None:
+        args.prec = CONFIG_PREC[args.workload]
+
+    # ---- N > 1 started plainly: become the launcher (nothing below has touched the GPU yet) ----------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    from gcnx import comm as gcomm
+    rank, local_rank, world = gcomm.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"or plainly as `python bench.py --gpus {args.gpus}`")
+    if args.selftest_launcher:
+        sys.exit(launcher_selftest(rank, world))
+    knobs = env_knobs()
+    if knobs and not args.allow_knobs:
+        raise SystemExit(f"bench.py: tuning knobs set in the environment ({knobs}); numbers taken with them are not the "
+                         f"product's.  Unset them or pass --allow-knobs (they are then recorded in the JSON line).")
 
     import gcnx
-    from gcnx import comm as gcomm, device as D, shard, synth
+    from gcnx import device as D, synth
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch, GCN2
 
-    rank, local_rank, world = gcomm.env_rank()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     scaling = args.scaling or ("weak" if args.workload == "ecoli" else "strong")
-
     ctx = gcnx.Context(local_rank)
     if args.model == "generalgnn":
         return bench_generalgnn(ctx, args)
     comm = gcomm.Communicator(ctx, rank, world)
-    hb_global, hidden = make_global_batch(args.workload, world, scaling)
-    hb, global_graphs = shard.shard_batch(hb_global, rank, world) if world > 1 else (hb_global, hb_global.n_graphs)
+    hb, hidden, global_graphs = make_shard(args.workload, rank, world, scaling)
 
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, hb.vals, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
@@ -166,30 +343,26 @@ def main():
         model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
     comm.barrier()
     ctx.sync()
-    ev0 = ctx.event().record()
+    evs = [ctx.event().record()]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
-    ev1 = ctx.event().record()
+        evs.append(ctx.event().record())        # per-step HIP events on the ctx stream (median)
     ctx.sync()
     comm.barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev1.elapsed_ms_since(ev0)
+    per_step = np.array([evs[i + 1].elapsed_ms_since(evs[i]) for i in range(args.steps)])
+    dev_ms = float(per_step.sum())
+    med_ms = float(np.median(per_step))
     elapsed = float(comm.allreduce_host([elapsed], "max")[0])
+    med_ms = float(comm.allreduce_host([med_ms], "max")[0])
     loss, acc = model.fetch_metrics(global_graphs)
 
     # ---- roofline of the dominant hot-path kernel: the GCNConv SpMM (forward shape of layer 1/2)
     iters = args.spmm_iters or 4 * args.steps
     h = ctx.to_device(np.random.default_rng(1).standard_normal((hb.n, hidden), dtype=np.float32))
     out = ctx.empty((hb.n, hidden))
-    for _ in range(5):
-        D.spmm(ctx, a, h, model.p["b1"], out, act="relu")
-    ctx.sync()
-    e0 = ctx.event().record()
-    for _ in range(iters):
-        D.spmm(ctx, a, h, model.p["b1"], out, act="relu")
-    e1 = ctx.event().record()
-    spmm_ms = e1.elapsed_ms_since(e0) / iters
+    spmm_ms = time_spmm(ctx, D, a, h, model.p["b1"], out, iters)
     alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, hidden, weighted=True)
     achieved = alg / (spmm_ms * 1e-3) / 1e9
 
@@ -197,52 +370,57 @@ def main():
     # enough for a bandwidth reading; reported next to the primary roofline, never as `value`
     big = None
     if world == 1 and args.workload == "ecoli" and not args.no_config3:
-        hb3 = synth.block_diag_batch(with_x=False)
+        sizes3, pairs3 = synth.block_diag_plan()
+        hb3 = synth.block_diag_shard(0, len(sizes3), sizes3, pairs3, 256, seed=2, with_x=False)
         v3 = synth.gcn_norm_host(hb3.rowptr, hb3.colidx)
         a3 = DeviceCSR.from_host_csr(ctx, hb3.rowptr, hb3.colidx, v3, hb3.graph_ptr)
         h3 = ctx.to_device(np.random.default_rng(2).standard_normal((hb3.n, 256), dtype=np.float32))
         o3 = ctx.empty((hb3.n, 256)); b3 = ctx.zeros(256)
-        for _ in range(3):
-            D.spmm(ctx, a3, h3, b3, o3, act="relu")
-        ctx.sync()
-        e0 = ctx.event().record()
-        for _ in range(20):
-            D.spmm(ctx, a3, h3, b3, o3, act="relu")
-        e1 = ctx.event().record()
-        ms3 = e1.elapsed_ms_since(e0) / 20
+        ms3 = time_spmm(ctx, D, a3, h3, b3, o3, 20)
         alg3 = synth.spmm_algorithmic_bytes(hb3.n, hb3.nnz, 256, weighted=True)
+        tr3, src3 = pmc_traffic("block1m")
         big = {"workload": "config3: N=1,000,000 nnz=10,000,000 F=256 fp32, weighted, bias+relu", "bound": "hbm",
                "achieved": alg3 / (ms3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("block1m"), "algorithmic_bytes": alg3, "avg_launch_us": 1e3 * ms3,
-               "launches": 20, "kernels": "spmm_duo_kernel (512- and 1024-thread shapes) + spmm_rows_kernel: one gcnx_spmm_csr call"}
-        for t in (a3, h3, o3):
-            pass
+               "frac": alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr3, "traffic_source": src3,
+               "algorithmic_bytes": alg3, "avg_launch_us": 1e3 * ms3,
+               "launches": 20, "kernels": "all kernels of one gcnx_spmm_csr call (tile tiers + row chunks)"}
 
     if rank == 0:
         small = hb.n < 128 * 1024
+        tr, src = pmc_traffic(args.workload)
         rec = {
             "metric": "graphs/sec (fwd+bwd) on E.coli-sized batches; GCNConv SpMM achieved HBM GB/s",
             "value": global_graphs * args.steps / elapsed, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if args.prec == "f32" else args.prec,
             "data": "synthetic",
-            "config": {"workload": {"ecoli": "config2: E. coli-shaped DisjointLoader batch, B=32 graphs per GPU, F=128, "
-                                             "2-layer GCNConv(relu)+GlobalSumPool+Dense softmax, CCE, SGD",
-                                    "block1m": "config3/4: 1M-node/10M-entry disjoint batch, F=256, same model",
-                                    "powerlaw": "config5: power-law degrees (max 4096), 8192-node graphs, F=256"}[args.workload],
+            "config": {"workload": {"ecoli": "config2: E. coli-shaped DisjointLoader batch, B=32 graphs per GPU, F=128, fp32, "
+                                             "2-layer GCNConv(relu)+GlobalSumPool+Dense softmax, CCE (from-logits form of tf.function), SGD",
+                                    "block1m": f"config3/4: 1M-node/10M-entry disjoint batch, F=256, same model, weight GEMMs {args.prec} "
+                                               "(bf16x3 = split-bf16 on the bf16 MFMA, fp32-grade; bf16 = plain bf16 operands)",
+                                    "powerlaw": f"config5: power-law degrees (max 4096), 8192-node graphs, F=256, weight GEMMs {args.prec}"}[args.workload],
                        "global_graphs": global_graphs, "nodes_per_gpu": hb.n, "nnz_per_gpu": hb.nnz, "features": hb.f,
-                       "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32)",
-                       "hip_graph": not args.no_graph, "gemm_precision": args.prec},
-            "device_ms_per_step": dev_ms / args.steps, "final_loss": loss, "final_acc": acc,
-            "roofline": {"kernel": ("spmm_rows_kernel" if small else "spmm_duo_kernel(+rows)") +
+                       "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32"
+                                                        f"{' inside the step graph' if world > 1 and model._comm_in_graph() else ''})",
+                       "hip_graph": not args.no_graph, "gemm_precision": args.prec, "cce": model.cce_train},
+            "device_ms_per_step": dev_ms / args.steps,
+            "m1_median": {"ms_per_step": med_ms, "graphs_per_s": global_graphs / (med_ms * 1e-3),
+                          "what": "median of per-step HIP-event times on the ctx stream, max over ranks (SURVEY 8(d) M1); "
+                                  "`value` is the wall-clock figure the bench contract defines"},
+            "final_loss": loss, "final_acc": acc,
+            "roofline": {"kernel": ("spmm_rows_kernel" if small else "spmm tile kernel(s) + row chunks") +
                                    " (GCNConv aggregation, weighted, bias+relu fused)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload), "algorithmic_bytes": alg, "avg_launch_us": 1e3 * spmm_ms, "launches": iters},
+                         "traffic": tr, "traffic_source": src, "algorithmic_bytes": alg, "avg_launch_us": 1e3 * spmm_ms, "launches": iters},
         }
+        if knobs:
+            rec["env_knobs"] = knobs
         if big is not None:
             rec["roofline_config3"] = big
         if world == 1 and args.cpu_seconds > 0:
             rec["cpu_baseline"] = cpu_baseline(hb, hidden, params0, args.cpu_seconds)
+            if args.scipy_seconds > 0:
+                rec["cpu_baseline_scipy"] = cpu_baseline_scipy(hb, hidden, params0, args.scipy_seconds)
         print(json.dumps(rec), flush=True)
     comm.barrier()
     comm.close()

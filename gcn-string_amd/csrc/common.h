@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "gcnx.h"
 
@@ -16,8 +17,17 @@ struct gcnx_ctx {
   // outside stream capture; a capture that would need growth fails with a clear message.
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  int* flag = nullptr;       // device int[4] for validation kernels
+  int* flag = nullptr;       // device int[4]: [0] validation kernels, [1] gcnx_csr_inspect, [3] the head kernel's ticket
   bool capturing = false;
+  // Captured graphs keep the workspace pointer they were recorded with in their kernel arguments.  While any graph
+  // is alive a workspace that has to grow is therefore retired, not freed: old graphs keep replaying into their old
+  // block, eager calls and later captures use the new one.  Retired blocks are released when the last graph is
+  // destroyed (or with the ctx).
+  int live_graphs = 0;
+  std::vector<void*> retired_ws;
+  // tuning knobs (diagnostics, not API), read once at ctx creation: GCNX_SPMM_KERNEL, GCNX_SPMM_SLAB, GCNX_SPMM_SG
+  int knob_spmm_kernel = 0;  // 0 auto, 1 rows, 2 tile
+  int knob_spmm_slab = 0, knob_spmm_sg = 0;
   // Side stream for gradient "leaves" (weight / bias gradients that nothing downstream in the backward pass
   // consumes): gcnx_side_begin swaps stream and workspace, so every entry point launches there unchanged.
   hipStream_t main_stream = nullptr, side_stream = nullptr;

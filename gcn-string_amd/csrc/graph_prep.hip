@@ -69,6 +69,51 @@ __global__ __launch_bounds__(256) void gcn_scale_kernel(const int32_t* __restric
 }
 
 
+// Structure check of a batch adjacency, one wave per row: (1) is A == A^T (pattern; values to 4 ulp -- gcn_filter's
+// v * d_r * d_c is rounded in a different order on either side of the diagonal), which lets the backward pass
+// reuse this CSR for A^T; (2) does every entry stay inside its row's graph_ptr block, which the tile plan and the
+// folded pool backward assume.  Failures clear bits of *props (device int, preset to all checks passed).
+__global__ __launch_bounds__(256) void csr_inspect_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                          const float* __restrict__ vals, int32_t n,
+                                                          const int32_t* __restrict__ gp, int32_t b, int* __restrict__ props) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const int a = rowptr[r], e1 = rowptr[r + 1];
+  int lo = 0, hi = n;
+  if (gp) {                                     // the block of row r: largest g with gp[g] <= r (uniform per wave)
+    int g0 = 0, g1 = b;                         // invariant: gp[g0] <= r < gp[g1]  (gp[0] == 0, gp[b] == n checked by the host)
+    while (g1 - g0 > 1) { const int m = (g0 + g1) >> 1; if (gp[m] <= r) g0 = m; else g1 = m; }
+    lo = gp[g0]; hi = gp[g1];
+  }
+  bool sym = true, blk = true;
+  for (int e = a + lane; e < e1; e += 64) {
+    const int c = colidx[e];
+    if (c < 0 || c >= n) { sym = false; blk = false; continue; }
+    if (c < lo || c >= hi) blk = false;
+    if (c == r) continue;
+    const float v = vals ? vals[e] : 1.0f;
+    bool found = false;
+    for (int q = rowptr[c]; q < rowptr[c + 1] && !found; ++q)
+      if (colidx[q] == r) {
+        const float w = vals ? vals[q] : 1.0f;
+        found = fabsf(w - v) <= 4.8e-7f * fmaxf(fabsf(w), fabsf(v));
+      }
+    sym &= found;
+  }
+  if (!sym) atomicAnd(props, ~GCNX_CSR_SYMMETRIC);
+  if (!blk) atomicAnd(props, ~GCNX_CSR_BLOCK_DIAGONAL);
+}
+
+__global__ void graph_ptr_check_kernel(const int32_t* __restrict__ gp, int32_t b, int32_t n, int* __restrict__ props) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > b) return;
+  bool ok = true;
+  if (g == 0) ok = gp[0] == 0;
+  if (g == b) ok = ok && gp[b] == n;
+  if (g < b) ok = ok && gp[g] <= gp[g + 1];
+  if (!ok) atomicAnd(props, ~(GCNX_CSR_BLOCK_DIAGONAL | GCNX_CSR_GRAPH_PTR_OK));
+}
+
 // ---- device-side collate -------------------------------------------------------------
 // The dataset lives in HBM as ONE disjoint union of all its graphs (features, CSR, labels, node_ptr).  A
 // batch = the graphs sel[0..b) in that order: their feature rows, CSR rows (row pointers and column indices
@@ -158,6 +203,36 @@ int gcnx_gcn_norm(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
   GCNX_HIP(ctx, hipMemcpyAsync(&h, ctx->flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_gcn_norm: a row stores no diagonal entry (add self-loops on the host: GCNConv.preprocess)");
+  return GCNX_OK;
+}
+
+int gcnx_csr_inspect(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, int32_t n,
+                     const int32_t* graph_ptr, int32_t b, int* props) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, props != nullptr, "gcnx_csr_inspect: props is NULL");
+  *props = 0;
+  GCNX_REQUIRE(ctx, n >= 0 && b >= 0, "gcnx_csr_inspect: negative size");
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_csr_inspect synchronises and cannot be captured");
+  GCNX_REQUIRE(ctx, n == 0 || (rowptr && colidx), "gcnx_csr_inspect: NULL pointer");
+  int h = GCNX_CSR_SYMMETRIC | (graph_ptr ? (GCNX_CSR_BLOCK_DIAGONAL | GCNX_CSR_GRAPH_PTR_OK) : 0);
+  GCNX_HIP(ctx, hipMemcpyAsync(ctx->flag + 1, &h, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));        // (h is a stack variable)
+  if (graph_ptr) {
+    hipLaunchKernelGGL(graph_ptr_check_kernel, dim3(gcnx_cdiv(b + 1, 256)), dim3(256), 0, ctx->stream, graph_ptr, b, n, ctx->flag + 1);
+    GCNX_LAUNCH_OK(ctx);
+    // the row -> block search below walks graph_ptr: only if it is well formed
+    GCNX_HIP(ctx, hipMemcpyAsync(&h, ctx->flag + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!(h & GCNX_CSR_GRAPH_PTR_OK)) graph_ptr = nullptr;
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(csr_inspect_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, rowptr, colidx, vals, n, graph_ptr, b,
+                       ctx->flag + 1);
+    GCNX_LAUNCH_OK(ctx);
+  }
+  GCNX_HIP(ctx, hipMemcpyAsync(&h, ctx->flag + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *props = h;
   return GCNX_OK;
 }
 

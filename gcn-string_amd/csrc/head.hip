@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
                                                    float denom, float* __restrict__ probs,
                                                    float* __restrict__ loss_acc, float* __restrict__ dw,
                                                    float* __restrict__ db, float* __restrict__ dpooled, int64_t lddp,
-                                                   float* __restrict__ slabs, int* __restrict__ ticket, PoolParts pp) {
+                                                   float* __restrict__ slabs, int* __restrict__ ticket, PoolParts pp,
+                                                   int from_logits) {
   static_assert(STAGED || !PARTS, "partials are combined into the LDS copy");
   const int c = CT > 0 ? CT : c_rt;
   constexpr bool staged = STAGED;
@@ -162,9 +163,12 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
       probs[g * c + k] = p;
       if (y) {
         const float yk = s_y[tid * c + k];
-        if (p > 1e-7f && p < 1.0f - 1e-7f) ymsum += yk;   // clip_by_value passes no gradient outside
+        // LOGITS (tf.function): softmax_cross_entropy_with_logits, no clip; PROBS (eager): clip_by_value passes
+        // no gradient outside [1e-7, 1 - 1e-7]
+        if (from_logits || (p > 1e-7f && p < 1.0f - 1e-7f)) ymsum += yk;
         if (yk > ymax) { ymax = yk; ya = k; }
-        loss -= yk * logf(fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f));
+        if (from_logits) loss += yk * ((m - z[k]) + logf(sum));
+        else loss -= yk * logf(fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f));
       }
       if (p > pmax) { pmax = p; pa = k; }
     }
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
       hit = (pa == ya) ? 1.f : 0.f;
       for (int k = 0; k < c; ++k) {
         const float p = expf(z[k] - m) / sum;
-        const float ym = (p > 1e-7f && p < 1.0f - 1e-7f) ? s_y[tid * c + k] : 0.f;
+        const float ym = (from_logits || (p > 1e-7f && p < 1.0f - 1e-7f)) ? s_y[tid * c + k] : 0.f;
         z[k] = (p * ymsum - ym) / denom;                  // dlogits replaces the logit in LDS
       }
     }
@@ -255,7 +259,7 @@ extern "C" {
 static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias, const float* y,
                      int32_t b, int32_t h, int32_t c, float denom, float* probs, float* loss_acc, float* dw, float* db,
                      float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
-                     float* pooled_out, float* db_relu);
+                     float* pooled_out, float* db_relu, int cce_mode);
 
 static size_t head_lds_floats(int32_t h, int32_t c, bool with_db_relu) {
   return (size_t)kHeadRows * (h + 1) + (size_t)h * c + (with_db_relu ? (size_t)kHeadRows * (h + 1) + 4 * (size_t)h : 0);
@@ -263,15 +267,16 @@ static size_t head_lds_floats(int32_t h, int32_t c, bool with_db_relu) {
 
 int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias,
                            const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
-                           float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp) {
+                           float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp, int cce_mode) {
   return head_impl(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, nullptr, nullptr,
-                   0, 0, nullptr, nullptr);
+                   0, 0, nullptr, nullptr, cce_mode);
 }
 
 int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
                                 int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
                                 const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
-                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp, float* db_relu) {
+                                float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp, float* db_relu,
+                                int cce_mode) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_pool_dense_softmax_cce: bad shape");
   GCNX_REQUIRE(ctx, pool_mode >= GCNX_POOL_SUM && pool_mode <= GCNX_POOL_MAX, "gcnx_pool_dense_softmax_cce: unknown pool mode %d",
@@ -286,12 +291,12 @@ int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const f
   if (!fused) {   // MAX pooling, many graphs (no split), operands too large for LDS: the separate calls as they are
     int rc = gcnx_segment_pool(ctx, graph_ptr, x, ldx, pooled, b, h, pool_mode, argmax);
     if (rc) return rc;
-    rc = gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp);
+    rc = gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, cce_mode);
     if (rc || !db_relu) return rc;
     return gcnx_pool_bwd_colsum(ctx, graph_ptr, b, dpooled, lddp, x, ldx, h, pool_mode, db_relu);
   }
   return head_impl(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, graph_ptr, x, ldx,
-                   pool_mode, pooled, db_relu);
+                   pool_mode, pooled, db_relu, cce_mode);
 }
 
 }  // extern "C"
@@ -299,8 +304,10 @@ int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const f
 static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias, const float* y,
                      int32_t b, int32_t h, int32_t c, float denom, float* probs, float* loss_acc, float* dw, float* db,
                      float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
-                     float* pooled_out, float* db_relu) {
+                     float* pooled_out, float* db_relu, int cce_mode) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, cce_mode == GCNX_CCE_PROBS || cce_mode == GCNX_CCE_LOGITS, "gcnx_dense_softmax_cce: unknown cce_mode %d", cce_mode);
+  const int fl = cce_mode == GCNX_CCE_LOGITS ? 1 : 0;
   GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_dense_softmax_cce: bad shape");
   GCNX_REQUIRE(ctx, c <= kHeadMaxC, "gcnx_dense_softmax_cce: at most %d classes (got %d); use gcnx_gemm + gcnx_softmax_cce",
                kHeadMaxC, c);
@@ -337,14 +344,14 @@ static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const floa
     pp = PoolParts{part, graph_ptr, pooled_out, nsplit, pool_mode == GCNX_POOL_AVG ? 1 : 0, cnt_part, want_db ? db_relu : nullptr};
 #define GCNX_HEAD(S, P, C)                                                                                                 \
     hipLaunchKernelGGL((head_kernel<S, P, C>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, pooled, ldp, w, bias, \
-                       y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp)
+                       y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp, fl)
     if (c == 2) GCNX_HEAD(true, true, 2); else GCNX_HEAD(true, true, 0);
   } else if (staged) {
     if (c == 2) GCNX_HEAD(true, false, 2); else GCNX_HEAD(true, false, 0);
 #undef GCNX_HEAD
   } else {
     hipLaunchKernelGGL((head_kernel<false, false>), dim3(nblk), dim3(256), 0, ctx->stream, pooled, ldp, w, bias, y, b, h, c,
-                       denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp);
+                       denom, probs, loss_acc, dw, db, dpooled, lddp, slabs, ctx->flag + 3, pp, fl);
   }
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;

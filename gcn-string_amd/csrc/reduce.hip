@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const int32_t* __restrict
 __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restrict__ logits,
                                                           const float* __restrict__ y, int32_t b, int32_t c,
                                                           float denom, float* __restrict__ probs,
-                                                          float* __restrict__ loss_acc, float* __restrict__ dlogits) {
+                                                          float* __restrict__ loss_acc, float* __restrict__ dlogits,
+                                                          int from_logits) {
   __shared__ float s_loss[256];
   __shared__ float s_hit[256];
   float loss = 0.f, hit = 0.f;
@@ -301,16 +302,19 @@ __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restric
     for (int k = 0; k < c; ++k) {
       const float p = expf(z[k] - m) / sum;
       probs[(int64_t)g * c + k] = p;
-      if (p > 1e-7f && p < 1.0f - 1e-7f) ymsum += yy[k];  // clip_by_value passes no gradient outside
+      // LOGITS (what Keras runs inside tf.function): softmax_cross_entropy_with_logits on the Softmax op's input --
+      // no renormalisation, no clip.  PROBS (eager tensors): clip_by_value passes no gradient outside [1e-7, 1-1e-7].
+      const bool pass = from_logits || (p > 1e-7f && p < 1.0f - 1e-7f);
+      if (pass) ymsum += yy[k];
       if (p > pmax) { pmax = p; pa = k; }
       if (yy[k] > ymax) { ymax = yy[k]; ya = k; }
-      const float pc = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);
-      l -= yy[k] * logf(pc);
+      if (from_logits) l += yy[k] * ((m - z[k]) + logf(sum));
+      else l -= yy[k] * logf(fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f));
     }
     if (dlogits)
       for (int k = 0; k < c; ++k) {
         const float p = expf(z[k] - m) / sum;
-        const float ym = (p > 1e-7f && p < 1.0f - 1e-7f) ? yy[k] : 0.f;
+        const float ym = (from_logits || (p > 1e-7f && p < 1.0f - 1e-7f)) ? yy[k] : 0.f;
         dlogits[(int64_t)g * c + k] = (p * ymsum - ym) / denom;
       }
     loss += l;
@@ -600,14 +604,15 @@ int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, con
 }
 
 int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t b, int32_t c, float denom,
-                     float* probs, float* loss_acc, float* dlogits) {
+                     float* probs, float* loss_acc, float* dlogits, int cce_mode) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, b >= 0 && c >= 1, "gcnx_softmax_cce: bad size b=%d c=%d", b, c);
   if (b == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, logits && y && probs && loss_acc, "gcnx_softmax_cce: NULL pointer");
   GCNX_REQUIRE(ctx, denom > 0.f, "gcnx_softmax_cce: denom must be positive");
+  GCNX_REQUIRE(ctx, cce_mode == GCNX_CCE_PROBS || cce_mode == GCNX_CCE_LOGITS, "gcnx_softmax_cce: unknown cce_mode %d", cce_mode);
   hipLaunchKernelGGL(softmax_cce_kernel, dim3(1), dim3(256), 0, ctx->stream, logits, y, b, c, denom, probs, loss_acc,
-                     dlogits);
+                     dlogits, cce_mode == GCNX_CCE_LOGITS ? 1 : 0);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

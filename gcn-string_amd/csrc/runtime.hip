@@ -1,4 +1,5 @@
 // libgcnx runtime: context lifecycle, device memory, events, HIP-graph capture.
+#include <cstdlib>
 #include <new>
 #include <utility>
 
@@ -26,7 +27,12 @@ int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes) {
   size_t want = bytes + (bytes >> 2);
   if (ctx->ws) {
     GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    GCNX_HIP(ctx, hipFree(ctx->ws));
+    if (ctx->live_graphs > 0) {
+      // a captured graph may hold this pointer (split-K slabs, head partials, BN partials): keep the block alive
+      try { ctx->retired_ws.push_back(ctx->ws); } catch (...) { return gcnx_fail(ctx, GCNX_ERR_NOMEM, "out of host memory"); }
+    } else {
+      GCNX_HIP(ctx, hipFree(ctx->ws));
+    }
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
   }
@@ -38,7 +44,7 @@ int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes) {
 
 extern "C" {
 
-int gcnx_version(void) { return 100; }
+int gcnx_version(void) { return 200; }
 
 int gcnx_device_count(int* n) {
   if (!n) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "gcnx_device_count: n is NULL");
@@ -81,6 +87,9 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   }
   ctx->num_cus = prop.multiProcessorCount;
   ctx->arch = prop.gcnArchName;
+  if (const char* k = getenv("GCNX_SPMM_KERNEL")) ctx->knob_spmm_kernel = k[0] == 'r' ? 1 : k[0] == 't' ? 2 : 0;
+  if (const char* k = getenv("GCNX_SPMM_SLAB")) ctx->knob_spmm_slab = atoi(k);
+  if (const char* k = getenv("GCNX_SPMM_SG")) ctx->knob_spmm_sg = atoi(k);
   if (ctx->arch.rfind("gfx950", 0) != 0) {
     int rc = gcnx_fail(nullptr, GCNX_ERR_UNSUPPORTED, "gcnx_ctx_create: device %d is %s; libgcnx is built for gfx950 only",
                        device, ctx->arch.c_str());
@@ -100,6 +109,7 @@ int gcnx_ctx_destroy(gcnx_ctx* ctx) {
   if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->ws_other) (void)hipFree(ctx->ws_other);
+  for (void* p : ctx->retired_ws) (void)hipFree(p);
   if (ctx->flag) (void)hipFree(ctx->flag);
   for (int i = 0; i < gcnx_ctx::kSideEvents; ++i) {
     if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
@@ -301,6 +311,7 @@ int gcnx_capture_end(gcnx_ctx* ctx, gcnx_graph** out) {
   gg->graph = g;
   gg->exec = ex;
   *out = gg;
+  ctx->live_graphs++;
   return GCNX_OK;
 }
 
@@ -318,6 +329,13 @@ int gcnx_graph_destroy(gcnx_ctx* ctx, gcnx_graph* g) {
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
   delete g;
+  if (--ctx->live_graphs <= 0) {           // nobody can replay into a retired workspace block any more
+    ctx->live_graphs = 0;
+    (void)hipStreamSynchronize(ctx->main_stream);
+    (void)hipStreamSynchronize(ctx->side_stream);
+    for (void* p : ctx->retired_ws) (void)hipFree(p);
+    ctx->retired_ws.clear();
+  }
   return GCNX_OK;
 }
 

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   if (fw) {
     int span = fo.b;                                  // gp[f_base] <= r0, answer in [f_base, f_base + span)
     while (true) {
-      const int k = __popcll(__builtin_amdgcn_ballot_w64(f_probe <= r0)) - 1;   // gp is non-decreasing: a lane prefix
+      const int k = max(__popcll(__builtin_amdgcn_ballot_w64(f_probe <= r0)) - 1, 0);   // gp is non-decreasing: a lane prefix
+                                                                                        // (gp[0] > r0, a malformed graph_ptr, stays in range)
       span = min(f_stride, span - k * f_stride);
       f_base += k * f_stride;
       if (span <= 1) break;
@@ -564,7 +565,13 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
     const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
     const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */,
-    int sg /* column slabs per unit */, int act, int nunits, int n, int dbg) {
+    int sg /* column slabs per unit */, int act, int nunits, int n, int dbg_rt) {
+#ifdef GCNX_TUNING
+  const int dbg = dbg_rt;                       // phase-ablation bits of a tuning build (results are wrong by design)
+#else
+  constexpr int dbg = 0;                        // release build: the ablation tests fold away
+  (void)dbg_rt;
+#endif
   constexpr int CPL = FT / (4 * LPR);           // float4 chunks per lane (2 only with LPR = 4, FT = 32)
   constexpr int RPW = 64 / LPR;                 // rows per wave
   constexpr int SPAN = (THREADS / 64) * RPW;
@@ -722,10 +729,7 @@ void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, 
   int lanes = f / 4;
   // Tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in floats
   // forces the lanes-per-row split of the rows kernel; results are identical.
-  if (const char* e = getenv("GCNX_SPMM_SLAB")) {
-    const int slab = atoi(e);
-    if (slab >= 16 && slab / 4 < lanes) lanes = slab / 4;
-  }
+  if (ctx->knob_spmm_slab >= 16 && ctx->knob_spmm_slab / 4 < lanes) lanes = ctx->knob_spmm_slab / 4;
   if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
   else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
   else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
@@ -746,8 +750,10 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  int dbg = 0;   // GCNX_SPMM_DBG: timing-only ablation bits (results are WRONG when set)
+  int dbg = 0;
+#ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set): only in a tuning build (make TUNING=1)
   if (const char* e = getenv("GCNX_SPMM_DBG")) dbg = atoi(e);
+#endif
   const int full = (THREADS == 512 ? 2 : 1) * ctx->num_cus;   // resident workgroups
   // column slabs per unit share one index burst; keep >= 3 units per workgroup so the static deal stays balanced
   // (config 3, measured per shape: 4 slabs per unit = 3.9 units per workgroup beats 2 slabs by 5 % and, on the
@@ -756,7 +762,7 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, cons
   int sg = 1;
   for (int c = 8; c > 1; c >>= 1)
     if (slabs % c == 0 && (long long)ngraphs * (slabs / c) >= 3LL * full) { sg = c; break; }
-  if (const char* e = getenv("GCNX_SPMM_SG")) { const int v = atoi(e); if (v >= 1 && slabs % v == 0) sg = v; }
+  if (ctx->knob_spmm_sg >= 1 && slabs % ctx->knob_spmm_sg == 0) sg = ctx->knob_spmm_sg;
   const int upg = slabs / sg;
   const long long nunits = (long long)ngraphs * upg;
   if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
@@ -864,12 +870,12 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  const char* force = getenv("GCNX_SPMM_KERNEL");  // tuning knob: "rows" disables the tile kernel, "tile" forces it
+  const int force = ctx->knob_spmm_kernel;   // tuning knob GCNX_SPMM_KERNEL (read at ctx creation): rows / tile
   // The tile kernel is a throughput design (one item per CU at a time): it needs a few items
   // per CU to fill the chip, otherwise the rows kernel's finer decomposition wins.
   bool tiles = plan && f % kSlab == 0 && (long long)(plan->n1 + 2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
-  if (force && force[0] == 'r') tiles = false;
-  if (force && force[0] == 't' && plan && f % kSlab == 0) tiles = true;
+  if (force == 1) tiles = false;
+  if (force == 2 && plan && f % kSlab == 0) tiles = true;
   if (!tiles) {
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0);
     GCNX_LAUNCH_OK(ctx);

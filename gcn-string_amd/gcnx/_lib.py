@@ -19,10 +19,13 @@ POOL_SUM, POOL_AVG, POOL_MAX = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 NORM_SPEKTRAL, NORM_PYG = 0, 1
 RED_SUM, RED_MAX = 0, 1
+CCE_PROBS, CCE_LOGITS = 0, 1
+CSR_SYMMETRIC, CSR_BLOCK_DIAGONAL, CSR_GRAPH_PTR_OK = 1, 2, 4
 UNIQUE_ID_BYTES = 128
 
 ACTS = {None: ACT_NONE, "linear": ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "prelu": ACT_PRELU}
 POOLS = {"sum": POOL_SUM, "avg": POOL_AVG, "mean": POOL_AVG, "max": POOL_MAX}
+CCES = {"probs": CCE_PROBS, "eager": CCE_PROBS, "logits": CCE_LOGITS, "graph": CCE_LOGITS}
 PRECS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -57,16 +60,17 @@ SIGNATURES = {
     "gcnx_coo_to_csr": [_vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "gcnx_collate": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "gcnx_gcn_norm": [_vp, _vp, _vp, _vp, _i32, _int, _vp],
+    "gcnx_csr_inspect": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, C.POINTER(C.c_int)],
     "gcnx_csr_transpose": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "gcnx_gemm": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp],
     "gcnx_spmm_plan_create": [_vp, _vp, _i32, C.POINTER(_vp)],
     "gcnx_spmm_plan_destroy": [_vp, _vp],
     "gcnx_spmm_csr": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp],
     "gcnx_segment_pool": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _int, _vp],
-    "gcnx_softmax_cce": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
-    "gcnx_dense_softmax_cce": [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64],
+    "gcnx_softmax_cce": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _int],
+    "gcnx_dense_softmax_cce": [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _int],
     "gcnx_pool_dense_softmax_cce": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp,
-                                    _vp, _vp, _vp, _vp, _i64, _vp],
+                                    _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "gcnx_act_bias_grad": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp],
     "gcnx_gemm_dw": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int],
     "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],

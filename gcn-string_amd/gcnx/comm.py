@@ -1,11 +1,13 @@
 """One process per GPU: RCCL communicator over the node's xGMI links, bootstrapped without MPI.
 
 The reference is single-device, so this has no reference behaviour to mirror
-except "N-GPU result == 1-GPU result".  Ranks are started by ``python -m torch.distributed.run``
-(which only sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment -- torch itself is
-never imported here, so only one HIP runtime lives in the process).  Rank 0 creates the RCCL
-unique id and publishes it through an atomically renamed file keyed by the launcher's PID and
-MASTER_PORT; all ranks of one node share that parent.
+except "N-GPU result == 1-GPU result".  Ranks are started either by ``bench.py --gpus N`` itself (it spawns one
+process per GPU before anything touches the GPU) or by ``python -m torch.distributed.run``; both only set RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment -- torch is never imported here, so only one HIP runtime
+lives in the process.  Rank 0 creates the RCCL unique id and publishes it through an atomically renamed file whose
+name is keyed by an id the LAUNCHER hands to every rank: ``GCNX_RUN_ID`` (a fresh uuid per launch: bench.py's own
+launcher, or any other launcher that exports it), else torchrun's run id + restart count + MASTER_PORT together with
+the elastic agent's pid (the one parent torchrun guarantees its workers share).  Single node by contract.
 """
 from __future__ import annotations
 
@@ -24,24 +26,36 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def _rendezvous_path():
-    port = os.environ.get("MASTER_PORT", "0")
-    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    return os.path.join(tempfile.gettempdir(), f"gcnx_uid_{os.getppid()}_{port}_{run_id}")
+def _rendezvous_path(env=None):
+    env = os.environ if env is None else env
+    port = env.get("MASTER_PORT", "0")
+    run_id = env.get("GCNX_RUN_ID")
+    if run_id:                                       # handed down by the launcher: unique per launch
+        key = f"{run_id}_{port}"
+    elif "TORCHELASTIC_RUN_ID" in env:               # torchrun: its workers are children of ONE elastic agent
+        key = f"{env['TORCHELASTIC_RUN_ID']}_{env.get('TORCHELASTIC_RESTART_COUNT', '0')}_{port}_{os.getppid()}"
+    else:                                            # some other launcher that exported neither: the port is all there is
+        key = f"port{port}"
+    return os.path.join(tempfile.gettempdir(), f"gcnx_uid_{key}")
 
 
-def exchange_unique_id(rank, world_size, timeout_s=120.0, path=None):
-    """Rank 0 writes the 128-byte id; the others poll for it."""
+def _rccl_unique_id():
     lib = L.load()
+    buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+    L.check(lib.gcnx_comm_unique_id(buf))
+    return buf.raw
+
+
+def exchange_unique_id(rank, world_size, timeout_s=120.0, path=None, make_id=_rccl_unique_id):
+    """Rank 0 writes the 128-byte id; the others poll for it."""
     path = path or _rendezvous_path()
     if rank == 0:
-        buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
-        L.check(lib.gcnx_comm_unique_id(buf))
+        raw = make_id()
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as fh:
-            fh.write(buf.raw)
+            fh.write(raw)
         os.replace(tmp, path)
-        return buf.raw
+        return raw
     t0 = time.time()
     while True:
         try:
@@ -57,6 +71,8 @@ def exchange_unique_id(rank, world_size, timeout_s=120.0, path=None):
 
 
 class Communicator:
+    capturable = True      # ncclAllReduce on the ctx stream can be recorded into the step's HIP graph
+
     def __init__(self, ctx, rank, world_size, uid_path=None):
         self.ctx, self.rank, self.world_size = ctx, rank, world_size
         self.h = None

@@ -213,16 +213,37 @@ class DeviceCSR:
     ``block_ptr`` (= graph_ptr) marks the diagonal blocks; ``symmetric`` lets the backward pass
     reuse this CSR for A^T (true for the reference's undirected contact graphs and for
     gcn_filter of a symmetric A); otherwise ``transpose()`` builds the transposed CSR once.
+    ``symmetric=None`` (the default of the constructors that take host data): checked once on the device
+    (gcnx_csr_inspect) -- the reference's loader accepts any scipy matrix, and a directed adjacency run through the
+    symmetric shortcut would give silently wrong gradients.  The same pass checks that no entry leaves its
+    graph_ptr block (what the tile plan and the folded pool backward assume); a batch that fails it is refused.
     """
 
-    def __init__(self, ctx, n, nnz, rowptr, colidx, vals=None, block_ptr=None, n_blocks=0, symmetric=True):
+    def __init__(self, ctx, n, nnz, rowptr, colidx, vals=None, block_ptr=None, n_blocks=0, symmetric=None):
         self.ctx, self.n, self.nnz = ctx, int(n), int(nnz)
         self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
         self.block_ptr, self.n_blocks = block_ptr, int(n_blocks)
-        self.symmetric = symmetric
         self._t = None
         self._plan = None
         self.dense_shape = (self.n, self.n)
+        if symmetric is None:
+            props = self.inspect()
+            symmetric = bool(props & L.CSR_SYMMETRIC)
+            if block_ptr is not None and self.n_blocks > 0 and not props & L.CSR_BLOCK_DIAGONAL:
+                raise ValueError("adjacency is not block-diagonal with respect to graph_ptr (a DisjointLoader batch is: "
+                                 "sp.block_diag); graph_ptr must start at 0, end at N and be non-decreasing")
+        self.symmetric = bool(symmetric)
+
+    def inspect(self):
+        """Device-side structure check (gcnx_csr_inspect): bit set of L.CSR_SYMMETRIC / CSR_BLOCK_DIAGONAL /
+        CSR_GRAPH_PTR_OK."""
+        props = C.c_int(0)
+        has_blocks = self.block_ptr is not None and self.n_blocks > 0
+        self.ctx._ck(self.ctx.lib.gcnx_csr_inspect(self.ctx.h, self.rowptr.ptr, self.colidx.ptr,
+                                                    self.vals.ptr if self.vals is not None else None, self.n,
+                                                    self.block_ptr.ptr if has_blocks else None,
+                                                    self.n_blocks if has_blocks else 0, C.byref(props)))
+        return props.value
 
     @property
     def plan(self):
@@ -244,7 +265,7 @@ class DeviceCSR:
         return p.h
 
     @classmethod
-    def from_host_csr(cls, ctx, rowptr, colidx, vals=None, graph_ptr=None, symmetric=True):
+    def from_host_csr(cls, ctx, rowptr, colidx, vals=None, graph_ptr=None, symmetric=None):
         n = len(rowptr) - 1
         d_rp = ctx.to_device(rowptr, np.int32)
         d_ci = ctx.to_device(colidx, np.int32)
@@ -253,7 +274,7 @@ class DeviceCSR:
         return cls(ctx, n, len(colidx), d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric)
 
     @classmethod
-    def from_coo(cls, ctx, indices, values, n, graph_ptr=None, symmetric=True, weighted=True):
+    def from_coo(cls, ctx, indices, values, n, graph_ptr=None, symmetric=None, weighted=True):
         """DisjointLoader's SparseTensor (indices[nnz,2] int64 row-major sorted) -> device CSR
         via gcnx_coo_to_csr (the COO never becomes a host CSR)."""
         indices = np.asarray(indices)
@@ -383,7 +404,7 @@ def segment_pool_bwd(ctx, seg, dpooled, dx, mode="sum", argmax=None, y=None, db=
 
 
 def pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None,
-                           dpooled=None, mode="sum", argmax=None, db_relu=None):
+                           dpooled=None, mode="sum", argmax=None, db_relu=None, cce="logits"):
     """segment_pool + dense_softmax_cce as one call (gcnx_pool_dense_softmax_cce): ``pooled`` is written as well;
     ``db_relu`` = column sums of pool'(dpooled) * [x > 0] (the bias gradient of the ReLU layer that produced x)."""
     b, h = pooled.shape
@@ -393,7 +414,7 @@ def pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, loss_acc=None
                                                 pooled.ld, _p(w), _p(bias), _p(y), b, h, c,
                                                 float(denom if denom else max(b, 1)), _p(probs), _p(loss_acc), _p(dw),
                                                 _p(db), _p(dpooled), dpooled.ld if dpooled is not None else 0,
-                                                _p(db_relu)))
+                                                _p(db_relu), L.CCES[cce]))
     return probs
 
 
@@ -413,20 +434,23 @@ def pool_bwd_colsum(ctx, seg, dpooled, y, db, mode="sum"):
     return db
 
 
-def softmax_cce(ctx, logits, y, probs, loss_acc, dlogits=None, denom=None):
+def softmax_cce(ctx, logits, y, probs, loss_acc, dlogits=None, denom=None, cce="logits"):
+    """cce = "logits": the softmax_cross_entropy_with_logits form Keras runs inside tf.function (gcn.py:328-335);
+    "probs": the renormalise-and-clip form it runs on eager tensors (evaluate, gcn.py:351-354)."""
     b, c = logits.shape
     ctx._ck(ctx.lib.gcnx_softmax_cce(ctx.h, _p(logits), _p(y), b, c, float(denom if denom else b), _p(probs),
-                                     _p(loss_acc), _p(dlogits)))
+                                     _p(loss_acc), _p(dlogits), L.CCES[cce]))
 
 
-def dense_softmax_cce(ctx, pooled, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None, dpooled=None):
+def dense_softmax_cce(ctx, pooled, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None, dpooled=None,
+                      cce="logits"):
     """The classifier head in one launch (gcnx_dense_softmax_cce): probs = softmax(pooled W + b); with labels y
     also loss_acc = [CCE sum / denom, #correct] (overwritten); with dw also dw, db, dpooled."""
     b, h = pooled.shape
     c = w.shape[1]
     ctx._ck(ctx.lib.gcnx_dense_softmax_cce(ctx.h, _p(pooled), pooled.ld, _p(w), _p(bias), _p(y), b, h, c,
                                            float(denom if denom else max(b, 1)), _p(probs), _p(loss_acc), _p(dw), _p(db),
-                                           _p(dpooled), dpooled.ld if dpooled is not None else 0))
+                                           _p(dpooled), dpooled.ld if dpooled is not None else 0, L.CCES[cce]))
     return probs
 
 

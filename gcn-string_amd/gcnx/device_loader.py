@@ -22,7 +22,7 @@ from .models import DeviceBatch
 class DeviceDataset:
     """All graphs of a ``Dataset`` resident in HBM."""
 
-    def __init__(self, ctx, dataset, normalize=None, weighted=True, symmetric=True):
+    def __init__(self, ctx, dataset, normalize=None, weighted=True, symmetric=None):
         self.ctx = ctx
         graphs = [dataset[i] for i in range(len(dataset))]
         (x, a, i), y = collate_disjoint(graphs)
@@ -34,7 +34,7 @@ class DeviceDataset:
         csr = D.DeviceCSR.from_coo(ctx, a.indices, a.values, n, graph_ptr=seg.host, symmetric=symmetric, weighted=weighted)
         if normalize:
             csr = csr.gcn_norm(normalize)
-        self.csr, self.symmetric = csr, symmetric
+        self.csr, self.symmetric = csr, csr.symmetric    # checked once on the union (symmetric=None); batches inherit it
         rows = np.asarray(a.indices)[:, 0]
         rowptr_host = np.zeros(n + 1, np.int64)
         np.cumsum(np.bincount(rows, minlength=n), out=rowptr_host[1:])

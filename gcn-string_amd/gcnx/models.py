@@ -35,7 +35,7 @@ class DeviceBatch:
         self.n_graphs = seg.n_graphs
 
     @classmethod
-    def from_host(cls, ctx, inputs, y=None, normalize=None, weighted=True, symmetric=True):
+    def from_host(cls, ctx, inputs, y=None, normalize=None, weighted=True, symmetric=None):
         """inputs = (x, a, i) as yielded by DisjointLoader.  ``a`` is a SparseTensor (COO) or a
         scipy sparse matrix.  normalize='spektral'|'pyg' applies gcn_filter on the device (the
         CSR must then hold every diagonal entry, as the reference's self-looped graphs do)."""
@@ -115,8 +115,16 @@ class _GraphRunner:
 class GCN2(_GraphRunner):
     PARAM_ORDER = ("w1", "b1", "w2", "b2", "w3", "b3")
 
-    def __init__(self, ctx, n_labels=2, hidden=None, pool="sum", prec="f32", seed=0, comm=None, use_graph=True):
+    def __init__(self, ctx, n_labels=2, hidden=None, pool="sum", prec="f32", seed=0, comm=None, use_graph=True,
+                 cce_train="logits", cce_eval="probs"):
+        """cce_train / cce_eval: which branch of keras.backend.categorical_crossentropy the loss follows (see
+        gcnx_cce_mode in include/gcnx.h).  train_step runs under tf.function (gcn.py:328-335), where Keras swaps the
+        Softmax op's output for its input and calls softmax_cross_entropy_with_logits ("logits": no clip, gradient
+        (p - y)/B everywhere); evaluate() is eager (gcn.py:351-354) and, on TF < 2.6, takes the renormalise-and-clip
+        branch ("probs").  cce_eval="logits" is the TF >= 2.6 behaviour (the output carries _keras_logits).  The
+        reference pins neither TensorFlow nor Spektral, so both stay selectable: PARITY UNPINNED."""
         self.ctx, self.n_labels, self.hidden, self.pool, self.prec = ctx, int(n_labels), hidden, pool, prec
+        self.cce_train, self.cce_eval = cce_train, cce_eval
         self.comm = comm                     # gcnx.comm.Communicator or None
         self.use_graph = use_graph
         self._rng = np.random.default_rng(seed)
@@ -201,10 +209,10 @@ class GCN2(_GraphRunner):
             # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"],
-                                     db_relu=self.g["b2"] if self._fold(batch) else None, **head)
+                                     db_relu=self.g["b2"] if self._fold(batch) else None, cce=self.cce_train, **head)
         elif with_loss:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
-                                     self.loss_acc, denom, **head)
+                                     self.loss_acc, denom, cce=self.cce_eval, **head)
         else:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], None, bufs["probs"], **head)
 
@@ -307,23 +315,48 @@ class GCN2(_GraphRunner):
         self._run(("fwd", batch.uid), lambda: self._forward(batch, bufs, False, None))
         return bufs["probs"].numpy()
 
+    def _comm_in_graph(self):
+        """Multi-GPU: the gradient all-reduce is recorded INTO the step graph (RCCL enqueues on the ctx stream and
+        supports stream capture), so a sharded step is one graph launch -- gradient kernels, ncclAllReduce, SGD --
+        instead of graph | eager collective | graph (two graph boundaries around a 0.14 ms step).  Falls back to
+        that three-part form if the communicator cannot be captured (the thread-rank test transport) or a capture
+        with the collective inside ever fails."""
+        return (self.use_graph and self._world() > 1 and getattr(self.comm, "capturable", False)
+                and not getattr(self, "_comm_capture_failed", False))
+
     def loss_and_grads(self, inputs, target, global_batch=None, _lr=None):
-        """Forward + loss + every gradient (no update).  Returns the device batch."""
+        """Forward + loss + every gradient (no update unless ``_lr``).  Returns the device batch."""
         batch = self._as_batch(inputs, target)
         bufs = self._ensure(batch)
         denom = float(global_batch or batch.n_graphs)
-        multi = self.comm is not None and self.comm.world_size > 1
+        multi = self._world() > 1
+        fused_comm = multi and _lr is not None and self._comm_in_graph()
 
         def seq():
             self._forward(batch, bufs, "grads", denom)
             if self._backward(batch, bufs, None if multi else _lr):
                 return
-            if _lr is not None and not multi:
-                # single process: the update rides in the same captured graph (one graph launch per step)
+            if fused_comm:
+                self.comm.allreduce_sum(self.flat_g)
+            if _lr is not None and (fused_comm or not multi):
+                # the update rides in the same captured graph (one graph launch per step)
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
-        self._run(("grad", batch.uid, denom, None if multi else _lr), seq)
-        if multi:
+        self._step_applied = fused_comm or not multi
+        try:
+            self._run(("grad", batch.uid, denom, _lr if self._step_applied else None), seq)
+        except Exception as e:
+            if not fused_comm:
+                raise
+            # capture with the collective inside failed: from now on graph | all-reduce | graph (every rank runs the
+            # same software, so every rank lands here together)
+            import sys
+            print(f"gcnx: RCCL all-reduce could not be captured into the step graph ({e}); falling back to an eager "
+                  f"collective between two graphs", file=sys.stderr)
+            self._comm_capture_failed = True
+            self._drop_graphs()
+            return self.loss_and_grads(batch, None, global_batch, _lr)
+        if multi and not fused_comm:
             self.comm.allreduce_sum(self.flat_g)
         self._last_batch = batch
         return batch
@@ -332,7 +365,7 @@ class GCN2(_GraphRunner):
         """One optimisation step (gcn.py:330-340).  With a communicator the batch given here is
         this rank's shard and ``global_batch`` the number of graphs over all ranks."""
         batch = self.loss_and_grads(inputs, target, global_batch, _lr=float(lr))
-        if self.comm is not None and self.comm.world_size > 1:
+        if not self._step_applied:
             self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
         if not fetch:
             return None
@@ -390,8 +423,9 @@ class GeneralGNN(_GraphRunner):
 
     def __init__(self, ctx, output, activation=None, hidden=256, message_passing=4, pre_process=2, post_process=2,
                  connectivity="cat", batch_norm=True, dropout=0.0, aggregate="sum", hidden_activation="prelu", pool="sum",
-                 prec="f32", seed=0, use_graph=True, comm=None):
+                 prec="f32", seed=0, use_graph=True, comm=None, cce_train="logits", cce_eval="probs"):
         self.use_graph, self._graphs = use_graph, {}
+        self.cce_train, self.cce_eval = cce_train, cce_eval     # see GCN2.__init__
         self.comm = comm                                  # gcnx.comm.Communicator: sync-BN + gradient all-reduce
         unsupported = {"connectivity": (connectivity, "cat"), "batch_norm": (batch_norm, True), "dropout": (dropout, 0.0),
                        "aggregate": (aggregate, "sum"), "hidden_activation": (hidden_activation, "prelu"),
@@ -633,7 +667,7 @@ class GeneralGNN(_GraphRunner):
         def seq():
             logits = self._forward(batch, bufs, True)
             self.loss_acc.fill_zero()
-            D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom)
+            D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom, cce=self.cce_train)
             self._backward(batch, bufs, True)
             if _lr is not None and not multi:              # the update rides in the same captured graph
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
@@ -661,7 +695,7 @@ class GeneralGNN(_GraphRunner):
         bufs = self._ensure(batch)
         logits = self._forward(batch, bufs, False)
         self.loss_acc.fill_zero()
-        D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, None, batch.n_graphs)
+        D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, None, batch.n_graphs, cce=self.cce_eval)
         la = self.loss_acc.numpy()
         return float(la[0]), float(la[1]) / batch.n_graphs, bufs["probs"].numpy()
 

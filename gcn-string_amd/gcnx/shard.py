@@ -13,10 +13,16 @@ import numpy as np
 def partition_graphs(graph_ptr, rowptr, world_size, f=1):
     """Returns bounds[world_size+1]: rank r owns graphs [bounds[r], bounds[r+1])."""
     gp = np.asarray(graph_ptr, dtype=np.int64)
-    b = len(gp) - 1
     nodes = np.diff(gp)
     nnz = np.asarray(rowptr, dtype=np.int64)[gp[1:]] - np.asarray(rowptr, dtype=np.int64)[gp[:-1]]
-    cost = (nnz + nodes).astype(np.float64) * f
+    return partition_by_cost((nnz + nodes).astype(np.float64) * f, world_size)
+
+
+def partition_by_cost(cost, world_size):
+    """Contiguous graph ranges of (nearly) equal summed cost: bounds[world_size+1].  Needs only the per-graph costs,
+    so a rank can partition a batch whose graphs it has not built (bench.py: every rank builds its own shard)."""
+    cost = np.asarray(cost, dtype=np.float64)
+    b = len(cost)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     total = cum[-1]
     bounds = [0]

@@ -176,11 +176,108 @@ def block_diag_batch(n=1_000_000, nnz=10_000_000, f=256, seed=2, mean_size=600, 
     return HostBatch(x, rowptr, colidx, None, gp.astype(np.int32), _labels(rng, b))
 
 
+# ---- shardable generators: graph g comes from its own random stream ---------------------------------
+# bench.py (every N, including 1) uses these: a rank builds ONLY the graphs of its shard -- sizes of all graphs are
+# cheap and generated everywhere (the partition needs them), edges and features only for the own range -- and the
+# global batch is the same whatever the number of ranks (graph g depends on (seed, g) alone).
+
+def _graph_rng(seed, g, stream=0):
+    return np.random.default_rng([int(seed), int(g), int(stream)])
+
+
+def ecoli_sizes(n_graphs, seed=1):
+    """(n_g, nnz_g upper estimate) of every graph of the per-graph-seeded E. coli batch (cheap: two draws per graph)."""
+    sizes = np.empty(n_graphs, np.int64)
+    for g in range(n_graphs):
+        rng = _graph_rng(seed, g)
+        sizes[g] = sum(int(np.clip(rng.lognormal(np.log(300.0), 0.5), 50, 1500)) for _ in range(2))
+    return sizes
+
+
+def ecoli_shard(g0, g1, f=128, seed=1):
+    """Graphs [g0, g1) of the per-graph-seeded BASELINE config 2 batch as one HostBatch (local indices)."""
+    sizes, us, vs, xs, off = [], [], [], [], 0
+    for g in range(g0, g1):
+        rng = _graph_rng(seed, g)
+        n, u, v = ecoli_graph_pairs(rng)               # its first two draws are the chain lengths (= ecoli_sizes)
+        us.append(u + off); vs.append(v + off)
+        sizes.append(n); off += n
+        xs.append(rng.standard_normal((n, f), dtype=np.float32))
+    rowptr, colidx = _csr_from_pairs(off, np.concatenate(us), np.concatenate(vs))
+    gp = np.zeros(g1 - g0 + 1, dtype=np.int32)
+    np.cumsum(sizes, out=gp[1:])
+    lab = np.array([int(_graph_rng(seed, g, 1).integers(0, 2)) for g in range(g0, g1)])
+    y = np.zeros((g1 - g0, 2), np.float32)
+    y[np.arange(g1 - g0), lab] = 1.0
+    return HostBatch(np.concatenate(xs) if xs else np.zeros((0, f), np.float32), rowptr, colidx, None, gp, y)
+
+
+def block_diag_plan(n=1_000_000, nnz=10_000_000, seed=2, mean_size=600):
+    """Sizes and off-diagonal pair counts of every graph of the per-graph-seeded BASELINE config 3 batch: sizes as
+    block_diag_batch, pairs split in proportion to the graph sizes (largest remainder), so that the batch holds
+    exactly `nnz` entries whichever ranks build which graphs."""
+    rng = np.random.default_rng(seed)
+    sizes = _lognormal_sizes(rng, n, mean_size, 50, 3000)
+    m_target = (nnz - n) // 2
+    cap = sizes * (sizes - 1) // 2
+    quota = m_target * sizes / sizes.sum()
+    m = np.minimum(np.floor(quota).astype(np.int64), cap)
+    order = np.argsort(-(quota - np.floor(quota)), kind="stable")
+    i = 0
+    while m.sum() < m_target:
+        j = order[i % len(order)]
+        if m[j] < cap[j]:
+            m[j] += 1
+        i += 1
+    return sizes, m
+
+
+def block_diag_shard(g0, g1, sizes, pairs, f=256, seed=2, with_x=True):
+    """Graphs [g0, g1) of that batch: column indices uniform within the row's own graph, symmetric, self-loops,
+    exactly pairs[g] off-diagonal pairs in graph g."""
+    us, vs, off = [], [], 0
+    for g in range(g0, g1):
+        rng = _graph_rng(seed, g)
+        n, m = int(sizes[g]), int(pairs[g])
+        keys = np.empty(0, np.int64)
+        while keys.size < m:
+            need = int((m - keys.size) * 1.1) + 16
+            u = rng.integers(0, n, size=need)
+            v = rng.integers(0, n - 1, size=need)
+            v += (v >= u)
+            keys = np.unique(np.concatenate([keys, np.minimum(u, v) * n + np.maximum(u, v)]))
+        if keys.size > m:
+            keys = np.sort(rng.choice(keys, size=m, replace=False))
+        us.append(keys // n + off); vs.append(keys % n + off)
+        off += n
+    rowptr, colidx = _csr_from_pairs(off, np.concatenate(us), np.concatenate(vs))
+    gp = np.zeros(g1 - g0 + 1, dtype=np.int32)
+    np.cumsum(sizes[g0:g1], out=gp[1:])
+    if with_x:
+        x = np.concatenate([_graph_rng(seed, g, 2).standard_normal((int(sizes[g]), f), dtype=np.float32) for g in range(g0, g1)])
+    else:
+        x = np.zeros((off, f), np.float32)
+    lab = np.array([int(_graph_rng(seed, g, 1).integers(0, 2)) for g in range(g0, g1)])
+    y = np.zeros((g1 - g0, 2), np.float32)
+    y[np.arange(g1 - g0), lab] = 1.0
+    return HostBatch(x, rowptr, colidx, None, gp, y)
+
+
 # ---- config 5: power-law degrees, max degree 4096 ---------------------------------------------------
 
-def power_law_batch(n_graphs=122, graph_size=8192, f=256, seed=3, alpha=2.0, max_deg=4096, with_x=True):
+def power_law_batch(n_graphs=122, graph_size=8192, f=256, seed=3, alpha=2.0, max_deg=4096, with_x=True, first_graph=None):
     """BASELINE config 5: per-node target degree ~ Zipf(alpha) truncated to [1, max_deg];
-    Chung-Lu pairing inside each 8192-node graph; symmetric + self-loops."""
+    Chung-Lu pairing inside each 8192-node graph; symmetric + self-loops.
+    first_graph (bench.py, sharded runs): graphs [first_graph, first_graph + n_graphs) of the per-graph-seeded batch --
+    every graph from its own stream, the explicitly wired max-degree row in global graph 0."""
+    if first_graph is not None:
+        parts = []
+        for g in range(first_graph, first_graph + n_graphs):
+            hb = power_law_batch(1, graph_size, f, seed=[int(seed), g], alpha=alpha, max_deg=max_deg, with_x=with_x)
+            if g != 0:      # only global graph 0 carries the explicit max-degree row: rebuild without it
+                hb = _power_law_one(np.random.default_rng([int(seed), g]), graph_size, f, alpha, max_deg, with_x, wire=False)
+            parts.append(hb)
+        return concat_batches(parts)
     rng = np.random.default_rng(seed)
     n = n_graphs * graph_size
     k = np.arange(1, max_deg + 1, dtype=np.float64)
@@ -204,6 +301,38 @@ def power_law_batch(n_graphs=122, graph_size=8192, f=256, seed=3, alpha=2.0, max
     gp = (np.arange(n_graphs + 1) * graph_size).astype(np.int32)
     x = rng.standard_normal((n, f), dtype=np.float32) if with_x else np.zeros((n, f), np.float32)
     return HostBatch(x, rowptr, colidx, None, gp, _labels(rng, n_graphs))
+
+
+def _power_law_one(rng, graph_size, f, alpha, max_deg, with_x, wire):
+    k = np.arange(1, max_deg + 1, dtype=np.float64)
+    pmf = k ** (-alpha)
+    pmf /= pmf.sum()
+    deg = rng.choice(max_deg, size=graph_size, p=pmf) + 1
+    if wire:
+        deg[0] = 1
+    w = deg / deg.sum()
+    m = int(deg.sum() // 2)
+    u = rng.choice(graph_size, size=m, p=w)
+    v = rng.choice(graph_size, size=m, p=w)
+    keep = u != v
+    us, vs = [u[keep]], [v[keep]]
+    if wire:
+        nb = 1 + rng.choice(graph_size - 1, size=max_deg - 1, replace=False)
+        us.append(np.zeros(max_deg - 1, dtype=np.int64)); vs.append(nb.astype(np.int64))
+    rowptr, colidx = _csr_from_pairs(graph_size, np.concatenate(us).astype(np.int64), np.concatenate(vs).astype(np.int64))
+    x = rng.standard_normal((graph_size, f), dtype=np.float32) if with_x else np.zeros((graph_size, f), np.float32)
+    return HostBatch(x, rowptr, colidx, None, np.array([0, graph_size], np.int32), _labels(rng, 1))
+
+
+def concat_batches(parts):
+    """Disjoint union of HostBatches (block_diag of the adjacencies)."""
+    noff = np.cumsum([0] + [p.n for p in parts])
+    eoff = np.cumsum([0] + [p.nnz for p in parts])
+    rowptr = np.concatenate([[0]] + [p.rowptr[1:].astype(np.int64) + eoff[i] for i, p in enumerate(parts)]).astype(np.int32)
+    colidx = np.concatenate([p.colidx.astype(np.int64) + noff[i] for i, p in enumerate(parts)]).astype(np.int32)
+    gp = np.concatenate([[0]] + [p.graph_ptr[1:].astype(np.int64) + noff[i] for i, p in enumerate(parts)]).astype(np.int32)
+    vals = None if parts[0].vals is None else np.concatenate([p.vals for p in parts])
+    return HostBatch(np.concatenate([p.x for p in parts]), rowptr, colidx, vals, gp, np.concatenate([p.y for p in parts]))
 
 
 def spmm_algorithmic_bytes(n, nnz, f, weighted, elem=4):

@@ -61,6 +61,16 @@ typedef enum { GCNX_POOL_SUM = 0, GCNX_POOL_AVG = 1, GCNX_POOL_MAX = 2 } gcnx_po
 typedef enum { GCNX_PREC_F32 = 0, GCNX_PREC_BF16 = 1, GCNX_PREC_BF16X3 = 2 } gcnx_prec;
 typedef enum { GCNX_NORM_SPEKTRAL = 0, GCNX_NORM_PYG = 1 } gcnx_norm_mode;
 typedef enum { GCNX_RED_SUM = 0, GCNX_RED_MAX = 1 } gcnx_redop;
+/* Which of Keras' two categorical_crossentropy code paths a loss entry point follows (keras.backend.
+ * categorical_crossentropy, from_logits=False, as constructed at gcn.py:326):
+ *   PROBS  -- the output is an EagerTensor (evaluate(), gcn.py:351-354, on TF < 2.6): p <- p / sum p, clip to
+ *             [1e-7, 1 - 1e-7], -sum_c y_c log p_c; the clip passes no gradient outside its range.
+ *   LOGITS -- the output is a graph tensor produced by a Softmax op (train_step runs under tf.function, gcn.py:328-335;
+ *             on TF >= 2.6 also eagerly, through the output's _keras_logits): Keras takes the op's INPUT and calls
+ *             softmax_cross_entropy_with_logits: loss = logsumexp(z) * sum_c y_c - sum_c y_c z_c, no renormalisation,
+ *             no clip, dlogits = (p * sum_c y_c - y) / denom everywhere.
+ * The two differ only where a probability saturates beyond 1e-7 (|z_i - z_j| > ~16). */
+typedef enum { GCNX_CCE_PROBS = 0, GCNX_CCE_LOGITS = 1 } gcnx_cce_mode;
 
 #define GCNX_UNIQUE_ID_BYTES 128
 
@@ -128,6 +138,20 @@ GCNX_API int gcnx_collate(gcnx_ctx* ctx, const int32_t* desc, int32_t b, const i
  * no stored diagonal. */
 GCNX_API int gcnx_gcn_norm(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx,
                   const float* vals_in, int32_t n, int mode, float* vals_out);
+/* What the scheduling shortcuts may assume about a batch adjacency, checked once per batch on the device (the
+ * reference's loader accepts any scipy matrix, gcn.py:104-116; nothing in Spektral requires symmetry).  *props
+ * (host int) receives a bit set:
+ *   GCNX_CSR_SYMMETRIC       A == A^T (pattern; values to 4 ulp): the backward aggregation may reuse this CSR for A^T
+ *                            (otherwise build gcnx_csr_transpose);
+ *   GCNX_CSR_GRAPH_PTR_OK    graph_ptr[0] == 0, graph_ptr[b] == n, non-decreasing;
+ *   GCNX_CSR_BLOCK_DIAGONAL  every entry of a row of graph g has its column in [graph_ptr[g], graph_ptr[g+1]): the
+ *                            premise of gcnx_spmm_plan_create and gcnx_spmm_csr_pool_bwd (sp.block_diag).
+ * graph_ptr may be NULL (only symmetry is checked).  Synchronises. */
+#define GCNX_CSR_SYMMETRIC 1
+#define GCNX_CSR_BLOCK_DIAGONAL 2
+#define GCNX_CSR_GRAPH_PTR_OK 4
+GCNX_API int gcnx_csr_inspect(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, int32_t n,
+                     const int32_t* graph_ptr, int32_t b, int* props);
 /* CSR of the transpose (for the backward SpMM when A^ is not symmetric).  Synchronises. */
 GCNX_API int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx,
                        const float* vals, int32_t n, int32_t nnz, int32_t* rowptr_t,
@@ -161,24 +185,26 @@ GCNX_API int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
 GCNX_API int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx,
                       float* pooled, int32_t b, int32_t f, int mode, int32_t* argmax);
 /* K8 Softmax + CategoricalCrossentropy + categorical_accuracy (gcn.py:326,335,339):
- * probs = softmax(logits); loss_acc[0] += sum_g -sum_c y log clip(p)/ denom;
- * loss_acc[1] += #(argmax p == argmax y); dlogits = (p*sum(y*m) - y*m)/denom with m = [1e-7 < p < 1-1e-7], the
- * gradient of the clipped loss (= (p - y)/denom in the unclipped region; NULL to skip).
- * denom = global batch size (so that shard gradients add up to the full-batch gradient).
+ * probs = softmax(logits); loss_acc[0] += sum_g loss_g / denom; loss_acc[1] += #(argmax p == argmax y).
+ * cce_mode GCNX_CCE_LOGITS (the training step, gcn.py:328-335): loss_g = sum_c y_c (logsumexp(z) - z_c),
+ *   dlogits = (p * sum_c y_c - y) / denom.
+ * cce_mode GCNX_CCE_PROBS (eager evaluate, gcn.py:351-354): loss_g = -sum_c y_c log clip(p_c, 1e-7, 1 - 1e-7),
+ *   dlogits = (p * sum(y*m) - y*m) / denom with m = [1e-7 < p < 1 - 1e-7], the gradient of the clipped loss.
+ * dlogits NULL to skip.  denom = global batch size (so that shard gradients add up to the full-batch gradient).
  * loss_acc is a device float[2] that the caller zeroes. */
 GCNX_API int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t b, int32_t c,
-                     float denom, float* probs, float* loss_acc, float* dlogits);
+                     float denom, float* probs, float* loss_acc, float* dlogits, int cce_mode);
 
 /* The classifier head in ONE launch: probs = softmax(pooled * W + b)  (the model's last Dense,
  * gcn.py:320 activation="softmax"), loss_acc[0] = CCE(y, probs) summed over the b graphs / denom and
  * loss_acc[1] = #(argmax probs == argmax y)  (gcn.py:326,335,339; loss_acc is OVERWRITTEN, not accumulated),
  * and, when dw != NULL, the head gradients tape.gradient (gcn.py:337) produces:
- * dlogits as gcnx_softmax_cce, dw[h,c] = pooled^T dlogits, db[c] = sum_g dlogits, dpooled[b,h] = dlogits W^T.
+ * dlogits as gcnx_softmax_cce (same cce_mode), dw[h,c] = pooled^T dlogits, db[c] = sum_g dlogits, dpooled[b,h] = dlogits W^T.
  * y == NULL: probabilities only.  c <= 32.  Same results as gcnx_gemm + gcnx_softmax_cce + gcnx_gemm_dw +
  * gcnx_act_bias_grad + gcnx_gemm_dx up to fp32 summation order; deterministic (fixed reduction order). */
 GCNX_API int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const float* w, const float* bias,
                            const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
-                           float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp);
+                           float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp, int cce_mode);
 
 /* GlobalSumPool / GlobalAvgPool / GlobalMaxPool (gcn.py:319) + the head above as one call: pooled[b,h] =
  * gcnx_segment_pool(x[n,h]) is still written (the caller's saved activation), but where the pool is split into
@@ -194,7 +220,7 @@ GCNX_API int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr
                                 int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
                                 const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,
                                 float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp,
-                                float* db_relu);
+                                float* db_relu, int cce_mode);
 
 /* ---- backward (what tape.gradient, gcn.py:337, generates) -------------------------------- */
 /* dZ = dY * act'(Y) (mask taken from the saved output Y; PReLU uses the saved pre-activation

@@ -74,10 +74,15 @@ class Gcn2Cpu:
         self.x = np.ascontiguousarray(batch.x, np.float32)
         self.y = np.ascontiguousarray(batch.y, np.float32)
 
-    def step(self, lr=0.0, denom=None):
+    def step(self, lr=0.0, denom=None, cce="logits", bf16_operands=False):
+        """cce "logits": the loss train_step computes under tf.function; "probs": the eager clip form.
+        bf16_operands: every dense product sees bf16-rounded operands (fp32 accumulate) -- the GCNX_PREC_BF16 model."""
         b = self.b
+        self.lib.orc_set_bf16_operands(C.c_int(1 if bf16_operands else 0))
         self.lib.orc_gcn2_step(_f(self.rowptr), _f(self.colidx), _f(self.vals), _f(self.gp), _f(self.x), _f(self.y),
                                C.c_int32(b.n), C.c_int32(b.n_graphs), C.c_int32(b.f), C.c_int32(self.h),
                                C.c_int32(self.c), _f(self.params), _f(self.grads), C.c_float(lr),
-                               C.c_float(denom or b.n_graphs), _f(self.work), _f(self.out))
+                               C.c_float(denom or b.n_graphs), _f(self.work), _f(self.out),
+                               C.c_int(1 if cce == "logits" else 0))
+        self.lib.orc_set_bf16_operands(C.c_int(0))
         return float(self.out[0]), float(self.out[1]) / b.n_graphs

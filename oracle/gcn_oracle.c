@@ -41,6 +41,22 @@ API void orc_set_threads(int n) {
 #endif
 }
 
+/* GEMM operand model.  0: fp32 operands (TensorFlow's CPU MatMul; GCNX_PREC_F32 / BF16X3 are held to this).  1: both
+ * operands of every dense product rounded to bfloat16 (round-to-nearest-even), products and sums in fp32 -- the
+ * arithmetic of BASELINE config 3's "bf16 MFMA weight GEMM" (GCNX_PREC_BF16), so that the plain-bf16 path can be
+ * checked against an oracle fed the same rounded operands instead of a loose bound. */
+static int g_bf16 = 0;
+API void orc_set_bf16_operands(int on) { g_bf16 = on; }
+static inline float opnd(float v) {
+  if (!g_bf16) return v;
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return v;          /* inf / nan unchanged */
+  u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  memcpy(&v, &u, 4);
+  return v;
+}
+
 /* K2/K3: out[t] = act(sum_e vals[e] * h[colidx[e]] + bias); vals NULL = ones. */
 API void orc_spmm_csr(const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h, int64_t ldh,
                       const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int relu) {
@@ -67,9 +83,10 @@ API void orc_gemm(const float* x, int64_t ldx, const float* w, const float* bias
     for (int32_t j = 0; j < fo; ++j) o[j] = 0.f;
     const float* xr = x + r * ldx;
     for (int32_t k = 0; k < fi; ++k) {
-      const float a = xr[k];
+      const float a = opnd(xr[k]);
       const float* wk = w + (int64_t)k * fo;
-      for (int32_t j = 0; j < fo; ++j) o[j] += a * wk[j];
+      if (g_bf16) for (int32_t j = 0; j < fo; ++j) o[j] += a * opnd(wk[j]);
+      else for (int32_t j = 0; j < fo; ++j) o[j] += a * wk[j];
     }
     if (bias) for (int32_t j = 0; j < fo; ++j) o[j] += bias[j];
     if (relu) for (int32_t j = 0; j < fo; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
@@ -86,19 +103,26 @@ API void orc_gemm_dx(const float* dh, int64_t lddh, const float* w, float* dx, i
     for (int32_t i = 0; i < fi; ++i) {
       const float* wi = w + (int64_t)i * fo;
       float s = 0.f;
-      for (int32_t k = 0; k < fo; ++k) s += d[k] * wi[k];
+      if (g_bf16) for (int32_t k = 0; k < fo; ++k) s += opnd(d[k]) * opnd(wi[k]);
+      else for (int32_t k = 0; k < fo; ++k) s += d[k] * wi[k];
       if (y_mask && !(y_mask[r * ldy + i] > 0.f)) s = 0.f;
       o[i] = s;
     }
   }
 }
 
-/* K1^T a: dW[Fi,Fo] = X^T dH (reduction over the N rows).  Per-thread partials summed in
- * thread order; the row order inside a thread is ascending. */
+/* K1^T a: dW[Fi,Fo] = X^T dH (reduction over the N rows).  Blocked summation: fp32 products and fp32 sums inside a
+ * block of 256 rows (what an fp32 kernel does), block sums combined in double, blocks in ascending row order per thread
+ * and threads in thread order -- so that at N = 10^6 rows the checker's own rounding (a serial fp32 sum drifts by
+ * ~sqrt(N) ulp) stays far below the 1e-4 bar it is used to judge.  Eigen's MatMul / reductions are blocked / pairwise
+ * too; no summation order of TensorFlow's is being claimed. */
+#define ORC_BLK 256
 API void orc_gemm_dw(const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n, int32_t fi,
                      int32_t fo) {
   const int nt = orc_max_threads();
-  float* part = (float*)calloc((size_t)nt * fi * fo, sizeof(float));
+  const size_t sz = (size_t)fi * fo;
+  double* part = (double*)calloc((size_t)nt * sz, sizeof(double));
+  const int64_t nblk = (n + ORC_BLK - 1) / ORC_BLK;
 #pragma omp parallel
   {
 #ifdef _OPENMP
@@ -106,30 +130,46 @@ API void orc_gemm_dw(const float* x, int64_t ldx, const float* dh, int64_t lddh,
 #else
     const int t = 0;
 #endif
-    float* p = part + (size_t)t * fi * fo;
+    double* p = part + (size_t)t * sz;
+    float* blk = (float*)malloc(sz * sizeof(float));
 #pragma omp for schedule(static)
-    for (int64_t r = 0; r < n; ++r) {
-      const float* xr = x + r * ldx;
-      const float* d = dh + r * lddh;
-      for (int32_t i = 0; i < fi; ++i) {
-        const float a = xr[i];
-        float* pi = p + (size_t)i * fo;
-        for (int32_t j = 0; j < fo; ++j) pi[j] += a * d[j];
+    for (int64_t bi = 0; bi < nblk; ++bi) {
+      const int64_t r0 = bi * ORC_BLK, r1 = r0 + ORC_BLK < n ? r0 + ORC_BLK : n;
+      memset(blk, 0, sz * sizeof(float));
+      for (int64_t r = r0; r < r1; ++r) {
+        const float* xr = x + r * ldx;
+        const float* d = dh + r * lddh;
+        for (int32_t i = 0; i < fi; ++i) {
+          const float a = opnd(xr[i]);
+          float* pi = blk + (size_t)i * fo;
+          if (g_bf16) for (int32_t j = 0; j < fo; ++j) pi[j] += a * opnd(d[j]);
+          else for (int32_t j = 0; j < fo; ++j) pi[j] += a * d[j];
+        }
       }
+      for (size_t q = 0; q < sz; ++q) p[q] += (double)blk[q];
     }
+    free(blk);
   }
-  for (int64_t q = 0; q < (int64_t)fi * fo; ++q) {
-    float s = 0.f;
-    for (int t = 0; t < nt; ++t) s += part[(size_t)t * fi * fo + q];
-    dw[q] = s;
+  for (size_t q = 0; q < sz; ++q) {
+    double s = 0.0;
+    for (int t = 0; t < nt; ++t) s += part[(size_t)t * sz + q];
+    dw[q] = (float)s;
   }
   free(part);
 }
 
 API void orc_colsum(const float* x, int64_t ldx, int64_t n, int32_t f, float* out) {
-  for (int32_t c = 0; c < f; ++c) out[c] = 0.f;
-  for (int64_t r = 0; r < n; ++r)
-    for (int32_t c = 0; c < f; ++c) out[c] += x[r * ldx + c];
+  double* acc = (double*)calloc((size_t)f, sizeof(double));
+  float* blk = (float*)malloc((size_t)f * sizeof(float));
+  for (int64_t r0 = 0; r0 < n; r0 += ORC_BLK) {
+    const int64_t r1 = r0 + ORC_BLK < n ? r0 + ORC_BLK : n;
+    for (int32_t c = 0; c < f; ++c) blk[c] = 0.f;
+    for (int64_t r = r0; r < r1; ++r)
+      for (int32_t c = 0; c < f; ++c) blk[c] += x[r * ldx + c];
+    for (int32_t c = 0; c < f; ++c) acc[c] += (double)blk[c];
+  }
+  for (int32_t c = 0; c < f; ++c) out[c] = (float)acc[c];
+  free(acc); free(blk);
 }
 
 /* K4: mode 0 sum, 1 avg, 2 max (first maximal row wins; argmax row index). */
@@ -172,10 +212,15 @@ API void orc_pool_bwd(const int32_t* gp, const float* dp, float* dx, int64_t ldd
   }
 }
 
-/* K8: softmax; Keras CCE with clip [1e-7, 1-1e-7]; categorical accuracy.
+/* K8: softmax; Keras CCE; categorical accuracy.
+ * from_logits = 0: the eager branch of keras.backend.categorical_crossentropy (evaluate, gcn.py:351-354): renormalise,
+ *   clip [1e-7, 1-1e-7], -sum y log p; the clip passes no gradient outside.
+ * from_logits = 1: what the same loss object computes inside tf.function (train_step, gcn.py:328-335): Keras takes the
+ *   Softmax op's input and calls softmax_cross_entropy_with_logits: sum_c y_c (logsumexp(z) - z_c), dlogits =
+ *   (p sum_c y_c - y) / denom.
  * loss_acc[0] += sum_g loss_g / denom, loss_acc[1] += #correct. */
 API void orc_softmax_cce(const float* logits, const float* y, int32_t b, int32_t c, float denom, float* probs,
-                         float* loss_acc, float* dlogits) {
+                         float* loss_acc, float* dlogits, int from_logits) {
   float loss = 0.f, hit = 0.f;
   for (int32_t g = 0; g < b; ++g) {
     const float* z = logits + (int64_t)g * c;
@@ -189,17 +234,21 @@ API void orc_softmax_cce(const float* logits, const float* y, int32_t b, int32_t
     for (int32_t k = 0; k < c; ++k) {
       const float p = expf(z[k] - m) / sum;
       probs[(int64_t)g * c + k] = p;
-      if (p > 1e-7f && p < 1.0f - 1e-7f) ymsum += yy[k];  /* clip passes no gradient outside */
+      if (from_logits || (p > 1e-7f && p < 1.0f - 1e-7f)) ymsum += yy[k];  /* clip passes no gradient outside */
       if (p > pmax) { pmax = p; pa = k; }
       if (yy[k] > ymax) { ymax = yy[k]; ya = k; }
-      float pc = p < 1e-7f ? 1e-7f : p;
-      pc = pc > 1.0f - 1e-7f ? 1.0f - 1e-7f : pc;
-      l -= yy[k] * logf(pc);
+      if (from_logits) {
+        l += yy[k] * ((m - z[k]) + logf(sum));
+      } else {
+        float pc = p < 1e-7f ? 1e-7f : p;
+        pc = pc > 1.0f - 1e-7f ? 1.0f - 1e-7f : pc;
+        l -= yy[k] * logf(pc);
+      }
     }
     if (dlogits)
       for (int32_t k = 0; k < c; ++k) {
         const float p = probs[(int64_t)g * c + k];
-        const float ym = (p > 1e-7f && p < 1.0f - 1e-7f) ? yy[k] : 0.f;
+        const float ym = (from_logits || (p > 1e-7f && p < 1.0f - 1e-7f)) ? yy[k] : 0.f;
         dlogits[(int64_t)g * c + k] = (p * ymsum - ym) / denom;
       }
     loss += l;
@@ -213,10 +262,11 @@ API void orc_softmax_cce(const float* logits, const float* y, int32_t b, int32_t
  * GCNConv(F->H,relu) -> GCNConv(H->H,relu) -> GlobalSumPool -> Dense(H->C) softmax, CCE,
  * all gradients, optional SGD apply (lr > 0).  params/grads flat: w1,b1,w2,b2,w3,b3.
  * work: caller-provided scratch of 4*N*H + 2*B*H + 3*B*C floats.  Adjacency assumed symmetric
- * (the reference's data) so A^T = A.  Returns loss in out[0], #correct in out[1]. */
+ * (the reference's data) so A^T = A.  Returns loss in out[0], #correct in out[1].
+ * from_logits: the CCE branch (orc_softmax_cce); 1 is what train_step runs under tf.function. */
 API void orc_gcn2_step(const int32_t* rowptr, const int32_t* colidx, const float* vals, const int32_t* gp,
                        const float* x, const float* y, int32_t n, int32_t b, int32_t f, int32_t hdim, int32_t c,
-                       float* params, float* grads, float lr, float denom, float* work, float* out) {
+                       float* params, float* grads, float lr, float denom, float* work, float* out, int from_logits) {
   float* w1 = params;            float* b1 = w1 + (int64_t)f * hdim;
   float* w2 = b1 + hdim;         float* b2 = w2 + (int64_t)hdim * hdim;
   float* w3 = b2 + hdim;         float* b3 = w3 + (int64_t)hdim * c;
@@ -236,7 +286,7 @@ API void orc_gcn2_step(const int32_t* rowptr, const int32_t* colidx, const float
   orc_pool(gp, y2, hdim, pooled, b, hdim, 0, NULL);
   orc_gemm(pooled, hdim, w3, b3, logits, c, b, hdim, c, 0);
   out[0] = out[1] = 0.f;
-  orc_softmax_cce(logits, y, b, c, denom, probs, out, dlogits);
+  orc_softmax_cce(logits, y, b, c, denom, probs, out, dlogits, from_logits);
 
   orc_gemm_dw(pooled, hdim, dlogits, c, gw3, b, hdim, c);
   orc_colsum(dlogits, c, b, c, gb3);

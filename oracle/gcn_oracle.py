@@ -284,6 +284,34 @@ def softmax_cce_grad(y, p, denom=None):
     return (p * ym.sum(1, keepdims=True) - ym) / bsz
 
 
+def cce_loss_from_logits(y, z, denom=None):
+    """What Keras' CategoricalCrossentropy() (from_logits=False, gcn.py:326) evaluates INSIDE tf.function
+    (train_step, gcn.py:328-335): keras.backend.categorical_crossentropy sees a graph tensor produced by a Softmax op
+    (TF >= 2.6: an output carrying _keras_logits), takes that op's input and calls
+    tf.nn.softmax_cross_entropy_with_logits -- no renormalisation, no clip:
+    loss_g = sum_c y_c * (logsumexp(z) - z_c), mean over the batch."""
+    m = z.max(1, keepdims=True)
+    lse = m + np.log(np.exp(z - m).sum(1, keepdims=True))
+    per = (y * (lse - z)).sum(1)
+    return per.sum() / (len(y) if denom is None else denom)
+
+
+def softmax_cce_grad_from_logits(y, p, denom=None):
+    """dL/dlogits of softmax_cross_entropy_with_logits: (p * sum_c y_c - y) / B everywhere."""
+    bsz = len(y) if denom is None else denom
+    return (p * y.sum(1, keepdims=True) - y) / bsz
+
+
+def cce(y, logits, probs, denom=None, mode="logits"):
+    """(loss, dlogits) of the two Keras code paths: mode "logits" = inside tf.function (train_step), "probs" = on eager
+    tensors (evaluate(), gcn.py:351-354, TF < 2.6)."""
+    if mode == "logits":
+        return cce_loss_from_logits(y, logits, denom), softmax_cce_grad_from_logits(y, probs, denom)
+    if mode == "probs":
+        return cce_loss(y, probs, denom), softmax_cce_grad(y, probs, denom)
+    raise ValueError(mode)
+
+
 def categorical_accuracy(y, p):
     return float(np.mean(np.argmax(y, 1) == np.argmax(p, 1)))
 
@@ -320,14 +348,14 @@ def gcn2_forward(params, x, csr, graph_ptr, pool="sum"):
                    "y1": y1, "y2": y2}
 
 
-def gcn2_loss_and_grads(params, x, csr, graph_ptr, y, pool="sum", denom=None, csr_t=None):
+def gcn2_loss_and_grads(params, x, csr, graph_ptr, y, pool="sum", denom=None, csr_t=None, cce_mode="logits"):
     """Returns loss, acc, grads dict, cache.  ``denom`` = global batch size B when this
-    call sees only a shard of the batch: summed shard grads == full-batch grads."""
+    call sees only a shard of the batch: summed shard grads == full-batch grads.
+    cce_mode "logits" (default) is the loss train_step computes under tf.function; "probs" the eager form."""
     probs, cache = gcn2_forward(params, x, csr, graph_ptr, pool)
     yf = y.astype(probs.dtype)
-    loss = cce_loss(yf, probs, denom)
+    loss, dlogits = cce(yf, cache["logits"], probs, denom, cce_mode)
     acc = categorical_accuracy(yf, probs)
-    dlogits = softmax_cce_grad(yf, probs, denom)
     g = {}
     g["w3"] = cache["pooled"].T @ dlogits
     g["b3"] = dlogits.sum(0)
@@ -411,7 +439,7 @@ def dense_bn_act_fwd(x, p, training, act, final_softmax=False):
     z = x @ p["kernel"] + p["bias"]
     zb, bnc, mm, mv = bn_fwd(z, p["gamma"], p["beta"], p["moving_mean"], p["moving_var"], training)
     if final_softmax:
-        y = softmax(zb)
+        y = softmax(zb)                                  # zb = the Softmax op's input (the logits Keras' loss takes)
     elif act == "prelu":
         y = act_fwd(zb, "prelu", p["alpha"])
     else:
@@ -494,11 +522,11 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
     return out, caches, stats
 
 
-def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None):
+def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits"):
     rowptr, colidx, _ = csr
     probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True)
     yf = y.astype(probs.dtype)
-    loss = cce_loss(yf, probs)
+    loss, dlogits = cce(yf, caches["post"][-1]["zb"], probs, None, cce_mode)
     acc = categorical_accuracy(yf, probs)
     grads = {"pre": [None] * len(layers["pre"]), "gnn": [None] * len(layers["gnn"]),
              "post": [None] * len(layers["post"])}
@@ -507,7 +535,7 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None):
     for k in reversed(range(n_post)):
         p, c = layers["post"][k], caches["post"][k]
         if k == n_post - 1:
-            d, grads["post"][k] = dense_bn_act_bwd(None, c, p, None, True, dzb=softmax_cce_grad(yf, probs))
+            d, grads["post"][k] = dense_bn_act_bwd(None, c, p, None, True, dzb=dlogits)
         else:
             d, grads["post"][k] = dense_bn_act_bwd(d, c, p, "prelu", True)
     d = global_pool_bwd(d, graph_ptr, x.shape[0], "sum")

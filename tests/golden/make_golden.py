@@ -32,7 +32,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def torch_gcn2(params, x, rowptr, colidx, vals, gp, y, pool):
+def torch_gcn2(params, x, rowptr, colidx, vals, gp, y, pool, cce_mode):
     import torch
 
     n = x.shape[0]
@@ -48,14 +48,19 @@ def torch_gcn2(params, x, rowptr, colidx, vals, gp, y, pool):
         seg = y2[gp[g]:gp[g + 1]]
         pooled.append(seg.sum(0) if pool == "sum" else seg.mean(0) if pool == "avg" else seg.max(0).values)
     pooled = torch.stack(pooled)
-    probs = torch.softmax(pooled @ tp["w3"] + tp["b3"], dim=1)
-    pc = torch.clamp(probs / probs.sum(1, keepdim=True), 1e-7, 1 - 1e-7)
-    loss = -(torch.tensor(y, dtype=torch.float64) * torch.log(pc)).sum(1).mean()
+    logits = pooled @ tp["w3"] + tp["b3"]
+    probs = torch.softmax(logits, dim=1)
+    yt = torch.tensor(y, dtype=torch.float64)
+    if cce_mode == "logits":      # softmax_cross_entropy_with_logits (what Keras runs inside tf.function)
+        loss = -(yt * torch.log_softmax(logits, dim=1)).sum(1).mean()
+    else:                         # eager Keras: renormalise, clip, log
+        pc = torch.clamp(probs / probs.sum(1, keepdim=True), 1e-7, 1 - 1e-7)
+        loss = -(yt * torch.log(pc)).sum(1).mean()
     loss.backward()
     return loss.item(), probs.detach().numpy(), {k: t.grad.numpy() for k, t in tp.items()}, y2.detach().numpy()
 
 
-def make_case(name, hb, hidden, weighted, pool="sum", seed=0):
+def make_case(name, hb, hidden, weighted, pool="sum", seed=0, w3_scale=1.0):
     """hb: synth.HostBatch (x fp32).  Writes golden/<name>.npz."""
     import scipy.sparse as sp
 
@@ -77,34 +82,43 @@ def make_case(name, hb, hidden, weighted, pool="sum", seed=0):
     params["b1"] = (0.1 * rng.standard_normal(hidden)).astype(np.float32).astype(np.float64)
     params["b2"] = (0.1 * rng.standard_normal(hidden)).astype(np.float32).astype(np.float64)
     params["b3"] = (0.1 * rng.standard_normal(2)).astype(np.float32).astype(np.float64)
+    params["w3"] = (params["w3"] * w3_scale).astype(np.float32).astype(np.float64)
     csr = (rowptr, colidx, vals)
-    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, x, csr, hb.graph_ptr, y, pool)
+    # "logits": the loss train_step computes under tf.function (keys loss, g_*); "probs": the eager clip form
+    # (keys loss_probs, gp_*)
+    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, x, csr, hb.graph_ptr, y, pool, cce_mode="logits")
+    loss_p, _, grads_p, _ = O.gcn2_loss_and_grads(params, x, csr, hb.graph_ptr, y, pool, cce_mode="probs")
     # independent check 1: scipy SpMM
     a = sp.csr_matrix((np.ones(len(colidx)) if vals is None else vals, colidx, rowptr), shape=(hb.n, hb.n))
     h1 = x @ params["w1"]
     assert rel(O.spmm_csr(rowptr, colidx, vals, h1), a @ h1) < 1e-12, "spmm: oracle vs scipy"
     # independent check 2: torch fp64 autograd
-    t_loss, t_probs, t_grads, t_y2 = torch_gcn2(params, x, rowptr, colidx, vals, hb.graph_ptr, y, pool)
-    assert abs(loss - t_loss) < 1e-10 * max(1, abs(t_loss)), (loss, t_loss)
-    assert rel(cache["probs"], t_probs) < 1e-10
-    assert rel(cache["y2"], t_y2) < 1e-10
-    for k in grads:
-        assert rel(grads[k], t_grads[k]) < 1e-10, (k, rel(grads[k], t_grads[k]))
+    for mode, l_or, g_or in (("logits", loss, grads), ("probs", loss_p, grads_p)):
+        t_loss, t_probs, t_grads, t_y2 = torch_gcn2(params, x, rowptr, colidx, vals, hb.graph_ptr, y, pool, mode)
+        assert abs(l_or - t_loss) < 1e-10 * max(1, abs(t_loss)), (mode, l_or, t_loss)
+        assert rel(cache["probs"], t_probs) < 1e-10
+        assert rel(cache["y2"], t_y2) < 1e-10
+        for k in g_or:
+            if np.max(np.abs(t_grads[k])) == 0 and np.max(np.abs(g_or[k])) == 0:
+                continue
+            assert rel(g_or[k], t_grads[k]) < 1e-10, (mode, k, rel(g_or[k], t_grads[k]))
     out = {
         "x": hb.x.astype(np.float32), "rowptr": hb.rowptr.astype(np.int32), "colidx": hb.colidx.astype(np.int32),
         "graph_ptr": hb.graph_ptr.astype(np.int32), "y": hb.y.astype(np.float32),
         "weighted": np.array(int(weighted)), "pool": np.array(pool), "lr": np.array(0.02),
         "y2": cache["y2"].astype(np.float32), "pooled": cache["pooled"].astype(np.float32),
-        "probs": cache["probs"], "loss": np.array(loss), "acc": np.array(acc),
+        "probs": cache["probs"], "logits": cache["logits"], "loss": np.array(loss), "loss_probs": np.array(loss_p),
+        "acc": np.array(acc),
     }
     if vals32 is not None:
         out["vals"] = vals32
     for k in O.GCN2_PARAM_ORDER:
         out["p_" + k] = params[k].astype(np.float32)
         out["g_" + k] = grads[k].astype(np.float32)
+        out["gp_" + k] = grads_p[k].astype(np.float32)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: N={hb.n} nnz={hb.nnz} B={hb.n_graphs} F={hb.f} H={hidden} loss={loss:.6f} "
+    print(f"{name}: N={hb.n} nnz={hb.nnz} B={hb.n_graphs} F={hb.f} H={hidden} loss={loss:.6f} (probs form {loss_p:.6f}) "
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
@@ -147,6 +161,10 @@ def main():
     pl = synth.power_law_batch(n_graphs=2, graph_size=512, f=32, seed=3, max_deg=256)
     pl.x *= 0.02
     make_case("gcn2_powerlaw_mini", pl, 32, True)
+    # saturated logits (|z_0 - z_1| up to several hundred): the clip of the eager form is active, the two Keras code
+    # paths give different losses and gradients (the clipped graphs get NO gradient in the "probs" form)
+    make_case("gcn2_saturated_logits", tiny_hostbatch(5, 16, 8), 16, True, seed=4, w3_scale=2.0)    # |z0 - z1| 40..70
+    make_case("gcn2_saturated_mixed", tiny_hostbatch(5, 16, 8), 16, True, seed=4, w3_scale=0.55)   # 6 of 8 graphs clipped
 
 
 if __name__ == "__main__":

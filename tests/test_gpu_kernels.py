@@ -168,13 +168,15 @@ def test_new_entry_points_zero_sizes_and_argument_errors(ctx):
     lib, h = ctx.lib, ctx.h
     buf = ctx.zeros((4, 4)); la = ctx.to_device(np.array([5.0, 5.0], np.float32)); dw = ctx.to_device(np.ones((4, 2), np.float32))
     # head: b == 0 -> loss_acc and dw zeroed, nothing else touched
-    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 0, 4, 2, 1.0, buf.ptr, la.ptr, dw.ptr, None, buf.ptr, 4) == 0
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 0, 4, 2, 1.0, buf.ptr, la.ptr, dw.ptr, None, buf.ptr, 4, 1) == 0
     assert not la.numpy().any() and not dw.numpy().any()
     # head: too many classes / gradients without labels
-    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 4, 4, 33, 1.0, buf.ptr, la.ptr, None, None, None, 0) == 1
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 4, 4, 33, 1.0, buf.ptr, la.ptr, None, None, None, 0, 1) == 1
     assert "at most 32 classes" in _lib.last_error(h)
-    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, None, 4, 4, 2, 1.0, buf.ptr, la.ptr, dw.ptr, None, buf.ptr, 4) == 1
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, None, 4, 4, 2, 1.0, buf.ptr, la.ptr, dw.ptr, None, buf.ptr, 4, 0) == 1
     assert "gradients need labels" in _lib.last_error(h)
+    assert lib.gcnx_dense_softmax_cce(h, buf.ptr, 4, buf.ptr, None, buf.ptr, 4, 4, 2, 1.0, buf.ptr, la.ptr, None, None, None, 0, 7) == 1
+    assert "unknown cce_mode" in _lib.last_error(h)
     # BN moments need rows
     assert lib.gcnx_bn_moments(h, buf.ptr, 4, 0, 4, 0.99, 1e-3, buf.ptr, buf.ptr, None, None) == 1
     # collate: b == 0 is a no-op; values in without values out is refused
@@ -196,11 +198,11 @@ def test_fused_step_entry_points_zero_sizes_and_argument_errors(ctx):
     buf = ctx.zeros((4, 4)); la = ctx.to_device(np.array([5.0, 5.0], np.float32)); dw = ctx.to_device(np.ones((4, 2), np.float32))
     dbr = ctx.to_device(np.ones(4, np.float32)); gp0 = ctx.zeros(1, np.int32)
     assert lib.gcnx_pool_dense_softmax_cce(h, gp0.ptr, buf.ptr, 4, 0, None, buf.ptr, 4, buf.ptr, None, buf.ptr, 0, 4, 2, 1.0, buf.ptr,
-                                           la.ptr, dw.ptr, None, buf.ptr, 4, dbr.ptr) == 0
+                                           la.ptr, dw.ptr, None, buf.ptr, 4, dbr.ptr, 1) == 0
     assert not la.numpy().any() and not dw.numpy().any() and not dbr.numpy().any()
     # db_relu needs the gradient outputs and SUM / AVG pooling
     assert lib.gcnx_pool_dense_softmax_cce(h, gp0.ptr, buf.ptr, 4, 2, None, buf.ptr, 4, buf.ptr, None, buf.ptr, 1, 4, 2, 1.0, buf.ptr,
-                                           la.ptr, dw.ptr, None, buf.ptr, 4, dbr.ptr) == 1
+                                           la.ptr, dw.ptr, None, buf.ptr, 4, dbr.ptr, 1) == 1
     assert "db_relu needs" in _lib.last_error(h)
     # dense backward with no rows: dW is zeroed, dX untouched; both outputs are required
     x0 = ctx.empty((0, 64)); dh0 = ctx.empty((0, 8)); w = ctx.zeros((64, 8)); dx0 = ctx.empty((0, 64))
@@ -574,7 +576,11 @@ def test_spmm_pool_bwd_fold_argument_errors(ctx):
     assert np.array_equal(db.numpy(), np.zeros(10, np.float32))
 
 
-def test_softmax_cce_matches_keras_semantics(ctx):
+@pytest.mark.parametrize("cce", ["logits", "probs"])
+def test_softmax_cce_matches_keras_semantics(ctx, cce):
+    """Both code paths of keras.backend.categorical_crossentropy (include/gcnx.h gcnx_cce_mode): "logits" = what
+    train_step runs under tf.function, "probs" = the eager renormalise-and-clip form; rows 0/1 are saturated, where
+    the two differ (loss 80 vs 16.1 for the mislabelled row, gradient -1/B vs 0)."""
     from gcnx import device as D
     o = O()
     rng = np.random.default_rng(4)
@@ -583,21 +589,25 @@ def test_softmax_cce_matches_keras_semantics(ctx):
     logits[0] = [40.0, -40.0]; logits[1] = [-40.0, 40.0]            # saturated: exercises the clip
     y = np.eye(c, dtype=np.float32)[rng.integers(0, c, b)]; y[0] = [1, 0]; y[1] = [1, 0]
     probs = ctx.empty((b, c)); la = ctx.zeros(2); dl = ctx.empty((b, c))
-    D.softmax_cce(ctx, ctx.to_device(logits), ctx.to_device(y), probs, la, dl, denom=b)
-    p = o.softmax(logits.astype(np.float64))
+    D.softmax_cce(ctx, ctx.to_device(logits), ctx.to_device(y), probs, la, dl, denom=b, cce=cce)
+    z64, y64 = logits.astype(np.float64), y.astype(np.float64)
+    p = o.softmax(z64)
+    rl, rdl = o.cce(y64, z64, p, None, cce)
     assert rel_err(probs.numpy(), p) < TIGHT
     loss, hits = la.numpy()
-    assert abs(loss - o.cce_loss(y.astype(np.float64), p)) < 1e-5 * max(1, loss)
+    assert abs(loss - rl) < 1e-5 * max(1, loss)
     assert hits == round(o.categorical_accuracy(y, p) * b)
-    assert rel_err(dl.numpy(), o.softmax_cce_grad(y.astype(np.float64), p)) < TIGHT
+    assert rel_err(dl.numpy(), rdl) < TIGHT
+    assert (dl.numpy()[1, 0] == 0.0) == (cce == "probs")            # the clipped row gets no gradient in the eager form only
     # shard semantics: denom = global batch
     la.fill_zero()
-    D.softmax_cce(ctx, ctx.to_device(logits[:10]), ctx.to_device(y[:10]), ctx.empty((10, c)), la, None, denom=40)
-    assert abs(la.numpy()[0] - o.cce_loss(y[:10].astype(np.float64), p[:10], denom=40)) < 1e-5
+    D.softmax_cce(ctx, ctx.to_device(logits[:10]), ctx.to_device(y[:10]), ctx.empty((10, c)), la, None, denom=40, cce=cce)
+    assert abs(la.numpy()[0] - o.cce(y64[:10], z64[:10], p[:10], 40, cce)[0]) < 1e-5
 
 
+@pytest.mark.parametrize("cce", ["logits", "probs"])
 @pytest.mark.parametrize("b,h,c", [(32, 128, 2), (1, 16, 1), (1667, 256, 2), (200, 40, 7), (40, 2000, 3)])
-def test_dense_softmax_cce_head(ctx, b, h, c):
+def test_dense_softmax_cce_head(ctx, b, h, c, cce):
     """gcnx_dense_softmax_cce (one launch) == Dense + softmax + clipped CCE + accuracy + the head gradients of the
     oracle; several workgroups (b > 64) reduce dW/db/loss in a fixed order: two launches agree bitwise."""
     from gcnx import device as D
@@ -608,27 +618,29 @@ def test_dense_softmax_cce_head(ctx, b, h, c):
     bias = rng.standard_normal(c).astype(np.float32)
     y = np.eye(c, dtype=np.float32)[rng.integers(0, c, b)]
     if c == 2 and b >= 2:
-        pooled[0] = 0; pooled[0, 0] = 400.0; w[0] = [1.0, -1.0]      # a saturated graph: exercises the clip
+        pooled[0] = 0; pooled[0, 0] = 400.0; w[0] = [1.0, -1.0]      # saturated graphs: exercise the clip / the no-clip form
+        pooled[1] = 0; pooled[1, 0] = -30.0; y[0] = [0, 1]; y[1] = [1, 0]
     denom = float(b + 3)                                             # a "global batch" larger than this shard
     dp, dw_, db_ = ctx.empty((b, h)), ctx.empty((h, c)), ctx.empty(c)
     probs, la = ctx.empty((b, c)), ctx.to_device(np.array([7.0, 7.0], np.float32))   # overwritten, not accumulated
     args = (ctx, ctx.to_device(pooled), ctx.to_device(w), ctx.to_device(bias), ctx.to_device(y), probs, la, denom)
-    D.dense_softmax_cce(*args, dw=dw_, db=db_, dpooled=dp)
+    D.dense_softmax_cce(*args, dw=dw_, db=db_, dpooled=dp, cce=cce)
     P, W, Y = pooled.astype(np.float64), w.astype(np.float64), y.astype(np.float64)
-    p = o.softmax(P @ W + bias.astype(np.float64))
-    dl = o.softmax_cce_grad(Y, p, denom=denom)
+    z = P @ W + bias.astype(np.float64)
+    p = o.softmax(z)
+    rl, dl = o.cce(Y, z, p, denom, cce)
     assert rel_err(probs.numpy(), p) < TIGHT
     loss, hits = la.numpy()
-    assert abs(loss - o.cce_loss(Y, p, denom=denom)) < 2e-5 * max(1.0, abs(loss))
+    assert abs(loss - rl) < 2e-5 * max(1.0, abs(loss))
     assert hits == round(o.categorical_accuracy(y, p) * b)
     assert rel_err(dw_.numpy(), P.T @ dl) < TIGHT and rel_err(db_.numpy(), dl.sum(0)) < TIGHT
     assert rel_err(dp.numpy(), dl @ W.T) < TIGHT
     first = (dw_.numpy().copy(), db_.numpy().copy(), la.numpy().copy())
-    D.dense_softmax_cce(*args, dw=dw_, db=db_, dpooled=dp)
+    D.dense_softmax_cce(*args, dw=dw_, db=db_, dpooled=dp, cce=cce)
     assert np.array_equal(first[0], dw_.numpy()) and np.array_equal(first[1], db_.numpy()) and np.array_equal(first[2], la.numpy())
     # loss only, and probabilities only
     la2 = ctx.zeros(2)
-    D.dense_softmax_cce(ctx, args[1], args[2], args[3], args[4], probs, la2, denom)
+    D.dense_softmax_cce(ctx, args[1], args[2], args[3], args[4], probs, la2, denom, cce=cce)
     assert np.array_equal(la2.numpy(), first[2])
     pr2 = ctx.empty((b, c))
     D.dense_softmax_cce(ctx, args[1], args[2], args[3], None, pr2)

@@ -3,6 +3,7 @@ C-ABI library (loads, exports every symbol include/gcnx.h declares, fails loudly
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -182,3 +183,67 @@ def test_piecewise_schedule_and_roc_auc_match_keras_and_sklearn():
     assert np.allclose(fpr, f2) and np.allclose(tpr, t2) and np.allclose(thr[1:], th2[1:])
     assert abs(gcnx.auc(fpr, tpr) - metrics.auc(f2, t2)) < 1e-12
     assert abs(gcnx.auc(fpr, tpr) - metrics.roc_auc_score(y, p)) < 1e-12
+
+
+def test_bench_launcher_starts_ranks_itself_and_rendezvous_is_keyed_by_the_launcher(tmp_path):
+    """`python bench.py --gpus N` invoked plainly must start the N rank processes itself (before
+    anything touches the GPU), hand them a fresh run id for the RCCL rendezvous file, pass rank 0's JSON line through
+    and fail if any rank fails.  CPU-side plumbing only (--selftest-launcher exchanges a fake id through the same
+    rendezvous file the Communicator uses); world sizes 2 and 3."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GCNX_RUN_ID")}
+    ids = []
+    for world in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--selftest-launcher"],
+                           capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0, r.stderr
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rec == {"selftest": "launcher", "world": world, "ranks_seen": world, "ok": True, "run_id": rec["run_id"]}
+        ids.append(rec["run_id"])
+    assert ids[0] != ids[1] and len(ids[0]) == 32                # a fresh id per launch
+    # a failing rank makes the launcher fail: WORLD_SIZE disagreeing with --gpus is refused by every rank
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=60)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+    # rendezvous key: the launcher's id when given, else torchrun's run id / restart count / port / agent pid
+    from gcnx import comm
+    p1 = comm._rendezvous_path({"GCNX_RUN_ID": "abc", "MASTER_PORT": "29500"})
+    p2 = comm._rendezvous_path({"TORCHELASTIC_RUN_ID": "none", "MASTER_PORT": "29500"})
+    p3 = comm._rendezvous_path({"TORCHELASTIC_RUN_ID": "none", "TORCHELASTIC_RESTART_COUNT": "1", "MASTER_PORT": "29500"})
+    assert p1.endswith("gcnx_uid_abc_29500") and str(os.getppid()) not in os.path.basename(p1)
+    assert p2 != p3 and os.path.basename(p2).endswith(f"_{os.getppid()}")
+
+
+def test_shardable_generators_do_not_depend_on_the_number_of_ranks():
+    """bench.py: every rank builds only its own graphs; graph g comes from its own random stream, so the global
+    batch is the same for every world size, and the per-graph sizes (all a partition needs) are available without
+    building any graph."""
+    from gcnx import shard, synth
+    sizes = synth.ecoli_sizes(12, seed=1)
+    full = synth.ecoli_shard(0, 12, 8, seed=1)
+    assert np.array_equal(np.diff(full.graph_ptr), sizes)
+    bounds = shard.partition_by_cost(sizes * 16.0, 3)
+    off = 0
+    for r in range(3):
+        part = synth.ecoli_shard(int(bounds[r]), int(bounds[r + 1]), 8, seed=1)
+        ref = full.slice_graphs(int(bounds[r]), int(bounds[r + 1]))
+        for k in ("x", "rowptr", "colidx", "graph_ptr", "y"):
+            assert np.array_equal(getattr(part, k), getattr(ref, k)), k
+        off += part.n
+    assert off == full.n
+    sz, pairs = synth.block_diag_plan(20000, 200000, seed=2)
+    assert sz.sum() == 20000 and sz.sum() + 2 * pairs.sum() == 200000
+    whole = synth.block_diag_shard(0, len(sz), sz, pairs, 4, seed=2)
+    assert whole.n == 20000 and whole.nnz == 200000
+    mid = synth.block_diag_shard(5, 9, sz, pairs, 4, seed=2)
+    ref = whole.slice_graphs(5, 9)
+    for k in ("x", "rowptr", "colidx", "graph_ptr", "y"):
+        assert np.array_equal(getattr(mid, k), getattr(ref, k)), k
+    a = (whole.rowptr, whole.colidx)
+    rows = np.repeat(np.arange(whole.n), np.diff(whole.rowptr))
+    g_of = np.repeat(np.arange(len(sz)), sz)
+    assert np.array_equal(g_of[rows], g_of[whole.colidx])          # block-diagonal
+    pl = synth.power_law_batch(3, 512, 4, seed=3, max_deg=128, first_graph=0)
+    assert 128 <= np.diff(pl.rowptr).max() <= 132 and np.array_equal(       # the wired hub row (+ a stray Chung-Lu partner)
+        synth.power_law_batch(2, 512, 4, seed=3, max_deg=128, first_graph=1).x, pl.x[512:])

@@ -73,9 +73,10 @@ def test_disjoint_collate_layout():
         off += m
 
 
+@pytest.mark.parametrize("cce_mode", ["logits", "probs"])
 @pytest.mark.parametrize("pool", ["sum", "avg", "max"])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_gcn2_gradients_match_torch_autograd(pool, weighted):
+def test_gcn2_gradients_match_torch_autograd(pool, weighted, cce_mode):
     import torch
     rng = np.random.default_rng(5)
     sizes = [7, 1, 12, 5]
@@ -94,7 +95,7 @@ def test_gcn2_gradients_match_torch_autograd(pool, weighted):
     params = O.gcn2_init(rng, 6, 5, 2)
     for k in ("b1", "b2", "b3"):
         params[k] = 0.1 * rng.standard_normal(params[k].shape)
-    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, x, (rowptr, colidx, vals), gp, y, pool)
+    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, x, (rowptr, colidx, vals), gp, y, pool, cce_mode=cce_mode)
 
     rows = np.repeat(np.arange(n), np.diff(rowptr))
     at = torch.sparse_coo_tensor(np.stack([rows, colidx]),
@@ -104,8 +105,12 @@ def test_gcn2_gradients_match_torch_autograd(pool, weighted):
     y2 = torch.relu(torch.sparse.mm(at, y1 @ tp["w2"]) + tp["b2"])
     segs = [y2[gp[g]:gp[g + 1]] for g in range(len(sizes))]
     pooled = torch.stack([s.sum(0) if pool == "sum" else s.mean(0) if pool == "avg" else s.max(0).values for s in segs])
-    probs = torch.softmax(pooled @ tp["w3"] + tp["b3"], 1)
-    tl = -(torch.tensor(y) * torch.log(torch.clamp(probs, 1e-7, 1 - 1e-7))).sum(1).mean()
+    logits = pooled @ tp["w3"] + tp["b3"]
+    probs = torch.softmax(logits, 1)
+    if cce_mode == "logits":     # tf.nn.softmax_cross_entropy_with_logits: what Keras' CCE runs inside tf.function
+        tl = -(torch.tensor(y) * torch.log_softmax(logits, 1)).sum(1).mean()
+    else:                        # the eager branch: clip, log
+        tl = -(torch.tensor(y) * torch.log(torch.clamp(probs, 1e-7, 1 - 1e-7))).sum(1).mean()
     tl.backward()
     assert abs(loss - tl.item()) < 1e-12
     for k in grads:
@@ -116,7 +121,8 @@ def test_gcn2_gradients_match_torch_autograd(pool, weighted):
         r0, r1 = gp[g0], gp[g1]
         e0, e1 = rowptr[r0], rowptr[r1]
         csr_s = (rowptr[r0:r1 + 1] - e0, colidx[e0:e1] - r0, None if vals is None else vals[e0:e1])
-        l_s, _, g_s, _ = O.gcn2_loss_and_grads(params, x[r0:r1], csr_s, gp[g0:g1 + 1] - r0, y[g0:g1], pool, denom=len(sizes))
+        l_s, _, g_s, _ = O.gcn2_loss_and_grads(params, x[r0:r1], csr_s, gp[g0:g1 + 1] - r0, y[g0:g1], pool, denom=len(sizes),
+                                               cce_mode=cce_mode)
         ltot += l_s
         for k in g_s:
             tot[k] = tot[k] + g_s[k]
@@ -206,15 +212,16 @@ def test_numpy_oracle_reproduces_goldens(name):
     hb = golden_batch(g)
     params = {k: g["p_" + k].astype(np.float64) for k in O.GCN2_PARAM_ORDER}
     vals = None if hb.vals is None else hb.vals.astype(np.float64)
-    loss, acc, grads, cache = O.gcn2_loss_and_grads(params, hb.x.astype(np.float64),
-                                                    (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals),
-                                                    hb.graph_ptr, hb.y.astype(np.float64), str(g["pool"]))
-    assert abs(loss - float(g["loss"])) < 1e-12 * max(1.0, abs(loss))
-    assert acc == float(g["acc"])
-    assert rel_err(cache["probs"], g["probs"]) < 1e-12
-    assert rel_err(cache["y2"], g["y2"]) < 1e-6          # goldens store activations in fp32
-    for k in O.GCN2_PARAM_ORDER:
-        assert rel_err(grads[k], g["g_" + k]) < 1e-6, k
+    for mode, lk, gk in (("logits", "loss", "g_"), ("probs", "loss_probs", "gp_")):
+        loss, acc, grads, cache = O.gcn2_loss_and_grads(params, hb.x.astype(np.float64),
+                                                        (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals),
+                                                        hb.graph_ptr, hb.y.astype(np.float64), str(g["pool"]), cce_mode=mode)
+        assert abs(loss - float(g[lk])) < 1e-12 * max(1.0, abs(loss))
+        assert acc == float(g["acc"])
+        assert rel_err(cache["probs"], g["probs"]) < 1e-12
+        assert rel_err(cache["y2"], g["y2"]) < 1e-6          # goldens store activations in fp32
+        for k in O.GCN2_PARAM_ORDER:
+            assert rel_err(grads[k], g[gk + k]) < 1e-6 or not np.any(g[gk + k]), (mode, k)
 
 
 @pytest.mark.parametrize("name", [n for n in GOLDEN if "max" not in n and "avg" not in n])
@@ -225,19 +232,21 @@ def test_c_oracle_matches_goldens_fp32(name):
     g = load_golden(name)
     hb = golden_batch(g)
     flat = np.concatenate([g["p_" + k].ravel() for k in O.GCN2_PARAM_ORDER]).astype(np.float32)
-    m = c_oracle.Gcn2Cpu(hb, g["p_w1"].shape[1], 2, flat)
-    loss, acc = m.step(lr=0.0)
-    assert abs(loss - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
-    assert acc == pytest.approx(float(g["acc"]))
-    off = 0
-    for k in O.GCN2_PARAM_ORDER:
-        n = g["g_" + k].size
-        assert rel_err(m.grads[off:off + n].reshape(g["g_" + k].shape), g["g_" + k]) < 1e-4, k
-        off += n
+    for mode, lk, gk in (("logits", "loss", "g_"), ("probs", "loss_probs", "gp_")):
+        m = c_oracle.Gcn2Cpu(hb, g["p_w1"].shape[1], 2, flat)
+        loss, acc = m.step(lr=0.0, cce=mode)
+        assert abs(loss - float(g[lk])) < 1e-4 * max(1.0, abs(float(g[lk])))
+        assert acc == pytest.approx(float(g["acc"]))
+        off = 0
+        for k in O.GCN2_PARAM_ORDER:
+            n = g[gk + k].size
+            got = m.grads[off:off + n].reshape(g[gk + k].shape)
+            assert rel_err(got, g[gk + k]) < 1e-4 or (not np.any(g[gk + k]) and not np.any(got)), (mode, k)
+            off += n
     # SGD apply (gcn.py:338)
     m2 = c_oracle.Gcn2Cpu(hb, g["p_w1"].shape[1], 2, flat)
     m2.step(lr=float(g["lr"]))
-    assert np.allclose(m2.params, flat - float(g["lr"]) * m2.grads, rtol=0, atol=1e-7)
+    assert np.allclose(m2.params, flat - np.float32(g["lr"]) * m2.grads, rtol=1e-6, atol=1e-7)
 
 
 def test_c_oracle_kernels_match_numpy():
@@ -260,3 +269,11 @@ def test_lr_schedule_and_losses():
     p = np.array([[1.0, 0.0], [0.5, 0.5]]); y = np.array([[1.0, 0.0], [0.0, 1.0]])
     assert np.isclose(O.cce_loss(y, p), (-np.log(1 - 1e-7) - np.log(0.5)) / 2)      # clip at 1-1e-7
     assert O.categorical_accuracy(y, np.array([[0.9, 0.1], [0.8, 0.2]])) == 0.5
+    # the two Keras code paths: identical while no probability saturates, different beyond |dz| ~ 16.1
+    z = np.array([[2.0, -1.0], [0.3, 0.1]])
+    assert np.isclose(O.cce_loss_from_logits(y, z), O.cce_loss(y, O.softmax(z)), rtol=1e-12)
+    assert np.allclose(O.softmax_cce_grad_from_logits(y, O.softmax(z)), O.softmax_cce_grad(y, O.softmax(z)), atol=1e-15)
+    zs = np.array([[-30.0, 30.0], [0.3, 0.1]])                 # graph 0: true class at p = e^-60
+    assert np.isclose(O.cce_loss_from_logits(y, zs), (60.0 + np.log1p(np.exp(-60.0)) + np.log(1 + np.exp(0.2))) / 2)
+    assert np.isclose(O.cce_loss(y, O.softmax(zs)), (-np.log(1e-7) + np.log(1 + np.exp(0.2))) / 2)
+    assert np.all(O.softmax_cce_grad(y, O.softmax(zs))[0] == 0) and abs(O.softmax_cce_grad_from_logits(y, O.softmax(zs))[0, 0] + 0.5) < 1e-12

@@ -39,6 +39,8 @@ class ThreadWorld:
 
 
 class ThreadCommunicator:
+    capturable = False     # host-mediated: cannot be recorded into a HIP graph
+
     def __init__(self, world, ctx, rank):
         self.world, self.ctx, self.rank, self.world_size = world, ctx, rank, world.world_size
         self.calls = 0
