@@ -28,6 +28,7 @@ struct gcnx_ctx {
   // tuning knobs (diagnostics, not API), read once at ctx creation: GCNX_SPMM_KERNEL, GCNX_SPMM_SLAB, GCNX_SPMM_SG
   int knob_spmm_kernel = 0;  // 0 auto, 1 rows, 2 tile
   int knob_spmm_slab = 0, knob_spmm_sg = 0;
+  int knob_gemm_stream = 1;  // GCNX_GEMM_STREAM=0: bf16 GEMMs stay on the tiled kernel (A/B measurement)
   // Side stream for gradient "leaves" (weight / bias gradients that nothing downstream in the backward pass
   // consumes): gcnx_side_begin swaps stream and workspace, so every entry point launches there unchanged.
   hipStream_t main_stream = nullptr, side_stream = nullptr;
@@ -48,6 +49,15 @@ extern thread_local std::string gcnx_tls_error;
 
 int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...);
 int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes);  // ensures ctx->ws has >= bytes
+// gemm_stream.hip: X W (transpose = 1) / dH W^T (transpose = 0) on the streaming bf16 kernel; GCNX_ERR_UNSUPPORTED
+// (no message) when the shape is not one it is built for.
+int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose, float* c,
+                        int64_t ldc, int64_t m, int prec, const float* bias, const float* alpha, int act, const float* mask,
+                        int64_t ldmask, int accumulate);
+// gemm_stream.hip: X^T dH for fi = fo = 256 on the streaming bf16 kernel: writes [slices][256 * 256] partial products to
+// `slabs` (room for max_slices of them) and returns the number of slices; 0 = shape not handled, < 0 = launch error.
+int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* slabs, int64_t n,
+                        int32_t fi, int32_t fo, int prec, int max_slices);
 #ifdef __HIPCC__
 // Column sums of a few hundred partial rows [rows][f] (f % 4 == 0): workgroup bx owns 8 columns (two float4 lanes)
 // x 128 row groups and folds the 128 partial sums in a fixed tree through LDS.  (colsum_kernel's 64 columns x 16 row

@@ -660,6 +660,11 @@ namespace {
 int launch_bf16_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose,
                    float* c, int64_t ldc, int64_t m, int prec, const Epilogue& ep) {
   const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
+  if (ep.vec_c && !ep.colpart) {            // tall activations: the streaming kernel (weights resident in LDS)
+    int rs = gcnx_gemm_stream_nn(ctx, a, lda, w, fi, fo, transpose, c, ldc, m, prec, ep.bias, ep.alpha, ep.act, ep.mask, ep.ldmask,
+                                 ep.accumulate);
+    if (rs != GCNX_ERR_UNSUPPORTED) return rs;
+  }
   const int kpad = ((K + HK - 1) / HK) * HK;
   const size_t img = (size_t)ncol * kpad;   // elements per image
   int rc = gcnx_ws_reserve(ctx, 2 * img * sizeof(__bf16) + 256);
@@ -880,6 +885,19 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
   GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo, "gcnx_gemm_dw: leading dimension too small");
   // dW[i, o] = sum_n X[n, i] * dH[n, o]: A[i][k=n] = X[n*ldx + i], B[k=n][o] = dH[n*lddh + o].
   if (prec != GCNX_PREC_F32) {
+    if (fi == 256 && fo == 256 && n >= 32 * 1024 && ctx->knob_gemm_stream) {   // tall: one slice per CU, whole product in registers
+      const int max_slices = ctx->num_cus;
+      int rc = gcnx_ws_reserve(ctx, (size_t)max_slices * 65536 * sizeof(float));
+      if (rc) return rc;
+      const int ns = gcnx_gemm_dw_stream(ctx, x, ldx, dh, lddh, (float*)ctx->ws, n, fi, fo, prec, max_slices);
+      if (ns < 0) return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_gemm_dw: streaming kernel launch failed");
+      if (ns > 0) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(65536, 64)), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
+                           (int64_t)65536, ns, dw, (int64_t)65536);
+        GCNX_LAUNCH_OK(ctx);
+        return GCNX_OK;
+      }
+    }
     const int tiles_h = gcnx_cdiv(fi, HM) * gcnx_cdiv(fo, HN);
     int ns = (int)((4LL * ctx->num_cus + tiles_h - 1) / tiles_h);
     const int64_t ksteps_h = (n + HK - 1) / HK;

@@ -90,6 +90,7 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   if (const char* k = getenv("GCNX_SPMM_KERNEL")) ctx->knob_spmm_kernel = k[0] == 'r' ? 1 : k[0] == 't' ? 2 : 0;
   if (const char* k = getenv("GCNX_SPMM_SLAB")) ctx->knob_spmm_slab = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_SG")) ctx->knob_spmm_sg = atoi(k);
+  if (const char* k = getenv("GCNX_GEMM_STREAM")) ctx->knob_gemm_stream = atoi(k);
   if (ctx->arch.rfind("gfx950", 0) != 0) {
     int rc = gcnx_fail(nullptr, GCNX_ERR_UNSUPPORTED, "gcnx_ctx_create: device %d is %s; libgcnx is built for gfx950 only",
                        device, ctx->arch.c_str());

@@ -497,6 +497,65 @@ def test_gemm_bf16_mfma_paths(ctx, n, fi, fo):
     assert rel_err(out.numpy(), x64 @ w64) < 2e-2
 
 
+@pytest.mark.parametrize("n,fi,fo", [(40000, 256, 256), (33001, 256, 192), (70000, 128, 128), (36000, 128, 256), (50000, 256, 64)])
+def test_gemm_bf16_streaming_kernel(ctx, n, fi, fo, monkeypatch):
+    """The streaming form of the bf16 weight GEMM (csrc/gemm_stream.hip: weight planes resident in LDS, activation
+    rows loaded straight into MFMA operand layout four K steps ahead, float4 epilogue), taken for tall activations
+    (>= 32 768 rows, K = 128 / 256): X W + b with ReLU / PReLU and dH W^T with the fused ReLU mask, ragged row counts,
+    one and two column halves, a partial second half -- bf16x3 at the fp32 bar, plain bf16 exact against
+    bf16-rounded operands; and bit-identical to nothing less than itself: two runs agree."""
+    import gcnx
+    from gcnx import device as D
+    rng = np.random.default_rng(n + fi + fo)
+    x = rng.standard_normal((n, fi), dtype=np.float32); w = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
+    dh = rng.standard_normal((n, fo), dtype=np.float32); b = rng.standard_normal(fo).astype(np.float32)
+    al = rng.random(fo).astype(np.float32)
+    ym = rng.standard_normal((n, fi), dtype=np.float32)
+    d_x, d_w, d_dh, d_b, d_ym, d_al = (ctx.to_device(v) for v in (x, w, dh, b, ym, al))
+    x64, w64, dh64 = x.astype(np.float64), w.astype(np.float64), dh.astype(np.float64)
+    xb, wb, dhb = (_bf16_round(v).astype(np.float64) for v in (x, w, dh))
+    out = ctx.empty((n, fo)); dx = ctx.empty((n, fi)); db = ctx.empty(fi)
+    for prec, tol, (ax, aw, adh) in (("bf16x3", TOL, (x64, w64, dh64)), ("bf16", 2e-5, (xb, wb, dhb))):
+        out.fill_zero()
+        D.gemm(ctx, d_x, d_w, d_b, out, act="relu", prec=prec)
+        got = out.numpy()
+        assert rel_err(got, np.maximum(ax @ aw + b, 0)) < tol, prec
+        D.gemm(ctx, d_x, d_w, d_b, out, act="relu", prec=prec)
+        assert np.array_equal(out.numpy(), got)
+        D.gemm(ctx, d_x, d_w, d_b, out, act="prelu", alpha=d_al, prec=prec)
+        z = ax @ aw + b
+        assert rel_err(out.numpy(), np.where(z > 0, z, al * z)) < tol, prec
+        D.gemm(ctx, d_x, d_w, None, out, prec=prec)
+        assert rel_err(out.numpy(), ax @ aw) < tol, prec
+        dx.fill_zero()
+        D.gemm_dx(ctx, d_dh, d_w, dx, prec=prec, y_mask=d_ym, db=db)
+        ref = (adh @ aw.T) * (ym > 0)
+        assert rel_err(dx.numpy(), ref) < tol and rel_err(db.numpy(), ref.sum(0)) < max(tol, 1e-5), prec
+        D.gemm_dx(ctx, d_dh, d_w, dx, prec=prec)
+        assert rel_err(dx.numpy(), adh @ aw.T) < tol, prec
+        # X^T dH (fi = fo = 256: one split-K slice per CU with the whole product in registers, transposing LDS reads)
+        dwv = ctx.empty((fi, fo))
+        D.gemm_dw(ctx, d_x, d_dh, dwv, prec=prec)
+        g1 = dwv.numpy()
+        assert rel_err(g1, ax.T @ adh) < tol, prec
+        D.gemm_dw(ctx, d_x, d_dh, dwv, prec=prec)
+        assert np.array_equal(dwv.numpy(), g1)
+    # column-slice views (leading dimension larger than the width) on both sides
+    wide_in, wide_out = ctx.to_device(np.concatenate([x, x], 1)), ctx.zeros((n, fo + 64))
+    D.gemm(ctx, wide_in.cols(fi, 2 * fi), d_w, d_b, wide_out.cols(64, 64 + fo), prec="bf16x3")
+    wo = wide_out.numpy()
+    assert rel_err(wo[:, 64:], x64 @ w64 + b) < TOL and not wo[:, :64].any()
+    # the knob that keeps the tiled kernel gives the same result to rounding
+    monkeypatch.setenv("GCNX_GEMM_STREAM", "0")
+    c2 = gcnx.Context(0)
+    try:
+        o2 = c2.empty((n, fo))
+        D.gemm(c2, c2.to_device(x), c2.to_device(w), c2.to_device(b), o2, act="relu", prec="bf16x3")
+        assert rel_err(o2.numpy(), np.maximum(x64 @ w64 + b, 0)) < TOL
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("mode", ["sum", "avg", "max"])
 def test_segment_pool_forward_backward(ctx, mode):
     from gcnx import device as D
