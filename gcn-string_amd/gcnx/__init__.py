@@ -7,10 +7,10 @@ No PyTorch, no TensorFlow, no CPU fallback.
 """
 from . import _lib
 from .io import best_epoch, load_weights_npz, save_to_npz
-from .loader import Dataset, DisjointLoader, Graph, ListDataset, SparseTensor
+from .loader import Dataset, DisjointLoader, Graph, ListDataset, NetworkxDataset, SparseTensor, format_graph, from_networkx
 from .train import PiecewiseConstantDecay, auc, fit, roc_curve
 
-__all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "SparseTensor", "Context", "GCNConv",
+__all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "NetworkxDataset", "from_networkx", "format_graph", "SparseTensor", "Context", "GCNConv", "GeneralConv",
            "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch",
            "save_to_npz", "load_weights_npz", "best_epoch", "DeviceDataset", "DeviceDisjointLoader",
            "PiecewiseConstantDecay", "fit", "roc_curve", "auc"]
@@ -20,7 +20,7 @@ def __getattr__(name):  # device-side names load libgcnx lazily, host-only use n
     if name in ("Context", "DeviceArray", "DeviceCSR", "Segments"):
         from . import device
         return getattr(device, name)
-    if name in ("GCNConv", "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense"):
+    if name in ("GCNConv", "GeneralConv", "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense"):
         from . import layers
         return getattr(layers, name)
     if name in ("DeviceDataset", "DeviceDisjointLoader", "collate_on_device"):

@@ -146,6 +146,105 @@ class GCNConv(Layer):
         return dx
 
 
+class GeneralConv(Layer):
+    """spektral.layers.GeneralConv -- the message-passing layer inside the model the reference trains (gcn.py:320
+    -> GeneralGNN):
+
+        h = activation(BatchNormalization(x W + b));   out[t] = sum_{(t, s) in a.indices} h[s]
+
+    ``GeneralConv(channels=256, batch_norm=True, dropout=0.0, aggregate="sum", activation="prelu", use_bias=True)``,
+    called as ``layer([x, a], training=bool)``.  The adjacency VALUES are ignored, no self-loop is added and nothing
+    is normalised (Spektral's ``propagate`` gathers by a.indices and segment-sums).  Only what the reference uses is
+    built: aggregate="sum", dropout=0.0; activation "prelu" (per-feature slopes, initial 0), "relu" or None.
+    Keras BatchNormalization semantics: momentum 0.99, eps 1e-3, biased batch variance, moving statistics updated in
+    training.  ``backward(dy)`` returns dx and leaves kernel / bias / gamma / beta / alpha gradients in ``grads``.
+    get_weights() order: kernel, bias, alpha, gamma, beta, moving_mean, moving_variance (the layer's own variables,
+    then its children's; non-trainables last -- see GeneralGNN.GNN_ORDERS; PARITY UNPINNED)."""
+
+    def __init__(self, channels=256, batch_norm=True, dropout=0.0, aggregate="sum", activation="prelu", use_bias=True,
+                 prec="f32", **kw):
+        super().__init__(**kw)
+        if aggregate != "sum":
+            raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): only 'sum' (what gcn.py:320 uses) is built")
+        if dropout:
+            raise NotImplementedError("GeneralConv(dropout > 0) is not built (the reference trains with 0.0)")
+        if activation not in (None, "linear", "relu", "prelu"):
+            raise NotImplementedError(f"GeneralConv activation {activation!r}")
+        if activation == "prelu" and not batch_norm:
+            raise NotImplementedError("GeneralConv(batch_norm=False, activation='prelu') is not built (PReLU is fused with BN)")
+        self.channels, self.batch_norm, self.activation, self.use_bias, self.prec = int(channels), bool(batch_norm), activation, use_bias, prec
+        self.state = {}
+
+    def _param_spec(self, in_dim):
+        c = self.channels
+        spec = [("kernel", (in_dim, c), glorot_uniform(self._rng, in_dim, c))]
+        if self.use_bias:
+            spec.append(("bias", (c,), np.zeros(c, np.float32)))
+        if self.activation == "prelu":
+            spec.append(("alpha", (c,), np.zeros(c, np.float32)))
+        if self.batch_norm:
+            spec += [("gamma", (c,), np.ones(c, np.float32)), ("beta", (c,), np.zeros(c, np.float32))]
+        return spec
+
+    def build(self, ctx, in_dim, p_store=None, g_store=None, offset=0):
+        off = super().build(ctx, in_dim, p_store, g_store, offset)
+        if self.batch_norm:
+            c = self.channels
+            self.state = {"moving_mean": ctx.zeros(c), "moving_var": ctx.to_device(np.ones(c, np.float32))}
+            self._mean, self._inv, self._sums, self._scratch = ctx.zeros(c), ctx.zeros(c), ctx.zeros(2 * c), ctx.zeros(3 * c)
+        return off
+
+    def get_weights(self):
+        return [self.params[k].numpy() for k in self.params] + [self.state[k].numpy() for k in self.state]
+
+    def set_weights(self, weights):
+        for k, w in zip(list(self.params) + list(self.state), weights):
+            (self.params[k] if k in self.params else self.state[k]).copy_from_host(np.asarray(w, np.float32))
+
+    def call(self, inputs, training=False, out=None):
+        x, a = inputs
+        if not self.built:
+            self.build(x.ctx, x.shape[1])
+        ctx, n, c = self.ctx, x.shape[0], self.channels
+        z, h = self._buf("z", (n, c)), self._buf("h", (n, c))
+        D.gemm(ctx, x, self.params["kernel"], self.params.get("bias"), z, prec=self.prec,
+               act=None if self.batch_norm else self.activation, alpha=None if self.batch_norm else self.params.get("alpha"))
+        if self.batch_norm:
+            if training:
+                D.bn_moments(ctx, z, self._sums, self._mean, self._inv, self.state["moving_mean"], self.state["moving_var"])
+            else:
+                D.bn_finalize(ctx, None, 1, self._mean, self._inv, self.state["moving_mean"], self.state["moving_var"])
+            D.bn_act(ctx, z, self._mean, self._inv, self.params["gamma"], self.params["beta"], h, act=self.activation,
+                     alpha=self.params.get("alpha"))
+        else:
+            h = z
+        y = out if out is not None else self._buf("y", (n, c))
+        au = a.unweighted()                                  # values ignored (8.A.4)
+        D.spmm(ctx, au, h, None, y)
+        self._saved = (x, au, z, h, bool(training))
+        return y
+
+    def backward(self, dy, need_dx=True):
+        x, au, z, h, training = self._saved
+        ctx = self.ctx
+        dh = self._buf("dh", dy.shape)
+        D.spmm(ctx, au.transpose(), dy, None, dh)            # dH = S^T dY
+        if self.batch_norm:
+            D.bn_act_bwd(ctx, dh, z, self._mean, self._inv, self.params["gamma"], self.params["beta"], dh, self._scratch,
+                         act=self.activation, alpha=self.params.get("alpha"), training=training,
+                         dgamma=self.grads["gamma"], dbeta=self.grads["beta"], dalpha=self.grads.get("alpha"))
+            D.act_bias_grad(ctx, dh, None, dh, None, db=self.grads.get("bias"))
+        else:
+            D.act_bias_grad(ctx, dh, h, dh, self.activation, db=self.grads.get("bias"), alpha=self.params.get("alpha"),
+                            dalpha=self.grads.get("alpha"))
+        D.gemm_dw(ctx, x, dh, self.grads["kernel"], prec=self.prec)
+        if not need_dx:
+            return None
+        dx = self._buf("dx", x.shape)
+        D.gemm_dx(ctx, dh, self.params["kernel"], dx, prec=self.prec)
+        return dx
+
+
 class Dense(Layer):
     """Keras Dense: act(x W + b); activation None / 'relu' (softmax is fused with the loss)."""
 

@@ -101,6 +101,57 @@ class ListDataset(Dataset):
         return self._graphs
 
 
+def format_graph(graph):
+    """MyDataset.format_graph (gcn.py:187-197): node labels -> integers 0..n-1 in the graph's own node order
+    (nx.convert_node_labels_to_integers), and the ``weight`` edge attribute removed -- so that the adjacency the model
+    sees is the 0/1 contact pattern, not the distances / DCA scores the offline builder stored on the edges."""
+    import networkx as nx
+    f = nx.convert_node_labels_to_integers(graph)
+    for _, _, d in f.edges(data=True):
+        d.pop("weight", None)
+    return f
+
+
+def from_networkx(graph, label, use_edge_data=False, feature_name="x"):
+    """One networkx graph of the reference's pickles -> ``Graph(x, a, y)`` exactly as MyDataset builds it
+    (gcn.py:104-128, 153-181, 187-197), without reading any file:
+      a  nx.adjacency_matrix in node order, scipy CSR int64, 0/1 (weights stripped), the builder's self-loops kept
+         (gcn_utills.py:224-227: the 0-Angstrom diagonal counts as a contact), symmetric for undirected graphs;
+      x  np.vstack of every node's ``feature_name`` attribute in node order (float64 as stored);
+      y  np.array(label) (the one-hot pair of gcn.py:259,262);
+      e  the edge attributes as an [n_edges, n_attrs] array, attached only with use_edge_data (gcn.py:173-180 computes
+         them either way and drops them by default)."""
+    import networkx as nx
+    import scipy.sparse as sp
+    g = format_graph(graph)
+    a = sp.csr_matrix(nx.adjacency_matrix(g)).astype(np.int64)
+    a.sort_indices()
+    x = np.vstack([feat for _, feat in g.nodes.data(feature_name)])
+    y = np.array(label)
+    if not use_edge_data:
+        return Graph(x=x, a=a, y=y)
+    attrs = [d for _, _, d in g.edges(data=True)]
+    names = list(attrs[0].keys()) if attrs else []
+    e = np.array([[d[k] for d in attrs] for k in names]).T if names else np.zeros((len(attrs), 0))
+    return Graph(x=x, a=a, y=y, e=e)
+
+
+class NetworkxDataset(Dataset):
+    """MyDataset (gcn.py:66-197) over in-memory networkx graphs: ``NetworkxDataset(graphs, labels, n_samples=None)``
+    reads the first n_samples graphs through from_networkx.  (The reference unpickles them from disk with
+    nx.read_gpickle, which networkx 3 no longer has; loading pickles is the caller's business -- nothing here does.)"""
+
+    def __init__(self, graphs, labels, n_samples=None, use_edge_data=False, **kwargs):
+        self._nx = list(graphs)
+        self.labels = list(labels)
+        self.n_samples = len(self._nx) if n_samples is None else int(n_samples)
+        self.use_edge_data = use_edge_data
+        super().__init__(**kwargs)
+
+    def read(self):
+        return [from_networkx(self._nx[i], self.labels[i], self.use_edge_data) for i in range(self.n_samples)]
+
+
 def to_disjoint(x_list, a_list):
     """spektral.data.utils.to_disjoint: x = vstack, a = block_diag, i = repeat(arange(B), n)."""
     import scipy.sparse as sp

@@ -388,20 +388,9 @@ class GCN2(_GraphRunner):
 
 
 def evaluate(model, loader, normalize=None):
-    """The reference's evaluate(loader) (src/scripts/gcn.py:342-362): one pass of
-    loader.steps_per_epoch batches, eager forward with training=False, per-batch loss and accuracy
-    averaged with the batch sizes as weights.  Returns ((loss, acc), [pred per batch])."""
-    output, preds = [], []
-    step = 0
-    while step < loader.steps_per_epoch:
-        step += 1
-        inputs, target = loader.__next__()
-        batch = DeviceBatch.from_host(model.ctx, inputs, target, normalize=normalize)
-        loss, acc, pred = model.evaluate_batch(batch, None)
-        preds.append(pred)
-        output.append((loss, acc, len(target)))
-    output = np.array(output)
-    return tuple(np.average(output[:, :-1], 0, weights=output[:, -1])), preds
+    """The reference's evaluate(loader) (src/scripts/gcn.py:342-362).  One implementation: gcnx.train.evaluate."""
+    from .train import evaluate as _evaluate
+    return _evaluate(model, loader, normalize)
 
 
 class GeneralGNN(_GraphRunner):
@@ -480,16 +469,33 @@ class GeneralGNN(_GraphRunner):
         self.f_in, self.built = f_in, True
 
     WEIGHT_ORDER = ("kernel", "bias", "gamma", "beta", "moving_mean", "moving_var", "alpha")
+    # Order of one layer's arrays in get_weights() / set_weights() (model.get_weights() at gcn.py:383 feeds the .npz dump;
+    # PARITY UNPINNED: neither Keras nor Spektral is importable here, these restate their published code):
+    #  "layer"  every layer as Dense -> BatchNormalization -> PReLU would list it: kernel, bias, gamma, beta, moving_mean,
+    #           moving_variance, alpha.  That IS the Keras order for the pre / post MLPs (a Sequential of separate
+    #           Dense / BN / Dropout / PReLU layers, each contributing layer.weights in turn).
+    #  "keras"  (default) the same, except that GeneralConv is ONE Keras Layer with child layers: Layer.weights =
+    #           trainable_weights + non_trainable_weights, and trainable_weights = the layer's own add_weight variables
+    #           (kernel, bias) followed by its children's in attribute order (PReLU is created in __init__, Dropout and
+    #           BatchNormalization in build): kernel, bias, alpha, gamma, beta | moving_mean, moving_variance.
+    #  "keras_children_first"  the reading the round-1 review proposed (children's trainables before the layer's own):
+    #           alpha, gamma, beta, kernel, bias | moving_mean, moving_variance.
+    GNN_ORDERS = {"layer": WEIGHT_ORDER,
+                  "keras": ("kernel", "bias", "alpha", "gamma", "beta", "moving_mean", "moving_var"),
+                  "keras_children_first": ("alpha", "gamma", "beta", "kernel", "bias", "moving_mean", "moving_var")}
 
-    def get_weights(self):
-        return [L[k].numpy() for L in self.layers for k in self.WEIGHT_ORDER if k in L]
+    def _weight_keys(self, L, order):
+        keys = self.GNN_ORDERS[order] if L["group"] == "gnn" else self.WEIGHT_ORDER
+        return [k for k in keys if k in L]
 
-    def set_weights(self, weights):
+    def get_weights(self, order="keras"):
+        return [L[k].numpy() for L in self.layers for k in self._weight_keys(L, order)]
+
+    def set_weights(self, weights, order="keras"):
         it = iter(weights)
         for L in self.layers:
-            for k in self.WEIGHT_ORDER:
-                if k in L:
-                    L[k].copy_from_host(np.asarray(next(it), np.float32).reshape(L[k].shape))
+            for k in self._weight_keys(L, order):
+                L[k].copy_from_host(np.asarray(next(it), np.float32).reshape(L[k].shape))
 
     @property
     def trainable_variables(self):
@@ -660,29 +666,49 @@ class GeneralGNN(_GraphRunner):
         multi = self._multi()
         denom = float(global_batch or batch.n_graphs)
         if multi:
-            tot = self.comm.allreduce_host([batch.n, batch.n_graphs], "sum")
-            self._counts = {"n": float(tot[0]), "b": float(tot[1])}
-            denom = float(global_batch or tot[1])
+            # global row / graph counts for sync-BN: one host round trip per BATCH (cached by its uid), not per step
+            if getattr(self, "_counts_uid", None) != batch.uid:
+                tot = self.comm.allreduce_host([batch.n, batch.n_graphs], "sum")
+                self._counts = {"n": float(tot[0]), "b": float(tot[1])}
+                self._counts_uid = batch.uid
+            denom = float(global_batch or self._counts["b"])
+        # with a capturable communicator (RCCL) the whole sync-BN step -- 2 small all-reduces per layer forward, 1 per
+        # layer backward, the gradient all-reduce and SGD -- is recorded into ONE HIP graph
+        fused_comm = (multi and _lr is not None and self.use_graph and getattr(self.comm, "capturable", False)
+                      and not getattr(self, "_comm_capture_failed", False))
 
         def seq():
             logits = self._forward(batch, bufs, True)
             self.loss_acc.fill_zero()
             D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom, cce=self.cce_train)
             self._backward(batch, bufs, True)
-            if _lr is not None and not multi:              # the update rides in the same captured graph
+            if fused_comm:
+                self.comm.allreduce_sum(self.flat_g)
+            if _lr is not None and (fused_comm or not multi):   # the update rides in the same captured graph
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
-        if multi:
-            seq()                                          # collectives inside: not captured
+        self._step_applied = fused_comm or not multi
+        if multi and not fused_comm:
+            seq()                                          # host-mediated collectives inside: not captured
             self.comm.allreduce_sum(self.flat_g)
         else:
-            self._run(("grad", batch.uid, _lr), seq)
+            try:
+                self._run(("grad", batch.uid, _lr, denom), seq)
+            except Exception as e:
+                if not fused_comm:
+                    raise
+                import sys
+                print(f"gcnx: the sync-BN step could not be captured with its collectives ({e}); running it eagerly",
+                      file=sys.stderr)
+                self._comm_capture_failed = True
+                self._drop_graphs()
+                return self.loss_and_grads(batch, None, _lr, global_batch)
         return batch
 
     def train_step(self, inputs, target=None, lr=0.02, fetch=True, global_batch=None):
         """gcn.py:330-340 for the live model: forward(training=True), CCE, gradients, SGD, accuracy."""
         batch = self.loss_and_grads(inputs, target, _lr=float(lr), global_batch=global_batch)
-        if self._multi():
+        if not self._step_applied:
             D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr)
         if not fetch:
             return None

@@ -45,11 +45,14 @@ def _as_batch(model, inputs, target, normalize):
 
 
 def evaluate(model, loader, normalize=None):
-    """gcn.py:342-362: one pass of ``loader.steps_per_epoch`` batches with training=False; per-batch loss and
-    accuracy averaged with the batch sizes as weights.  Returns ((loss, acc), [probabilities per batch])."""
+    """gcn.py:342-362: one pass of ``loader.steps_per_epoch`` batches (the test loader is infinite, epochs=None:
+    the step count ends the pass) with training=False, eagerly; per-batch loss and accuracy averaged with the batch
+    sizes as weights.  Returns ((loss, acc), [probabilities per batch]).  The loss follows ``model.cce_eval``."""
     output, preds = [], []
-    for _ in range(loader.steps_per_epoch):
-        inputs, target = next(loader)
+    step = 0
+    while step < loader.steps_per_epoch:
+        step += 1
+        inputs, target = loader.__next__()
         batch = _as_batch(model, inputs, target, normalize)
         loss, acc, pred = model.evaluate_batch(batch, None)
         preds.append(pred)

@@ -284,6 +284,10 @@ API void orc_gcn2_step(const int32_t* rowptr, const int32_t* colidx, const float
   orc_gemm(y1, hdim, w2, NULL, h, hdim, n, hdim, hdim, 0);
   orc_spmm_csr(rowptr, colidx, vals, h, hdim, b2, y2, hdim, n, hdim, 1);
   orc_pool(gp, y2, hdim, pooled, b, hdim, 0, NULL);
+  /* the classifier head ([B,H] x [H,C], a few kilobytes) stays fp32 in every precision mode: the bf16 operand model
+   * covers the two GCNConv kernel products and their gradients only (what GCNX_PREC_BF16 selects) */
+  const int bf16_saved = g_bf16;
+  g_bf16 = 0;
   orc_gemm(pooled, hdim, w3, b3, logits, c, b, hdim, c, 0);
   out[0] = out[1] = 0.f;
   orc_softmax_cce(logits, y, b, c, denom, probs, out, dlogits, from_logits);
@@ -291,6 +295,7 @@ API void orc_gcn2_step(const int32_t* rowptr, const int32_t* colidx, const float
   orc_gemm_dw(pooled, hdim, dlogits, c, gw3, b, hdim, c);
   orc_colsum(dlogits, c, b, c, gb3);
   orc_gemm_dx(dlogits, c, w3, dpooled, hdim, b, hdim, c, NULL, 0);
+  g_bf16 = bf16_saved;
   orc_pool_bwd(gp, dpooled, dz, hdim, b, hdim, 0, NULL, y2, hdim);
   orc_colsum(dz, hdim, n, hdim, gb2);
   orc_spmm_csr(rowptr, colidx, vals, dz, hdim, NULL, h, hdim, n, hdim, 0);

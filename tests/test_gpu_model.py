@@ -451,11 +451,11 @@ def _general_gnn_case(seed, f_in, hidden, mp, n_graphs, tiny=False):
     return hb, layers, flat
 
 
-def _kink_free_case(f_in, hidden, mp, n_graphs, margin=5e-5):
+def _kink_free_case(f_in, hidden, mp, n_graphs, margin=5e-5, seeds=200):
     """A GeneralGNN case in which no BN output lies within `margin` of the PReLU kink, so that fp32 and fp64
     take the same branch everywhere and gradients are comparable at 1e-4 (seed scan on the host, deterministic)."""
     from oracle import gcn_oracle as O
-    for seed in range(200):
+    for seed in range(seeds):
         hb, layers, flat = _general_gnn_case(seed, f_in, hidden, mp, n_graphs, tiny=True)
         csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
         _, caches, _ = O.general_gnn_forward(layers, hb.x.astype(np.float64), csr, hb.graph_ptr, True)
@@ -466,7 +466,8 @@ def _kink_free_case(f_in, hidden, mp, n_graphs, margin=5e-5):
     raise AssertionError("no kink-free case found")
 
 
-@pytest.mark.parametrize("f_in,hidden,mp,n_graphs,strict", [(16, 16, 4, 8, True), (16, 32, 2, 6, False), (16, 64, 4, 8, False)])
+@pytest.mark.parametrize("f_in,hidden,mp,n_graphs,strict", [(16, 16, 4, 8, True), (16, 32, 2, 6, False), (16, 64, 4, 8, False),
+                                                             (16, 256, 4, 3, True)])
 def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict):
     """The live model of gcn.py:320 (GeneralGNN: BN + PReLU + concat-skip + sum aggregation) on the
     device against the numpy oracle that test_oracle.py pins to torch autograd: training forward,
@@ -474,7 +475,12 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict):
     from oracle import gcn_oracle as O
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch, GeneralGNN
-    if strict:
+    if strict and hidden == 256:
+        # the reference's own size (gcn.py:320: hidden=256, message_passing=4, NetSurfP width 16; concat width 1280,
+        # 1.06 M parameters).  ~10^5 BN outputs: none within 2e-5 of the PReLU kink on the seed found (fp32 resolves
+        # them at ~1e-6), so that the gradients can be held to the same bar as the forward pass.
+        hb, layers, flat = _kink_free_case(f_in, hidden, mp, n_graphs, margin=2e-5, seeds=600)
+    elif strict:
         hb, layers, flat = _kink_free_case(f_in, hidden, mp, n_graphs)
     else:
         hb, layers, flat = _general_gnn_case(3 + mp, f_in, hidden, mp, n_graphs)
@@ -482,8 +488,8 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict):
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
     m = GeneralGNN(ctx, 2, activation="softmax", hidden=hidden, message_passing=mp)
     m.build(f_in)
-    m.set_weights(flat)
-    assert all(np.array_equal(w, f.astype(np.float32)) for w, f in zip(m.get_weights(), flat))
+    m.set_weights(flat, order="layer")
+    assert all(np.array_equal(w, f.astype(np.float32)) for w, f in zip(m.get_weights(order="layer"), flat))
     csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
     x64, y64 = hb.x.astype(np.float64), hb.y.astype(np.float64)
     # inference forward (moving statistics), evaluate() semantics of gcn.py:351
@@ -494,7 +500,7 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict):
     # flips one gradient element by O(1) -- the fp32 run of the numpy oracle itself deviates from its fp64
     # run by up to 2e-3 there -- so gradients only get a gross-error bound of 2 %.
     rl, ra, rg, rp, stats = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64)
-    before = m.get_weights()
+    before = m.get_weights(order="layer")
     loss, acc = m.train_step(batch, None, lr=0.01)
     assert abs(loss - rl) < TOL * max(1, rl) and acc == pytest.approx(ra)
     assert rel_err(m._bufs["probs"].numpy(), rp) < TOL
@@ -510,7 +516,7 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict):
                 assert np.max(np.abs(got[li][name] - ref)) < tol * np.abs(ref).max() + 1e-5 * layer_max, (grp, li, name)
             li += 1
     # moving statistics: m <- 0.99 m + 0.01 batch   (Keras momentum)
-    after = m.get_weights()
+    after = m.get_weights(order="layer")
     it_b, it_a = iter(before), iter(after)
     si = 0
     for L in m.layers:
@@ -525,6 +531,41 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict):
                 si += 1
             elif k == "kernel":
                 assert np.allclose(wa, wb - np.float32(0.01) * got[m.layers.index(L)]["kernel"], rtol=0, atol=1e-6)
+
+
+def test_general_gnn_weight_orders(ctx):
+    """get_weights() / set_weights() orders (model.get_weights(), gcn.py:383): "layer" lists every layer as Dense, BN,
+    PReLU would; "keras" (default) differs for the four GeneralConv layers only -- one Keras Layer whose own kernel and
+    bias come before its children's trainables (PReLU, then BatchNormalization), non-trainables last;
+    "keras_children_first" is the alternative reading.  All three round-trip; PARITY UNPINNED (no Keras here)."""
+    from gcnx.models import GeneralGNN
+    m = GeneralGNN(ctx, 2, activation="softmax", hidden=8, message_passing=2, seed=1)
+    m.build(4)
+    rng = np.random.default_rng(0)
+    for L in m.layers:                                    # make every array distinguishable
+        for k in m.WEIGHT_ORDER:
+            if k in L:
+                L[k].copy_from_host(rng.standard_normal(L[k].shape).astype(np.float32))
+    by_layer = m.get_weights(order="layer")
+    assert [w.shape for w in by_layer[:7]] == [(4, 8), (8,), (8,), (8,), (8,), (8,), (8,)]
+    keras = m.get_weights()
+    n_pre = 2 * 7
+    for a, b in zip(keras[:n_pre], by_layer[:n_pre]):      # the MLPs: identical in every order
+        assert np.array_equal(a, b)
+    g = by_layer[n_pre:n_pre + 7]                          # first GeneralConv: kernel,bias,gamma,beta,mm,mv,alpha
+    want = [g[0], g[1], g[6], g[2], g[3], g[4], g[5]]      # kernel, bias | alpha | gamma, beta | mm, mv
+    for a, b in zip(keras[n_pre:n_pre + 7], want):
+        assert np.array_equal(a, b)
+    cf = m.get_weights(order="keras_children_first")[n_pre:n_pre + 7]
+    for a, b in zip(cf, [g[6], g[2], g[3], g[0], g[1], g[4], g[5]]):
+        assert np.array_equal(a, b)
+    for order in ("layer", "keras", "keras_children_first"):
+        m2 = GeneralGNN(ctx, 2, activation="softmax", hidden=8, message_passing=2, seed=9)
+        m2.build(4)
+        m2.set_weights(m.get_weights(order=order), order=order)
+        assert all(np.array_equal(a, b) for a, b in zip(m2.get_weights(order="layer"), by_layer))
+    # the last post layer has no PReLU: 6 arrays
+    assert len(by_layer) == 7 * 5 + 6 and len(keras) == len(by_layer)
 
 
 def test_general_gnn_rejects_unbuilt_options(ctx):
@@ -685,3 +726,51 @@ def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     g1 = np.concatenate([m.gradients()[k].ravel() for k in ORDER])
     m.train_step(batch, None, lr=0.0)
     assert np.array_equal(g1, np.concatenate([m.gradients()[k].ravel() for k in ORDER]))
+
+
+@pytest.mark.parametrize("batch_norm,activation", [(True, "prelu"), (True, "relu"), (False, "relu"), (False, None)])
+def test_general_conv_layer_surface(ctx, batch_norm, activation):
+    """spektral.layers.GeneralConv as a layer of its own (SURVEY 8(b) surface list; inside GeneralGNN at gcn.py:320):
+    layer([x, a], training=) = sum-aggregation over a.indices of activation(BN(x W + b)) -- adjacency values ignored --
+    and backward(dy), against the oracle's dense_bn_act + spmm; training updates the moving statistics, inference
+    uses them."""
+    from oracle import gcn_oracle as O
+    from gcnx import synth
+    from gcnx.device import DeviceCSR
+    from gcnx.layers import GeneralConv
+    hb = synth.ecoli_batch(2, 12, seed=5)
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)            # values present -- and ignored
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    x = ctx.to_device(hb.x)
+    conv = GeneralConv(20, batch_norm=batch_norm, activation=activation, seed=4)
+    conv([x, a], training=True)                                  # builds
+    rng = np.random.default_rng(1)
+    names = list(conv.params) + list(conv.state)
+    assert names == (["kernel", "bias"] + (["alpha"] if activation == "prelu" else []) +
+                     (["gamma", "beta", "moving_mean", "moving_var"] if batch_norm else []))
+    w = {k: (v.numpy() + 0.1 * rng.standard_normal(v.shape)).astype(np.float32) for k, v in {**conv.params, **conv.state}.items()}
+    if "moving_var" in w:
+        w["moving_var"] = np.abs(w["moving_var"]) + 0.5
+    if "alpha" in w:
+        w["alpha"] = (0.25 * rng.random(20)).astype(np.float32)
+    conv.set_weights([w[k] for k in names])
+    p = {k: v.astype(np.float64) for k, v in w.items()}
+    if not batch_norm:
+        p.update(gamma=np.ones(20), beta=np.zeros(20), moving_mean=np.zeros(20), moving_var=np.ones(20) - O.BN_EPS)
+    x64 = hb.x.astype(np.float64)
+    rp, ci = hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64)
+    for training in ((False, True) if batch_norm else (False,)):
+        y = conv([x, a], training=training)
+        h, cache, mm, mv = O.dense_bn_act_fwd(x64, p, training, activation)
+        assert rel_err(y.numpy(), O.spmm_csr(rp, ci, None, h)) < TOL, training
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    dx = conv.backward(ctx.to_device(dy))
+    dh = O.spmm_csr_T(rp, ci, None, dy.astype(np.float64))
+    rdx, rg = O.dense_bn_act_bwd(dh, cache, p, activation)
+    assert rel_err(dx.numpy(), rdx) < 2 * TOL
+    for k in conv.grads:
+        assert rel_err(conv.grads[k].numpy(), rg[k]) < 2 * TOL or np.abs(rg[k]).max() < 1e-9, k
+    if batch_norm:
+        assert rel_err(conv.state["moving_mean"].numpy(), mm) < TOL and rel_err(conv.state["moving_var"].numpy(), mv) < TOL
+    with pytest.raises(NotImplementedError):
+        GeneralConv(8, aggregate="max")

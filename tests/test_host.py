@@ -247,3 +247,47 @@ def test_shardable_generators_do_not_depend_on_the_number_of_ranks():
     pl = synth.power_law_batch(3, 512, 4, seed=3, max_deg=128, first_graph=0)
     assert 128 <= np.diff(pl.rowptr).max() <= 132 and np.array_equal(       # the wired hub row (+ a stray Chung-Lu partner)
         synth.power_law_batch(2, 512, 4, seed=3, max_deg=128, first_graph=1).x, pl.x[512:])
+
+
+def test_from_networkx_reproduces_the_reference_data_contract():
+    """VERDICT r1 item 9 / SURVEY 8(a) a8: MyDataset's per-graph steps (gcn.py:104-128, 161-197) on networkx graphs
+    built here (no pickle anywhere): node labels -> integers in node order, ``weight`` stripped so the adjacency is
+    0/1, the builder's self-loops kept, scipy CSR int64, features stacked in node order as float64, one-hot label,
+    edge attributes dropped unless requested -- and the graphs feed DisjointLoader like any other."""
+    import networkx as nx
+    import scipy.sparse as sp
+    from gcnx import DisjointLoader, NetworkxDataset, from_networkx
+    rng = np.random.default_rng(0)
+    graphs, labels = [], []
+    for k, n in enumerate((5, 8, 3)):
+        g = nx.Graph()
+        names = [f"res{n - i}" for i in range(n)]                       # string names, NOT in sorted order
+        for i, nm in enumerate(names):
+            g.add_node(nm, x=rng.standard_normal(16))
+            g.add_edge(nm, nm, weight=0.0, dca=0.0, proximity=1.0)     # the 0-Angstrom self contact (gcn_utills.py:224-227)
+        for i in range(n - 1):
+            g.add_edge(names[i], names[i + 1], weight=3.8 + i, dca=0.1 * i, proximity=0.5)
+        g.add_edge(names[0], names[-1], weight=9.5, dca=0.9, proximity=0.1)
+        graphs.append(g); labels.append([1, 0] if k % 2 else [0, 1])
+    sg = from_networkx(graphs[1], labels[1])
+    n = 8
+    assert sp.issparse(sg.a) and sg.a.dtype == np.int64 and sg.a.shape == (n, n)
+    dense = sg.a.toarray()
+    assert set(np.unique(dense)) == {0, 1}                              # weights stripped: a 0/1 pattern
+    assert np.array_equal(dense, dense.T) and np.all(np.diag(dense) == 1)   # undirected, self-loops kept
+    assert dense.sum() == n + 2 * (n - 1) + 2 - (2 if n == 2 else 0)
+    assert dense[0, 1] == 1 and dense[0, n - 1] == 1 and dense[0, 2] == 0   # node ORDER of the graph, not of the names
+    assert sg.x.dtype == np.float64 and sg.x.shape == (n, 16)
+    assert np.array_equal(sg.x[0], graphs[1].nodes["res8"]["x"]) and np.array_equal(sg.x[-1], graphs[1].nodes["res1"]["x"])
+    assert np.array_equal(sg.y, [1, 0]) and sg.e is None
+    assert "weight" in graphs[1].edges["res8", "res7"]                  # the caller's graph is left untouched
+    se = from_networkx(graphs[1], labels[1], use_edge_data=True)
+    assert se.e.shape == (graphs[1].number_of_edges(), 2)              # dca, proximity (weight removed)
+    ds = NetworkxDataset(graphs, labels, n_samples=3)
+    assert len(ds) == 3 and ds.n_labels == 2 and ds.n_node_features == 16
+    (x, a, i), y = next(DisjointLoader(ds, batch_size=3, epochs=1, shuffle=False))
+    assert x.shape == (16, 16) and a.dense_shape == (16, 16) and np.array_equal(np.bincount(i), [5, 8, 3])
+    assert a.indices.dtype == np.int64 and np.all(a.values == 1) and y.shape == (3, 2)
+    # a directed graph gives an asymmetric adjacency: allowed by the contract (the device side then transposes)
+    dg = nx.DiGraph(); dg.add_node(0, x=np.zeros(2)); dg.add_node(1, x=np.ones(2)); dg.add_edge(0, 1, weight=2.0)
+    assert np.array_equal(from_networkx(dg, [1, 0]).a.toarray(), [[0, 1], [0, 0]])
