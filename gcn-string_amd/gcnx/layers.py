@@ -191,7 +191,7 @@ class GeneralConv(Layer):
         if self.batch_norm:
             c = self.channels
             self.state = {"moving_mean": ctx.zeros(c), "moving_var": ctx.to_device(np.ones(c, np.float32))}
-            self._mean, self._inv, self._sums, self._scratch = ctx.zeros(c), ctx.zeros(c), ctx.zeros(2 * c), ctx.zeros(3 * c)
+            self._mean, self._inv, self._sums, self._bn_scratch = ctx.zeros(c), ctx.zeros(c), ctx.zeros(2 * c), ctx.zeros(3 * c)
         return off
 
     def get_weights(self):
@@ -230,7 +230,7 @@ class GeneralConv(Layer):
         dh = self._buf("dh", dy.shape)
         D.spmm(ctx, au.transpose(), dy, None, dh)            # dH = S^T dY
         if self.batch_norm:
-            D.bn_act_bwd(ctx, dh, z, self._mean, self._inv, self.params["gamma"], self.params["beta"], dh, self._scratch,
+            D.bn_act_bwd(ctx, dh, z, self._mean, self._inv, self.params["gamma"], self.params["beta"], dh, self._bn_scratch,
                          act=self.activation, alpha=self.params.get("alpha"), training=training,
                          dgamma=self.grads["gamma"], dbeta=self.grads["beta"], dalpha=self.grads.get("alpha"))
             D.act_bias_grad(ctx, dh, None, dh, None, db=self.grads.get("bias"))
