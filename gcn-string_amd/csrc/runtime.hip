@@ -87,7 +87,7 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   }
   ctx->num_cus = prop.multiProcessorCount;
   ctx->arch = prop.gcnArchName;
-  if (const char* k = getenv("GCNX_SPMM_KERNEL")) ctx->knob_spmm_kernel = k[0] == 'r' ? 1 : k[0] == 't' ? 2 : 0;
+  if (const char* k = getenv("GCNX_SPMM_KERNEL")) ctx->knob_spmm_kernel = k[0] == 'r' ? 1 : k[0] == 't' ? 2 : k[0] == 'p' ? 3 : 0;
   if (const char* k = getenv("GCNX_SPMM_SLAB")) ctx->knob_spmm_slab = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_SG")) ctx->knob_spmm_sg = atoi(k);
   if (const char* k = getenv("GCNX_GEMM_STREAM")) ctx->knob_gemm_stream = atoi(k);
@@ -125,6 +125,18 @@ int gcnx_ctx_destroy(gcnx_ctx* ctx) {
 const char* gcnx_last_error(gcnx_ctx* ctx) {
   if (ctx && !ctx->err.empty()) return ctx->err.c_str();
   return gcnx_tls_error.c_str();
+}
+
+int gcnx_set_tuning(gcnx_ctx* ctx, const char* key, int value) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, key != nullptr, "gcnx_set_tuning: key is NULL");
+  const std::string k = key;
+  if (k == "spmm_kernel") ctx->knob_spmm_kernel = value;
+  else if (k == "spmm_slab") ctx->knob_spmm_slab = value;
+  else if (k == "spmm_sg") ctx->knob_spmm_sg = value;
+  else if (k == "gemm_stream") ctx->knob_gemm_stream = value;
+  else return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_set_tuning: unknown key '%s'", key);
+  return GCNX_OK;
 }
 
 int gcnx_device_info(gcnx_ctx* ctx, char* name, int len, int* cus, size_t* hbm_bytes) {

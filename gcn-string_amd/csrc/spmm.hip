@@ -678,6 +678,257 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
 }
 #undef GCNX_DSTEP4
 
+// ----------------------------------------------------------------------------------------------
+// Pipelined tile kernel (opt-in, see gcnx_spmm_csr): the tile kernel above with its phases OVERLAPPED.
+//
+// What the round-1 ablation of the tile kernel showed: tile in + result out run at the HBM rate, the LDS reduction costs
+// less than that -- but inside a workgroup they ADD (DMA, barrier, reduce, store), and two workgroups per CU cover
+// each other only a little.  Here one 1024-thread workgroup per CU holds TWO source buffers (624 rows x 32 columns x
+// 4 B = 78 KiB each):
+//   * at the start of a phase all 16 waves issue the LDS-DMA of the NEXT phase's source rows into the other buffer
+//     (inline asm: with the builtin hipcc drains it, vmcnt(0), in front of the first LDS read -- what serialised the
+//     first double-buffered version; a dedicated loader wave was tried too: one wave moves ~20 GB/s, 313 us for the
+//     launch), then reduce the current buffer; the wait for the pieces is placed by hand at the end of the phase,
+//     counted past the output stores (every wave issues exactly 6 per slab: range-checked buffer stores).
+//   * a phase = (work item, column slab, source chunk).  Graphs taller than one buffer are gathered chunk by chunk
+//     (entries are sorted by column: a chunk owns a contiguous part of every row's entries; the others point at a zero
+//     row) with the accumulators kept in registers across the chunks -- so EVERY graph of a disjoint batch takes this
+//     kernel (no tiers, no fallback to the row gather), graphs of more than 960 rows as several output-row blocks.
+//   * one barrier per phase: reduce(p) runs while DMA(p + 1) streams.
+// A row's first 32 entries live in registers for the whole item (the second 16 through range-checked buffer loads: rows
+// of up to 16 entries, 98 % at degree 10, fetch nothing); rows with more than 32 add the rest after the last chunk
+// straight from global memory.  (A first version fetched entries 17.. there, serially: 230 us of a 750 us launch.)
+// ----------------------------------------------------------------------------------------------
+constexpr int kPipeChunk = 624;                       // source rows per LDS buffer
+constexpr int kPipeBuf = (kPipeChunk + 1) * 128;      // bytes: rows + the all-zero row padding entries point at
+constexpr int kPipeQuads = 256;                       // output rows per pass (16 waves x 16 quads)
+constexpr int kPipeNI = 3;                            // passes: at most 720 output rows per work item
+constexpr int kPipeOutCap = kPipeQuads * kPipeNI;
+constexpr int kPipeMaxF = 512;                        // bias slice kept in LDS
+constexpr int kPipeLds = 2 * kPipeBuf + kPipeMaxF * 4;
+
+struct PipeItem { int row0, ng, o0, o1; };            // graph rows [row0, row0 + ng), output rows [o0, o1) of the graph
+
+#define GCNX_PSTEP4(J, MC, MV, T)                                                                              \
+  if (__builtin_amdgcn_ballot_w64(slot == (J) && any4) != 0) {                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      const int off = quad_bcast<4, (J)>(MC[i]);                                                               \
+      f32x2 w2 = f32x2{1.f, 1.f};                                                                              \
+      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[i]))); w2 = f32x2{w, w}; } \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+        const float4 hv = *reinterpret_cast<const float4*>(tb[j] + off);                                       \
+        if (WEIGHTED) {                                                                                        \
+          acc[T][j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[T][j][0]);                       \
+          acc[T][j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[T][j][1]);                       \
+        } else {                                                                                               \
+          acc[T][j][0] += f32x2{hv.x, hv.y};                                                                   \
+          acc[T][j][1] += f32x2{hv.z, hv.w};                                                                   \
+        }                                                                                                      \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
+// LDS-DMA of one 16-byte piece per lane, written as inline asm ON PURPOSE: for the builtin, hipcc (ROCm 7.2) puts
+// s_waitcnt vmcnt(0) in front of every later LDS read (it cannot tell the two buffers apart), which serialises the
+// pipeline; an asm statement is invisible to its wait-count pass, and the waits for these pieces are placed by hand
+// (end of the phase, counted past the output stores).  lds_base: wave-uniform byte address (M0); the DMA adds lane * 16.
+__device__ __forceinline__ void pipe_dma16(const float* gptr, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory");
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(1024, 4) void spmm_pipe_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
+    const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
+    const PipeItem* __restrict__ items, int upg /* slab groups per item */, int sg /* slabs per group */, int act,
+    int nunits, int n, int f, int dbg_rt) {
+#ifdef GCNX_TUNING
+  const int dbg = dbg_rt;                             // phase-ablation bits of a tuning build (results wrong by design):
+#else                                                 // 1 no DMA, 2 no reduction, 4 no stores, 8 no index burst
+  constexpr int dbg = 0;
+  (void)dbg_rt;
+#endif
+  extern __shared__ __attribute__((aligned(16))) char plds[];
+  float* lbias = reinterpret_cast<float*>(plds + 2 * kPipeBuf);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = gridDim.x;
+  const int w = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // consecutive virtual ids share an XCD
+  auto unit_of = [&](int round) { return round * G + ((round & 1) ? (G - 1 - w) : w); };
+  if (unit_of(0) >= nunits) return;                   // uniform per workgroup: before any barrier
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)plds;
+
+  // Phase sequence of this workgroup: unit -> (item, slab group); slab s of the group; source chunk c (balanced
+  // chunks: nch = ceil(ng / 624), rows per chunk = ceil(ng / nch)).  A small cursor walks it one phase ahead for the DMA.
+  struct Cursor { int round, s, c, nch, crows, row0, ng, cbase; bool live; };
+  auto load_unit = [&](Cursor& k) {
+    const int u = unit_of(k.round);
+    k.live = u < nunits;
+    if (!k.live) return;
+    const PipeItem it = items[u / upg];
+    k.row0 = it.row0; k.ng = it.ng; k.cbase = (u % upg) * sg * 32;
+    k.nch = (it.ng + kPipeChunk - 1) / kPipeChunk; k.crows = (it.ng + k.nch - 1) / k.nch;
+    k.s = 0; k.c = 0;
+  };
+  auto advance = [&](Cursor& k) {
+    if (++k.c < k.nch) return;
+    k.c = 0;
+    if (++k.s < sg) return;
+    ++k.round;
+    load_unit(k);
+  };
+  // all 16 waves issue the pieces of a phase: lane l of wave v moves piece (l & 7) of rows 8 (v + 16 k) + (l >> 3)
+  auto dma_phase = [&](const Cursor& k, int buf) {
+    if (!k.live || (dbg & 1)) return;
+    const int r0 = k.c * k.crows, rows = min(k.crows, k.ng - r0);
+    const float* src = h + (int64_t)(k.row0 + r0 + wave * 8 + (lane >> 3)) * ldh + k.cbase + k.s * 32 + (lane & 7) * 4;
+    const unsigned dst = lds0 + buf * kPipeBuf + wave * 1024;
+    const int64_t step = 128 * ldh;
+    for (int rb = wave * 8, kk = 0; rb < rows; rb += 128, ++kk) {       // wave-uniform trip count
+      if (rb + (lane >> 3) < rows) pipe_dma16(src, __builtin_amdgcn_readfirstlane(dst + kk * 16384));
+      src += step;
+    }
+  };
+
+  const int sub = lane & 3, slot = sub;               // lane of the quad: entries [4 slot, 4 slot + 4) of its row
+  const int rbase = wave * 16 + (lane >> 2);          // this quad's row within a pass
+  const int csw = (((lane >> 2) + 2) >> 2) & 1;       // chunk-order swizzle against ds_read_b128 bank conflicts (as above)
+  for (int i = tid; i < 32; i += 1024) {              // the two zero rows
+    reinterpret_cast<float*>(plds + kPipeChunk * 128)[i] = 0.f;
+    reinterpret_cast<float*>(plds + kPipeBuf + kPipeChunk * 128)[i] = 0.f;
+  }
+  for (int i = tid; i < f; i += 1024) lbias[i] = bias ? bias[i] : 0.f;
+  const int nnz = rowptr[n];
+  const EntryBufs ebufs = entry_bufs(colidx, vals, nnz);
+  const __amdgpu_buffer_rsrc_t obuf =
+      __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)min((uint64_t)n * (uint64_t)ldo * 4u, (uint64_t)0xFFFFFFF0u), 0x00020000);
+  const unsigned ldo4 = (unsigned)ldo * 4u;
+
+  Cursor nxt{0, 0, 0, 1, 0, 0, 0, 0, false};
+  load_unit(nxt);
+  dma_phase(nxt, 0);                                  // phase 0
+  advance(nxt);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int round = 0;; ++round) {
+    const int u = unit_of(round);
+    if (u >= nunits) break;
+    const PipeItem it = items[u / upg];
+    const int cbase = (u % upg) * sg * 32;
+    const int nch = (it.ng + kPipeChunk - 1) / kPipeChunk, crows = (it.ng + nch - 1) / nch;
+    const int orows = it.o1 - it.o0;
+    // index burst of the item: row pointers and the first 32 entries of every output row of this quad (raw column
+    // index relative to the graph, -1 = padding), shared by all slabs and chunks of the item
+    int ea[kPipeNI], eb[kPipeNI], mcol[kPipeNI][4], mcol2[kPipeNI][4];
+    float mv[kPipeNI][4], mv2[kPipeNI][4];
+#pragma unroll
+    for (int t = 0; t < kPipeNI; ++t) {
+      const int r = rbase + t * kPipeQuads;
+      const I2u p = *reinterpret_cast<const I2u*>(rowptr + it.row0 + it.o0 + min(r, orows - 1));
+      ea[t] = p.x;
+      eb[t] = r < orows ? p.y : p.x;
+    }
+#pragma unroll
+    for (int t = 0; t < kPipeNI; ++t) {
+      if (!(dbg & 8)) {
+        fetch_entries<WEIGHTED, 1>(ebufs, ea[t], slot, eb[t], it.row0, -1, mcol[t], mv[t]);
+        fetch_entries<WEIGHTED, 1>(ebufs, ea[t] + 16, slot, eb[t], it.row0, -1, mcol2[t], mv2[t]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mcol[t][i] = mcol2[t][i] = -1; mv[t][i] = mv2[t][i] = 0.f; }
+      }
+    }
+    for (int s = 0; s < sg; ++s) {
+      const int c0 = cbase + s * 32;
+      f32x2 acc[kPipeNI][2][2];
+#pragma unroll
+      for (int t = 0; t < kPipeNI; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j][0] = acc[t][j][1] = f32x2{0.f, 0.f};
+      for (int c = 0; c < nch; ++c) {
+        // the next phase's rows stream into the other buffer while this one is reduced
+        dma_phase(nxt, buf ^ 1);
+        advance(nxt);
+        const bool last = c == nch - 1;
+        const int ch0 = c * crows, chn = min(crows, it.ng - ch0);
+        const char* tb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tb[j] = plds + buf * kPipeBuf + (sub + 4 * (j ^ csw)) * 16;
+#pragma unroll
+        for (int t = 0; t < kPipeNI; ++t) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (t * kPipeQuads < orows && !(dbg & 2)) {
+            int mc[4];
+            bool any4 = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {             // tile byte offset of the entry in THIS chunk, else the zero row
+              const unsigned rel = (unsigned)(mcol[t][i] - ch0);
+              const bool ok = rel < (unsigned)chn;
+              mc[i] = ok ? (int)rel * 128 : kPipeChunk * 128;
+              any4 |= ok;
+            }
+            GCNX_PSTEP4(0, mc, mv[t], t)
+            GCNX_PSTEP4(1, mc, mv[t], t)
+            GCNX_PSTEP4(2, mc, mv[t], t)
+            GCNX_PSTEP4(3, mc, mv[t], t)
+            if (__builtin_amdgcn_ballot_w64(eb[t] - ea[t] > 16) != 0) {   // entries 17 .. 32 of the wave's long rows
+              any4 = false;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const unsigned rel = (unsigned)(mcol2[t][i] - ch0);
+                const bool ok = rel < (unsigned)chn;
+                mc[i] = ok ? (int)rel * 128 : kPipeChunk * 128;
+                any4 |= ok;
+              }
+              GCNX_PSTEP4(0, mc, mv2[t], t)
+              GCNX_PSTEP4(1, mc, mv2[t], t)
+              GCNX_PSTEP4(2, mc, mv2[t], t)
+              GCNX_PSTEP4(3, mc, mv2[t], t)
+            }
+          }
+          if (last) {
+            // rows longer than 32 entries: the rest straight from global memory (rare; h is L2-resident)
+            if (__builtin_amdgcn_ballot_w64(eb[t] - ea[t] > 32) != 0) {
+              for (int e = ea[t] + 32; e < eb[t]; ++e) {
+                const int col = colidx[e];
+                const float v = WEIGHTED ? vals[e] : 1.0f;
+                const float* hr = h + (int64_t)col * ldh + c0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  const float4 hv = *reinterpret_cast<const float4*>(hr + (sub + 4 * (j ^ csw)) * 4);
+                  acc[t][j][0] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{hv.x, hv.y}, acc[t][j][0]);
+                  acc[t][j][1] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{hv.z, hv.w}, acc[t][j][1]);
+                }
+              }
+            }
+            // epilogue of this row group right behind its reduction (the stores stream under the next group's LDS
+            // reads): bias, activation, 128 bytes per row.  Range-checked buffer stores: a quad without a row gets an
+            // out-of-range offset, so that EVERY wave issues exactly 2 kPipeNI stores per slab -- the count the
+            // hand-placed vmcnt below relies on.
+            const int r = rbase + t * kPipeQuads;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int cc = c0 + (sub + 4 * (j ^ csw)) * 4;
+              const float4 bvj = *reinterpret_cast<const float4*>(lbias + cc);
+              float4 o = make_float4(acc[t][j][0][0] + bvj.x, acc[t][j][0][1] + bvj.y, acc[t][j][1][0] + bvj.z, acc[t][j][1][1] + bvj.w);
+              if (act == GCNX_ACT_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+              const unsigned off = (r < orows && !(dbg & 4)) ? (unsigned)(it.row0 + it.o0 + r) * ldo4 + (unsigned)cc * 4u : 0xFFFFFFF0u;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4v{o.x, o.y, o.z, o.w}), obuf, off, 0, 0);
+            }
+          }
+        }
+        // end of the phase: this wave's DMA pieces of the next phase have landed once at most the stores issued
+        // after them (2 kPipeNI, only behind a slab's last chunk) are still outstanding; then everybody's have.
+        if (last) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kPipeNI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+      }
+    }
+  }
+}
+#undef GCNX_PSTEP4
+
 // Fallback for widths / strides that are not multiples of 4 floats: one lane per column.
 __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ colidx,
@@ -788,6 +1039,8 @@ struct gcnx_spmm_plan {
   long long tile_rows = 0;
   int cap1 = kDuoCap32, cap2 = kSoloCap32;   // tier limits the lists were built for
   int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
+  PipeItem* items = nullptr;            // pipelined kernel: work items (graph, output-row block), costliest first
+  int nitems = 0;
 };
 
 extern "C" {
@@ -836,6 +1089,31 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
     }
+    // work items of the pipelined kernel: every graph, in output-row blocks of at most kPipeOutCap rows
+    std::vector<PipeItem> items;
+    for (int g = 0; g < nblocks; ++g) {
+      const int r0 = bp[g], ng = bp[g + 1] - bp[g];
+      if (ng <= 0) continue;
+      const int nob = (ng + kPipeOutCap - 1) / kPipeOutCap, per = (ng + nob - 1) / nob;
+      for (int o = 0; o < ng; o += per) items.push_back(PipeItem{r0, ng, o, std::min(o + per, ng)});
+    }
+    auto cost = [](const PipeItem& a) { return (long long)(a.o1 - a.o0) * (1 + (a.ng + kPipeChunk - 1) / kPipeChunk); };
+    std::sort(items.begin(), items.end(), [&](const PipeItem& a, const PipeItem& b) {
+      const long long ca = cost(a), cb = cost(b);
+      return ca != cb ? ca > cb : (a.row0 != b.row0 ? a.row0 < b.row0 : a.o0 < b.o0);
+    });
+    p->nitems = (int)items.size();
+    if (!items.empty()) {
+      hipError_t e = hipMalloc((void**)&p->items, items.size() * sizeof(PipeItem));
+      if (e == hipSuccess) e = hipMemcpyAsync(p->items, items.data(), items.size() * sizeof(PipeItem), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) {
+        if (p->items) (void)hipFree(p->items);
+        if (p->dev) (void)hipFree(p->dev);
+        delete p;
+        return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e));
+      }
+    }
     *out = p;
   } catch (const std::bad_alloc&) {
     return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_create: out of host memory");
@@ -848,6 +1126,7 @@ int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
   if (!plan) return GCNX_OK;
   (void)hipStreamSynchronize(ctx->stream);
   if (plan->dev) (void)hipFree(plan->dev);
+  if (plan->items) (void)hipFree(plan->items);
   delete plan;
   return GCNX_OK;
 }
@@ -870,14 +1149,50 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  const int force = ctx->knob_spmm_kernel;   // tuning knob GCNX_SPMM_KERNEL (read at ctx creation): rows / tile
+  const int force = ctx->knob_spmm_kernel;   // tuning knob GCNX_SPMM_KERNEL / gcnx_set_tuning: 1 rows, 2 tile (tiers), 3 pipe
   // The tile kernel is a throughput design (one item per CU at a time): it needs a few items
   // per CU to fill the chip, otherwise the rows kernel's finer decomposition wins.
   bool tiles = plan && f % kSlab == 0 && (long long)(plan->n1 + 2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
   if (force == 1) tiles = false;
-  if (force == 2 && plan && f % kSlab == 0) tiles = true;
+  if (force >= 2 && plan && f % kSlab == 0) tiles = true;
   if (!tiles) {
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0);
+    GCNX_LAUNCH_OK(ctx);
+    return GCNX_OK;
+  }
+  // The pipelined kernel (opt-in: GCNX_SPMM_KERNEL=pipe / gcnx_set_tuning): every graph of the batch, no tiers, one
+  // 1024-thread workgroup per CU with two source buffers.  Correct on every case the tier kernels are tested on, but
+  // at config 3 it measures 690-750 us against 646 for the tier kernels (the phases overlap, yet with
+  // ONE lock-stepped workgroup per CU the LDS reduction itself runs slower than in two independent workgroups), so the
+  // tier kernels stay the default.
+  if (force == 3 && plan->nitems > 0 && f <= kPipeMaxF && (uint64_t)n * (uint64_t)ldo * 4u < 0xFFFFFFF0ull) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
+      attr_set = true;
+    }
+    const int slabs = f / kSlab, full = ctx->num_cus;
+    int sg = 1;
+    for (int c = 8; c > 1; c >>= 1)
+      if (slabs % c == 0 && (long long)plan->nitems * (slabs / c) >= 3LL * full) { sg = c; break; }
+    if (ctx->knob_spmm_sg >= 1 && slabs % ctx->knob_spmm_sg == 0) sg = ctx->knob_spmm_sg;
+    const int upg = slabs / sg;
+    const long long nunits = (long long)plan->nitems * upg;
+    if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
+    const int grid = (int)(nunits < full ? nunits : full);
+    int pdbg = 0;
+#ifdef GCNX_TUNING
+    if (const char* e = getenv("GCNX_SPMM_DBG")) pdbg = atoi(e);
+#endif
+    if (vals)
+      hipLaunchKernelGGL((spmm_pipe_kernel<true>), dim3(grid), dim3(1024), kPipeLds, ctx->stream, rowptr, colidx, vals, h, ldh,
+                         bias, out, ldo, plan->items, upg, sg, act, (int)nunits, n, f, pdbg);
+    else
+      hipLaunchKernelGGL((spmm_pipe_kernel<false>), dim3(grid), dim3(1024), kPipeLds, ctx->stream, rowptr, colidx, vals, h, ldh,
+                         bias, out, ldo, plan->items, upg, sg, act, (int)nunits, n, f, pdbg);
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }

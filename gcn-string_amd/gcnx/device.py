@@ -32,6 +32,7 @@ class Context:
         self.h = h
         self.device = int(device)
         self._live = True
+        self._force_plan = os.environ.get("GCNX_SPMM_KERNEL", "")[:1] in ("t", "p")
 
     # -- info ------------------------------------------------------------------------------
     def info(self):
@@ -43,6 +44,16 @@ class Context:
 
     def _ck(self, rc):
         L.check(rc, self.h)
+
+    SPMM_KERNELS = {"auto": 0, "rows": 1, "tile": 2, "pipe": 3}
+
+    def set_tuning(self, key, value):
+        """Kernel-selection knobs of this context (gcnx_set_tuning; diagnostics: results never depend on them).
+        ``set_tuning("spmm_kernel", "auto" | "rows" | "tile" | "pipe")``, ``("gemm_stream", 0 | 1)``, ..."""
+        if key == "spmm_kernel":
+            self._force_plan = value in ("tile", "pipe")
+            value = self.SPMM_KERNELS[value]
+        self._ck(self.lib.gcnx_set_tuning(self.h, key.encode(), int(value)))
 
     # -- memory ----------------------------------------------------------------------------
     def empty(self, shape, dtype=np.float32):
@@ -253,7 +264,7 @@ class DeviceCSR:
             return None
         # The tile kernels need >= 4 (graph, 32-column slab) units per CU (gcnx_spmm_csr); below ~128 graphs no
         # width reaches that, and building a plan (a D2H copy, a host sort, an upload) per streamed batch is wasted.
-        if self.n_blocks < 128 and os.environ.get("GCNX_SPMM_KERNEL", "") != "tile":
+        if self.n_blocks < 128 and not getattr(self.ctx, "_force_plan", False):
             return None
         holder = self.block_ptr
         p = getattr(holder, "_spmm_plan", None)

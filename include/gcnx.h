@@ -84,6 +84,12 @@ GCNX_API const char* gcnx_last_error(gcnx_ctx* ctx);
 /* Fills name[len] with the device's gcnArchName and *cus with its compute-unit count. */
 GCNX_API int gcnx_device_info(gcnx_ctx* ctx, char* name, int len, int* cus, size_t* hbm_bytes);
 
+/* Diagnostics, not part of the drop-in contract: kernel-selection knobs of this ctx (the GCNX_* environment variables
+ * set their initial values at gcnx_ctx_create; results never depend on them, only which kernel computes them).
+ * Keys: "spmm_kernel" (0 auto, 1 rows, 2 tile = the round-1 tier kernels, 3 pipe = force the pipelined tile kernel),
+ * "spmm_slab", "spmm_sg", "gemm_stream" (0 = bf16 GEMMs stay on the tiled kernel). */
+GCNX_API int gcnx_set_tuning(gcnx_ctx* ctx, const char* key, int value);
+
 /* ---- memory / sync (h2d, d2h synchronise the ctx stream) ------------------------------- */
 GCNX_API int gcnx_malloc(gcnx_ctx* ctx, size_t bytes, void** dptr);
 GCNX_API int gcnx_free(gcnx_ctx* ctx, void* dptr);

@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for v in "" abl1 abl2 abl3; do
-  if [ -n "$v" ]; then export GCNX_LIB=$GRAFT_REPO_ROOT/scripts/variants/lib_$v.so; fi
-  echo "== variant ${v:-base}"
-  for p in bf16x3 bf16; do timeout -k 10 120 python scripts/gemm_bench.py --n 1000000 --shapes 256x256 --prec $p --iters 10; done
-done 2>&1
+timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "spmm" 2>&1 | tail -5
+export GCNX_LIB=$GRAFT_REPO_ROOT/scripts/variants/lib_tune.so
+for d in 0 1 2 4 6 7; do echo "== pipe DBG=$d"; GCNX_SPMM_DBG=$d GCNX_SPMM_KERNEL=pipe timeout -k 10 200 python scripts/spmm_bench.py --workload block1m --rounds 1 --iters 10 --slabs 0 2>&1 | tail -1; done
+for sgv in 2 4; do echo "== pipe SG=$sgv"; GCNX_SPMM_SG=$sgv GCNX_SPMM_KERNEL=pipe timeout -k 10 200 python scripts/spmm_bench.py --workload block1m --rounds 1 --iters 10 --slabs 0 2>&1 | tail -1; done

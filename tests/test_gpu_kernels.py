@@ -63,16 +63,17 @@ def test_spmm_long_rows_overflowing_the_lds_stage(ctx):
 
 @pytest.mark.parametrize("weighted", [False, True])
 def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
-    """The LDS-tile kernel on a batch that holds every scheduling class: graphs at and around the tier limits (604
-    rows: two 512-thread workgroups per CU; 1236: one 1024-thread workgroup), taller ones (row chunks for the rows
-    kernel), a single-node graph, rows with > 16 entries (on-demand index fetch)."""
+    """The LDS-tile kernels on a batch that holds every scheduling class: graphs at and around the limits of the
+    pipelined kernel (624 rows: one source buffer; 720: one output-row block; 1248: two chunks) and of the round-1
+    tier kernels (604 / 1236), taller ones, a single-node graph, rows with > 16 and > 32 entries (second register set / tail from global memory;
+    on-demand index fetch) -- pipelined kernel, tier kernels and row gather against the oracle."""
     from gcnx import device as D, synth
     import scipy.sparse as sp
     rng = np.random.default_rng(11)
-    sizes = [1, 40, 604, 605, 632, 633, 1236, 1237, 1264, 1265, 300, 2000, 7]
+    sizes = [1, 40, 100, 604, 605, 624, 625, 632, 633, 720, 721, 1236, 1237, 1248, 1249, 1264, 1265, 300, 2000, 7]
     blocks = []
     for i, m in enumerate(sizes):
-        dens = 0.5 if m == 40 else min(1.0, 9.0 / m)          # the 40-node graph has ~20-entry rows
+        dens = 0.5 if m in (40, 100) else min(1.0, 9.0 / m)   # ~20-entry rows (40 nodes) and ~50-entry rows (100 nodes)
         a = sp.random(m, m, density=dens, random_state=i, format="csr")
         a = ((a + a.T) > 0).astype(np.float32) + sp.identity(m, dtype=np.float32, format="csr")
         blocks.append((a > 0).astype(np.float32))
@@ -85,17 +86,27 @@ def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
     bias = rng.standard_normal(64).astype(np.float32)
     ref = _ref_spmm(hb, vals, hb.x, bias, True)
     out = ctx.zeros((n, 64))
-    for kernel in ("tile", "rows"):
-        monkeypatch.setenv("GCNX_SPMM_KERNEL", kernel)
-        out.fill_zero()
-        D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out, act="relu")
-        assert rel_err(out.numpy(), ref) < TIGHT, kernel
-    # the tile path is deterministic: a second launch reproduces the first bit for bit
-    monkeypatch.setenv("GCNX_SPMM_KERNEL", "tile")
-    out2 = ctx.zeros((n, 64))
-    D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out, act="relu")
-    D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out2, act="relu")
-    assert np.array_equal(out.numpy(), out2.numpy())
+    try:
+        for kernel in ("pipe", "tile", "rows"):
+            ctx.set_tuning("spmm_kernel", kernel)
+            out.fill_zero()
+            D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out, act="relu")
+            assert rel_err(out.numpy(), ref) < TIGHT, kernel
+            # deterministic: a second launch reproduces the first bit for bit
+            out2 = ctx.zeros((n, 64))
+            D.spmm(ctx, csr, ctx.to_device(hb.x), ctx.to_device(bias), out2, act="relu")
+            assert np.array_equal(out.numpy(), out2.numpy()), kernel
+        # the pipelined kernel at other widths (1, 2, 4, 8 slabs; slab groups of 1 and 4), without bias / activation
+        ctx.set_tuning("spmm_kernel", "pipe")
+        for f, sgk in ((32, 0), (128, 1), (256, 4), (256, 0)):
+            ctx.set_tuning("spmm_sg", sgk)
+            xf = rng.standard_normal((n, f), dtype=np.float32)
+            o = ctx.zeros((n, f))
+            D.spmm(ctx, csr, ctx.to_device(xf), None, o)
+            assert rel_err(o.numpy(), _ref_spmm(hb, vals, xf, None, False)) < TIGHT, (f, sgk)
+    finally:
+        ctx.set_tuning("spmm_kernel", "auto")
+        ctx.set_tuning("spmm_sg", 0)
 
 
 def test_side_sections_order_and_capture(ctx):
