@@ -1041,6 +1041,7 @@ struct gcnx_spmm_plan {
   int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
   PipeItem* items = nullptr;            // pipelined kernel: work items (graph, output-row block), costliest first
   int nitems = 0;
+  int nitems_tall = 0;                  // the first nitems_tall of them belong to graphs taller than any tier (> cap2 rows)
 };
 
 extern "C" {
@@ -1099,10 +1100,13 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     }
     auto cost = [](const PipeItem& a) { return (long long)(a.o1 - a.o0) * (1 + (a.ng + kPipeChunk - 1) / kPipeChunk); };
     std::sort(items.begin(), items.end(), [&](const PipeItem& a, const PipeItem& b) {
+      const bool ta = a.ng > cap2, tb = b.ng > cap2;          // tall graphs first: they are also a list of their own
+      if (ta != tb) return ta;
       const long long ca = cost(a), cb = cost(b);
       return ca != cb ? ca > cb : (a.row0 != b.row0 ? a.row0 < b.row0 : a.o0 < b.o0);
     });
     p->nitems = (int)items.size();
+    for (const PipeItem& it : items) p->nitems_tall += it.ng > cap2 ? 1 : 0;
     if (!items.empty()) {
       hipError_t e = hipMalloc((void**)&p->items, items.size() * sizeof(PipeItem));
       if (e == hipSuccess) e = hipMemcpyAsync(p->items, items.data(), items.size() * sizeof(PipeItem), hipMemcpyHostToDevice, ctx->stream);
@@ -1160,12 +1164,10 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
-  // The pipelined kernel (opt-in: GCNX_SPMM_KERNEL=pipe / gcnx_set_tuning): every graph of the batch, no tiers, one
-  // 1024-thread workgroup per CU with two source buffers.  Correct on every case the tier kernels are tested on, but
-  // at config 3 it measures 690-750 us against 646 for the tier kernels (the phases overlap, yet with
-  // ONE lock-stepped workgroup per CU the LDS reduction itself runs slower than in two independent workgroups), so the
-  // tier kernels stay the default.
-  if (force == 3 && plan->nitems > 0 && f <= kPipeMaxF && (uint64_t)n * (uint64_t)ldo * 4u < 0xFFFFFFF0ull) {
+  // The pipelined kernel: any graph size, one 1024-thread workgroup per CU with two source buffers.  Opt-in
+  // (GCNX_SPMM_KERNEL=pipe / gcnx_set_tuning): correct on every case the tier kernels are tested on, but at config 3 it
+  // measures 690-750 us against 646 for the tiers, so the tier kernels stay the default.
+  auto launch_pipe = [&](int count) -> int {
     static bool attr_set = false;
     if (!attr_set) {
       GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<true>),
@@ -1177,10 +1179,10 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     const int slabs = f / kSlab, full = ctx->num_cus;
     int sg = 1;
     for (int c = 8; c > 1; c >>= 1)
-      if (slabs % c == 0 && (long long)plan->nitems * (slabs / c) >= 3LL * full) { sg = c; break; }
+      if (slabs % c == 0 && (long long)count * (slabs / c) >= 3LL * full) { sg = c; break; }
     if (ctx->knob_spmm_sg >= 1 && slabs % ctx->knob_spmm_sg == 0) sg = ctx->knob_spmm_sg;
     const int upg = slabs / sg;
-    const long long nunits = (long long)plan->nitems * upg;
+    const long long nunits = (long long)count * upg;
     if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
     const int grid = (int)(nunits < full ? nunits : full);
     int pdbg = 0;
@@ -1195,7 +1197,9 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
                          bias, out, ldo, plan->items, upg, sg, act, (int)nunits, n, f, pdbg);
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
-  }
+  };
+  const bool pipe_ok = f <= kPipeMaxF && (uint64_t)n * (uint64_t)ldo * 4u < 0xFFFFFFF0ull;
+  if (force == 3 && plan->nitems > 0 && pipe_ok) return launch_pipe(plan->nitems);
   // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
   if (plan->n1 > 0) {
     int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1);
@@ -1206,6 +1210,8 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
                                      plan->n2);
     if (rc) return rc;
   }
+  // (the taller graphs through the pipelined kernel instead -- launch_pipe(plan->nitems_tall) -- measured 677 us against
+  // 649: ~100 work items do not fill 256 CUs)
   if (plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
                   plan->nchunks);
