@@ -16,12 +16,13 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--slabs", default="0")
 ap.add_argument("--unweighted", action="store_true")
 args = ap.parse_args()
-if args.workload == "block1m":
-    hb = synth.block_diag_batch(with_x=False); f = 256
+if args.workload == "block1m":       # the batches bench.py times (per-graph-seeded generators)
+    sizes, pairs = synth.block_diag_plan()
+    hb = synth.block_diag_shard(0, len(sizes), sizes, pairs, 256, seed=2, with_x=False); f = 256
 elif args.workload == "ecoli":
-    hb = synth.ecoli_batch(); f = 128
+    hb = synth.ecoli_shard(0, 32, 128, seed=1); f = 128
 else:
-    hb = synth.power_law_batch(with_x=False); f = 256
+    hb = synth.power_law_batch(122, 8192, 256, seed=3, with_x=False, first_graph=0); f = 256
 vals = None if args.unweighted else synth.gcn_norm_host(hb.rowptr, hb.colidx)
 ctx = gcnx.Context(0)
 a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
@@ -31,10 +32,12 @@ alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, f, vals is not None)
 print(f"N={hb.n} nnz={hb.nnz} F={f} alg={alg/1e6:.1f} MB")
 for rnd in range(args.rounds):
     for slab in args.slabs.split(","):
-        for k_ in ("GCNX_SPMM_SLAB", "GCNX_SPMM_KERNEL", "GCNX_SPMM_ABLATE"): os.environ.pop(k_, None)
-        if slab.startswith("tile") and slab != "tile": os.environ["GCNX_SPMM_ABLATE"] = slab[4:]; os.environ["GCNX_SPMM_KERNEL"] = "tile"
-        elif slab in ("rows", "tile"): os.environ["GCNX_SPMM_KERNEL"] = slab
-        elif slab != "0": os.environ["GCNX_SPMM_SLAB"] = slab; os.environ["GCNX_SPMM_KERNEL"] = "rows"
+        # variants: "0" = what the library picks; "rows" / "tile" / "pipe" = that kernel; a number = rows kernel, that slab width
+        if "GCNX_SPMM_KERNEL" not in os.environ:
+            ctx.set_tuning("spmm_slab", 0)
+            if slab in ("rows", "tile", "pipe"): ctx.set_tuning("spmm_kernel", slab)
+            elif slab != "0": ctx.set_tuning("spmm_slab", int(slab)); ctx.set_tuning("spmm_kernel", "rows")
+            else: ctx.set_tuning("spmm_kernel", "auto")
         for _ in range(3): D.spmm(ctx, a, h, bias, out, act="relu")
         e0 = ctx.event().record()
         for _ in range(args.iters): D.spmm(ctx, a, h, bias, out, act="relu")
