@@ -679,44 +679,62 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
 #undef GCNX_DSTEP4
 
 // ----------------------------------------------------------------------------------------------
-// Pipelined tile kernel (opt-in, see gcnx_spmm_csr): the tile kernel above with its phases OVERLAPPED.
+// Pipelined tile kernel: the tile kernel above with its phases OVERLAPPED.
 //
-// What the round-1 ablation of the tile kernel showed: tile in + result out run at the HBM rate, the LDS reduction costs
-// less than that -- but inside a workgroup they ADD (DMA, barrier, reduce, store), and two workgroups per CU cover
-// each other only a little.  Here one 1024-thread workgroup per CU holds TWO source buffers (624 rows x 32 columns x
-// 4 B = 78 KiB each):
-//   * at the start of a phase all 16 waves issue the LDS-DMA of the NEXT phase's source rows into the other buffer
-//     (inline asm: with the builtin hipcc drains it, vmcnt(0), in front of the first LDS read -- what serialised the
-//     first double-buffered version; a dedicated loader wave was tried too: one wave moves ~20 GB/s, 313 us for the
-//     launch), then reduce the current buffer; the wait for the pieces is placed by hand at the end of the phase,
-//     counted past the output stores (every wave issues exactly 6 per slab: range-checked buffer stores).
-//   * a phase = (work item, column slab, source chunk).  Graphs taller than one buffer are gathered chunk by chunk
-//     (entries are sorted by column: a chunk owns a contiguous part of every row's entries; the others point at a zero
-//     row) with the accumulators kept in registers across the chunks -- so EVERY graph of a disjoint batch takes this
-//     kernel (no tiers, no fallback to the row gather), graphs of more than 960 rows as several output-row blocks.
-//   * one barrier per phase: reduce(p) runs while DMA(p + 1) streams.
-// A row's first 32 entries live in registers for the whole item (the second 16 through range-checked buffer loads: rows
-// of up to 16 entries, 98 % at degree 10, fetch nothing); rows with more than 32 add the rest after the last chunk
-// straight from global memory.  (A first version fetched entries 17.. there, serially: 230 us of a 750 us launch.)
+// What the round-1 ablation of the tile kernel showed: tile in + result out run at the HBM rate, the LDS reduction
+// costs less than that -- but inside a workgroup they ADD (DMA, barrier, reduce, store), and two workgroups per CU
+// cover each other only a little.  Here one 1024-thread workgroup per CU holds TWO source buffers of 78 KiB:
+//   * a phase = (graph, column slab).  Graphs of up to 624 rows use 32-column slabs, graphs of up to 1024 rows
+//     16-column slabs (25 % more index work per column, but no graph is gathered in pieces); taller graphs stay with
+//     the row gather (plan-listed chunks).
+//   * while a phase is reduced, the rows of the NEXT phase stream into the other buffer by LDS-DMA, issued a piece at a
+//     time between the row groups (a burst blocks the issuing waves for as long as the memory pipeline takes to accept
+//     it: 90-150 us of a launch were spent "issuing").  The DMA is inline asm ON PURPOSE: for the builtin, hipcc
+//     (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every later LDS read -- it cannot tell the two buffers apart --
+//     which is what serialised every double-buffered version before this one (scripts/micro/lds_dma_overlap.hip shows the
+//     hardware overlaps the two perfectly).  The wait for the pieces is placed by hand at the end of the phase,
+//     counted past the last row group's stores (range-checked buffer stores: every wave issues the same number).
+//   * a row's first 32 entries live in registers for the whole graph: column indices as 16-bit pairs (entry k and
+//     entry 16 + k of the row share a register; 0xFFFF... no: padding entries hold the index of an all-zero row), so a
+//     quad broadcast (DPP) and ONE v_mad_u32_u16 (op_sel picks the half) give the LDS address; weights as fp32.  Rows of
+//     up to 16 entries (98 % at degree 10) fetch nothing for the second half (range-checked buffer loads); rows with
+//     more than 32 add the rest after the reduction straight from global memory.
+//   * one barrier per phase.
 // ----------------------------------------------------------------------------------------------
-constexpr int kPipeChunk = 624;                       // source rows per LDS buffer
-constexpr int kPipeBuf = (kPipeChunk + 1) * 128;      // bytes: rows + the all-zero row padding entries point at
-constexpr int kPipeQuads = 256;                       // output rows per pass (16 waves x 16 quads)
-constexpr int kPipeNI = 3;                            // passes: at most 720 output rows per work item
-constexpr int kPipeOutCap = kPipeQuads * kPipeNI;
+constexpr int kPipeBufBytes = 624 * 128;              // = 1248 * 64: source rows of a phase
+constexpr int kPipeBuf = kPipeBufBytes + 128;         // + the all-zero row padding entries point at
+constexpr int kPipeCap32 = 624, kPipeCap16 = 1024;    // graph rows per phase with 32- / 16-column slabs (16: 4 row groups of 256:
+                                                      // the registers that hold 32 entries per row allow no more)
 constexpr int kPipeMaxF = 512;                        // bias slice kept in LDS
 constexpr int kPipeLds = 2 * kPipeBuf + kPipeMaxF * 4;
 
-struct PipeItem { int row0, ng, o0, o1; };            // graph rows [row0, row0 + ng), output rows [o0, o1) of the graph
+struct PipeItem { int row0, ng; };                    // graph rows [row0, row0 + ng)
 
-#define GCNX_PSTEP4(J, MC, MV, T)                                                                              \
-  if (__builtin_amdgcn_ballot_w64(slot == (J) && any4) != 0) {                                                  \
+// LDS-DMA of one 16-byte piece per lane (see above why not the builtin).  lds_base: wave-uniform byte address (M0); the
+// DMA adds lane * 16.
+__device__ __forceinline__ void pipe_dma16(const float* gptr, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory");
+}
+// LDS address of an entry's row: base + (16-bit half of packed) * row_bytes, one instruction.
+template <int HI>
+__device__ __forceinline__ unsigned pipe_addr(unsigned packed, unsigned row_bytes, unsigned base) {
+  unsigned a;
+  if (HI) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a) : "v"(packed), "v"(row_bytes), "v"(base));
+  else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(a) : "v"(packed), "v"(row_bytes), "v"(base));
+  return a;
+}
+
+// One phase's reduction of row group T: 16 (+16) entries, FT columns per row (CPL float4 per lane of the quad).
+#define GCNX_PSTEP4(J, HI, MV, T)                                                                              \
+  if (__builtin_amdgcn_ballot_w64(slot == (J) && (HI ? cnt > 16 + 4 * (J) : cnt > 4 * (J))) != 0) {             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      const int off = quad_bcast<4, (J)>(MC[i]);                                                               \
+      const unsigned cp = (unsigned)quad_bcast<4, (J)>((int)colp[T][i]);                                        \
+      const unsigned a = pipe_addr<HI>(cp, FT * 4u, lbase);                                                     \
       f32x2 w2 = f32x2{1.f, 1.f};                                                                              \
-      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[i]))); w2 = f32x2{w, w}; } \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-        const float4 hv = *reinterpret_cast<const float4*>(tb[j] + off);                                       \
+      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[T][i]))); w2 = f32x2{w, w}; } \
+      _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                        \
+        const f32x4v hq = *reinterpret_cast<const __attribute__((address_space(3))) f32x4v*>(a + j * 64u);      \
+        const float4 hv = make_float4(hq.x, hq.y, hq.z, hq.w);                                                 \
         if (WEIGHTED) {                                                                                        \
           acc[T][j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[T][j][0]);                       \
           acc[T][j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[T][j][1]);                       \
@@ -728,25 +746,22 @@ struct PipeItem { int row0, ng, o0, o1; };            // graph rows [row0, row0 
     }                                                                                                          \
   }
 
-// LDS-DMA of one 16-byte piece per lane, written as inline asm ON PURPOSE: for the builtin, hipcc (ROCm 7.2) puts
-// s_waitcnt vmcnt(0) in front of every later LDS read (it cannot tell the two buffers apart), which serialises the
-// pipeline; an asm statement is invisible to its wait-count pass, and the waits for these pieces are placed by hand
-// (end of the phase, counted past the output stores).  lds_base: wave-uniform byte address (M0); the DMA adds lane * 16.
-__device__ __forceinline__ void pipe_dma16(const float* gptr, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory");
-}
+struct PipeCursor { int round, ph, nph, row0, ng, cbase, ft; bool live; };
 
-template <bool WEIGHTED>
+template <bool WEIGHTED, int KFT>
 __global__ __launch_bounds__(1024, 4) void spmm_pipe_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
     const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-    const PipeItem* __restrict__ items, int upg /* slab groups per item */, int sg /* slabs per group */, int act,
-    int nunits, int n, int f, int dbg_rt) {
+    const PipeItem* __restrict__ items, int upg /* slab groups per graph */, int sg /* 32-column slabs per group */, int act,
+    int nunits, int n, int f, int dbg_rt, unsigned long long* __restrict__ stamps) {
 #ifdef GCNX_TUNING
+#define PIPE_STAMP(K) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); seg[K] += t_ - tlast; tlast = t_; }
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
   const int dbg = dbg_rt;                             // phase-ablation bits of a tuning build (results wrong by design):
 #else                                                 // 1 no DMA, 2 no reduction, 4 no stores, 8 no index burst
   constexpr int dbg = 0;
-  (void)dbg_rt;
+  (void)dbg_rt; (void)stamps;
+#define PIPE_STAMP(K)
 #endif
   extern __shared__ __attribute__((aligned(16))) char plds[];
   float* lbias = reinterpret_cast<float*>(plds + 2 * kPipeBuf);
@@ -757,44 +772,49 @@ __global__ __launch_bounds__(1024, 4) void spmm_pipe_kernel(
   if (unit_of(0) >= nunits) return;                   // uniform per workgroup: before any barrier
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)plds;
 
-  // Phase sequence of this workgroup: unit -> (item, slab group); slab s of the group; source chunk c (balanced
-  // chunks: nch = ceil(ng / 624), rows per chunk = ceil(ng / nch)).  A small cursor walks it one phase ahead for the DMA.
-  struct Cursor { int round, s, c, nch, crows, row0, ng, cbase; bool live; };
-  auto load_unit = [&](Cursor& k) {
+  // Phase sequence of this workgroup: unit -> (graph, slab group); the group's sg 32-column slabs as sg phases of 32
+  // columns (graphs of up to 624 rows) or 2 sg phases of 16.  A cursor walks it one phase ahead for the DMA.
+  auto load_unit = [&](PipeCursor& k) {
     const int u = unit_of(k.round);
     k.live = u < nunits;
     if (!k.live) return;
     const PipeItem it = items[u / upg];
-    k.row0 = it.row0; k.ng = it.ng; k.cbase = (u % upg) * sg * 32;
-    k.nch = (it.ng + kPipeChunk - 1) / kPipeChunk; k.crows = (it.ng + k.nch - 1) / k.nch;
-    k.s = 0; k.c = 0;
+    k.row0 = __builtin_amdgcn_readfirstlane(it.row0); k.ng = __builtin_amdgcn_readfirstlane(it.ng);
+    k.cbase = (u % upg) * sg * 32;
+    k.ft = KFT;
+    k.nph = sg * (32 / KFT);
+    k.ph = 0;
   };
-  auto advance = [&](Cursor& k) {
-    if (++k.c < k.nch) return;
-    k.c = 0;
-    if (++k.s < sg) return;
+  auto advance = [&](PipeCursor& k) {
+    if (++k.ph < k.nph) return;
     ++k.round;
     load_unit(k);
   };
-  // all 16 waves issue the pieces of a phase: lane l of wave v moves piece (l & 7) of rows 8 (v + 16 k) + (l >> 3)
-  auto dma_phase = [&](const Cursor& k, int buf) {
+  // Piece step kk (0..4) of the phase under cursor k into buffer buf: one 1-KiB instruction per wave = 8 rows of 128 B
+  // (32-column slabs) or 16 rows of 64 B (16-column slabs); wave v takes rows [8 | 16] (v + 16 kk) ...
+  auto dma_step = [&](const PipeCursor& k, int buf, int kk) {
     if (!k.live || (dbg & 1)) return;
-    const int r0 = k.c * k.crows, rows = min(k.crows, k.ng - r0);
-    const float* src = h + (int64_t)(k.row0 + r0 + wave * 8 + (lane >> 3)) * ldh + k.cbase + k.s * 32 + (lane & 7) * 4;
-    const unsigned dst = lds0 + buf * kPipeBuf + wave * 1024;
-    const int64_t step = 128 * ldh;
-    for (int rb = wave * 8, kk = 0; rb < rows; rb += 128, ++kk) {       // wave-uniform trip count
-      if (rb + (lane >> 3) < rows) pipe_dma16(src, __builtin_amdgcn_readfirstlane(dst + kk * 16384));
-      src += step;
+    const int c0 = k.cbase + k.ph * k.ft;
+    if (KFT == 32) {
+      const int r = wave * 8 + kk * 128 + (lane >> 3);
+      if (wave * 8 + kk * 128 < k.ng) {               // uniform per wave
+        const float* src = h + (int64_t)(k.row0 + min(r, k.ng - 1)) * ldh + c0 + (lane & 7) * 4;
+        if (r < k.ng) pipe_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * kPipeBuf + (wave * 8 + kk * 128) * 128));
+      }
+    } else {
+      const int r = wave * 16 + kk * 256 + (lane >> 2);
+      if (wave * 16 + kk * 256 < k.ng) {
+        const float* src = h + (int64_t)(k.row0 + min(r, k.ng - 1)) * ldh + c0 + (lane & 3) * 4;
+        if (r < k.ng) pipe_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * kPipeBuf + (wave * 16 + kk * 256) * 64));
+      }
     }
   };
 
-  const int sub = lane & 3, slot = sub;               // lane of the quad: entries [4 slot, 4 slot + 4) of its row
-  const int rbase = wave * 16 + (lane >> 2);          // this quad's row within a pass
-  const int csw = (((lane >> 2) + 2) >> 2) & 1;       // chunk-order swizzle against ds_read_b128 bank conflicts (as above)
+  const int sub = lane & 3, slot = sub;               // lane of the quad: entries [4 slot, 4 slot + 4) (+16) of its row
+  const int rbase = wave * 16 + (lane >> 2);          // this quad's row within a pass of 256
   for (int i = tid; i < 32; i += 1024) {              // the two zero rows
-    reinterpret_cast<float*>(plds + kPipeChunk * 128)[i] = 0.f;
-    reinterpret_cast<float*>(plds + kPipeBuf + kPipeChunk * 128)[i] = 0.f;
+    reinterpret_cast<float*>(plds + kPipeBufBytes)[i] = 0.f;
+    reinterpret_cast<float*>(plds + kPipeBuf + kPipeBufBytes)[i] = 0.f;
   }
   for (int i = tid; i < f; i += 1024) lbias[i] = bias ? bias[i] : 0.f;
   const int nnz = rowptr[n];
@@ -803,129 +823,112 @@ __global__ __launch_bounds__(1024, 4) void spmm_pipe_kernel(
       __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)min((uint64_t)n * (uint64_t)ldo * 4u, (uint64_t)0xFFFFFFF0u), 0x00020000);
   const unsigned ldo4 = (unsigned)ldo * 4u;
 
-  Cursor nxt{0, 0, 0, 1, 0, 0, 0, 0, false};
+  PipeCursor nxt{0, 0, 1, 0, 0, 0, 32, false};
   load_unit(nxt);
-  dma_phase(nxt, 0);                                  // phase 0
+#pragma unroll
+  for (int kk = 0; kk < 5; ++kk) dma_step(nxt, 0, kk);   // phase 0
   advance(nxt);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  PIPE_STAMP(0)                                       // prologue
   int buf = 0;
+
+  // The body of one graph's phases, for one slab width: FT columns per phase, NI row groups of 256 rows.
+#define GCNX_PIPE_GRAPH(FT_, NI_)                                                                               \
+  {                                                                                                             \
+    constexpr int FT = FT_, NI = NI_, CPL = FT / 16;                                                            \
+    constexpr unsigned ZROW = kPipeBufBytes / (FT * 4);      /* index of the all-zero row in either buffer */   \
+    unsigned colp[NI][4], rcnt[NI];                                                                             \
+    float mv[NI][4], mv2[NI][4];                                                                                \
+    _Pragma("unroll") for (int t = 0; t < NI; ++t) {                                                            \
+      const int r = rbase + t * 256;                                                                            \
+      const I2u p = *reinterpret_cast<const I2u*>(rowptr + it.row0 + min(r, it.ng - 1));                        \
+      const int ea_t = p.x;                                                                                     \
+      rcnt[t] = r < it.ng ? (unsigned)(p.y - p.x) : 0u;                                                         \
+      int c1[4], c2[4];                                                                                         \
+      const int eb = ea_t + (int)rcnt[t];                                                                       \
+      if (!(dbg & 8)) {                                                                                         \
+        fetch_entries<WEIGHTED, 1>(ebufs, ea_t, slot, eb, it.row0, (int)ZROW, c1, mv[t]);                       \
+        fetch_entries<WEIGHTED, 1>(ebufs, ea_t + 16, slot, eb, it.row0, (int)ZROW, c2, mv2[t]);                 \
+      } else {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { c1[i] = c2[i] = (int)ZROW; mv[t][i] = mv2[t][i] = 0.f; } \
+      }                                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) colp[t][i] = (unsigned)c1[i] | ((unsigned)c2[i] << 16);     \
+    }                                                                                                           \
+    PIPE_STAMP(1)                                     /* index burst of the graph */                           \
+    for (int ph = 0; ph < nph; ++ph) {                                                                          \
+      const int c0 = cbase + ph * FT;                                                                           \
+      const unsigned lbase = lds0 + buf * kPipeBuf + sub * 16;                                                  \
+      f32x2 acc[NI][CPL][2];                                                                                    \
+      _Pragma("unroll") for (int t = 0; t < NI; ++t)                                                            \
+        _Pragma("unroll") for (int j = 0; j < CPL; ++j) acc[t][j][0] = acc[t][j][1] = f32x2{0.f, 0.f};          \
+      _Pragma("unroll") for (int t = 0; t < NI; ++t) {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        /* the next phase's rows, a piece at a time: all five pieces are out before the last row group's stores */ \
+        if (NI == 3) { if (t == 0) { dma_step(nxt, buf ^ 1, 0); dma_step(nxt, buf ^ 1, 1); }                     \
+                       if (t == 1) { dma_step(nxt, buf ^ 1, 2); dma_step(nxt, buf ^ 1, 3); }                     \
+                       if (t == 2) dma_step(nxt, buf ^ 1, 4); }                                                 \
+        else { dma_step(nxt, buf ^ 1, t); if (t == NI - 1) dma_step(nxt, buf ^ 1, NI); }                         \
+        const unsigned cnt = rcnt[t];                                                                           \
+        if (t * 256 < it.ng && !(dbg & 2)) {                                                                    \
+          GCNX_PSTEP4(0, 0, mv, t) GCNX_PSTEP4(1, 0, mv, t) GCNX_PSTEP4(2, 0, mv, t) GCNX_PSTEP4(3, 0, mv, t)     \
+          if (__builtin_amdgcn_ballot_w64(cnt > 16) != 0) {                                                     \
+            GCNX_PSTEP4(0, 1, mv2, t) GCNX_PSTEP4(1, 1, mv2, t) GCNX_PSTEP4(2, 1, mv2, t) GCNX_PSTEP4(3, 1, mv2, t) \
+          }                                                                                                     \
+          if (__builtin_amdgcn_ballot_w64(cnt > 32) != 0) {   /* the rest straight from global memory (rare) */  \
+            const int ea_t = rowptr[it.row0 + min(rbase + t * 256, it.ng - 1)];                                 \
+            for (int e = ea_t + 32; e < ea_t + (int)cnt; ++e) {                                                 \
+              const int col = colidx[e];                                                                        \
+              const float v = WEIGHTED ? vals[e] : 1.0f;                                                        \
+              const float* hr = h + (int64_t)col * ldh + c0 + sub * 4;                                          \
+              _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                 \
+                const float4 hv = *reinterpret_cast<const float4*>(hr + j * 16);                                \
+                acc[t][j][0] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{hv.x, hv.y}, acc[t][j][0]);         \
+                acc[t][j][1] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{hv.z, hv.w}, acc[t][j][1]);         \
+              }                                                                                                 \
+            }                                                                                                   \
+          }                                                                                                     \
+        }                                                                                                       \
+        /* epilogue of the row group right behind its reduction: bias, activation, FT * 4 bytes per row.  Range-  \
+           checked buffer stores (a quad without a row gets an out-of-range offset): every wave issues exactly CPL \
+           per row group, the count the hand-placed vmcnt below relies on. */                                    \
+        const int r = rbase + t * 256;                                                                          \
+        _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                       \
+          const int cc = c0 + sub * 4 + j * 16;                                                                 \
+          const float4 bvj = *reinterpret_cast<const float4*>(lbias + cc);                                      \
+          float4 o = make_float4(acc[t][j][0][0] + bvj.x, acc[t][j][0][1] + bvj.y, acc[t][j][1][0] + bvj.z, acc[t][j][1][1] + bvj.w); \
+          if (act == GCNX_ACT_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); } \
+          const unsigned off = (r < it.ng && !(dbg & 4)) ? (unsigned)(it.row0 + r) * ldo4 + (unsigned)cc * 4u : 0xFFFFFFF0u; \
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4v{o.x, o.y, o.z, o.w}), obuf, off, 0, 0); \
+        }                                                                                                       \
+      }                                                                                                         \
+      advance(nxt);                                                                                             \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+      PIPE_STAMP(3)                                   /* reduction + epilogue issue (+ DMA issue) */           \
+      /* every DMA piece of the next phase is older than the last row group's CPL stores */                     \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPL) : "memory");                                     \
+      PIPE_STAMP(4)                                   /* wait for the next phase's rows */                     \
+      __builtin_amdgcn_s_barrier();                                                                             \
+      PIPE_STAMP(5)                                   /* barrier */                                            \
+      buf ^= 1;                                                                                                 \
+    }                                                                                                           \
+  }
+
   for (int round = 0;; ++round) {
     const int u = unit_of(round);
     if (u >= nunits) break;
     const PipeItem it = items[u / upg];
     const int cbase = (u % upg) * sg * 32;
-    const int nch = (it.ng + kPipeChunk - 1) / kPipeChunk, crows = (it.ng + nch - 1) / nch;
-    const int orows = it.o1 - it.o0;
-    // index burst of the item: row pointers and the first 32 entries of every output row of this quad (raw column
-    // index relative to the graph, -1 = padding), shared by all slabs and chunks of the item
-    int ea[kPipeNI], eb[kPipeNI], mcol[kPipeNI][4], mcol2[kPipeNI][4];
-    float mv[kPipeNI][4], mv2[kPipeNI][4];
-#pragma unroll
-    for (int t = 0; t < kPipeNI; ++t) {
-      const int r = rbase + t * kPipeQuads;
-      const I2u p = *reinterpret_cast<const I2u*>(rowptr + it.row0 + it.o0 + min(r, orows - 1));
-      ea[t] = p.x;
-      eb[t] = r < orows ? p.y : p.x;
-    }
-#pragma unroll
-    for (int t = 0; t < kPipeNI; ++t) {
-      if (!(dbg & 8)) {
-        fetch_entries<WEIGHTED, 1>(ebufs, ea[t], slot, eb[t], it.row0, -1, mcol[t], mv[t]);
-        fetch_entries<WEIGHTED, 1>(ebufs, ea[t] + 16, slot, eb[t], it.row0, -1, mcol2[t], mv2[t]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { mcol[t][i] = mcol2[t][i] = -1; mv[t][i] = mv2[t][i] = 0.f; }
-      }
-    }
-    for (int s = 0; s < sg; ++s) {
-      const int c0 = cbase + s * 32;
-      f32x2 acc[kPipeNI][2][2];
-#pragma unroll
-      for (int t = 0; t < kPipeNI; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][j][0] = acc[t][j][1] = f32x2{0.f, 0.f};
-      for (int c = 0; c < nch; ++c) {
-        // the next phase's rows stream into the other buffer while this one is reduced
-        dma_phase(nxt, buf ^ 1);
-        advance(nxt);
-        const bool last = c == nch - 1;
-        const int ch0 = c * crows, chn = min(crows, it.ng - ch0);
-        const char* tb[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) tb[j] = plds + buf * kPipeBuf + (sub + 4 * (j ^ csw)) * 16;
-#pragma unroll
-        for (int t = 0; t < kPipeNI; ++t) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (t * kPipeQuads < orows && !(dbg & 2)) {
-            int mc[4];
-            bool any4 = false;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {             // tile byte offset of the entry in THIS chunk, else the zero row
-              const unsigned rel = (unsigned)(mcol[t][i] - ch0);
-              const bool ok = rel < (unsigned)chn;
-              mc[i] = ok ? (int)rel * 128 : kPipeChunk * 128;
-              any4 |= ok;
-            }
-            GCNX_PSTEP4(0, mc, mv[t], t)
-            GCNX_PSTEP4(1, mc, mv[t], t)
-            GCNX_PSTEP4(2, mc, mv[t], t)
-            GCNX_PSTEP4(3, mc, mv[t], t)
-            if (__builtin_amdgcn_ballot_w64(eb[t] - ea[t] > 16) != 0) {   // entries 17 .. 32 of the wave's long rows
-              any4 = false;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const unsigned rel = (unsigned)(mcol2[t][i] - ch0);
-                const bool ok = rel < (unsigned)chn;
-                mc[i] = ok ? (int)rel * 128 : kPipeChunk * 128;
-                any4 |= ok;
-              }
-              GCNX_PSTEP4(0, mc, mv2[t], t)
-              GCNX_PSTEP4(1, mc, mv2[t], t)
-              GCNX_PSTEP4(2, mc, mv2[t], t)
-              GCNX_PSTEP4(3, mc, mv2[t], t)
-            }
-          }
-          if (last) {
-            // rows longer than 32 entries: the rest straight from global memory (rare; h is L2-resident)
-            if (__builtin_amdgcn_ballot_w64(eb[t] - ea[t] > 32) != 0) {
-              for (int e = ea[t] + 32; e < eb[t]; ++e) {
-                const int col = colidx[e];
-                const float v = WEIGHTED ? vals[e] : 1.0f;
-                const float* hr = h + (int64_t)col * ldh + c0;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                  const float4 hv = *reinterpret_cast<const float4*>(hr + (sub + 4 * (j ^ csw)) * 4);
-                  acc[t][j][0] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{hv.x, hv.y}, acc[t][j][0]);
-                  acc[t][j][1] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{hv.z, hv.w}, acc[t][j][1]);
-                }
-              }
-            }
-            // epilogue of this row group right behind its reduction (the stores stream under the next group's LDS
-            // reads): bias, activation, 128 bytes per row.  Range-checked buffer stores: a quad without a row gets an
-            // out-of-range offset, so that EVERY wave issues exactly 2 kPipeNI stores per slab -- the count the
-            // hand-placed vmcnt below relies on.
-            const int r = rbase + t * kPipeQuads;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int cc = c0 + (sub + 4 * (j ^ csw)) * 4;
-              const float4 bvj = *reinterpret_cast<const float4*>(lbias + cc);
-              float4 o = make_float4(acc[t][j][0][0] + bvj.x, acc[t][j][0][1] + bvj.y, acc[t][j][1][0] + bvj.z, acc[t][j][1][1] + bvj.w);
-              if (act == GCNX_ACT_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-              const unsigned off = (r < orows && !(dbg & 4)) ? (unsigned)(it.row0 + it.o0 + r) * ldo4 + (unsigned)cc * 4u : 0xFFFFFFF0u;
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4v{o.x, o.y, o.z, o.w}), obuf, off, 0, 0);
-            }
-          }
-        }
-        // end of the phase: this wave's DMA pieces of the next phase have landed once at most the stores issued
-        // after them (2 kPipeNI, only behind a slab's last chunk) are still outstanding; then everybody's have.
-        if (last) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kPipeNI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        buf ^= 1;
-      }
-    }
+    const int nph = sg * (32 / KFT);
+    if (KFT == 32) GCNX_PIPE_GRAPH(32, 3)
+    else GCNX_PIPE_GRAPH(16, 4)
   }
+#undef GCNX_PIPE_GRAPH
+#ifdef GCNX_TUNING
+  if (stamps && (tid & 63) == 0)
+    for (int k = 0; k < 8; ++k) stamps[((size_t)blockIdx.x * 16 + wave) * 8 + k] = seg[k];
+#endif
+#undef PIPE_STAMP
 }
 #undef GCNX_PSTEP4
 
@@ -1039,9 +1042,10 @@ struct gcnx_spmm_plan {
   long long tile_rows = 0;
   int cap1 = kDuoCap32, cap2 = kSoloCap32;   // tier limits the lists were built for
   int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
-  PipeItem* items = nullptr;            // pipelined kernel: work items (graph, output-row block), costliest first
-  int nitems = 0;
-  int nitems_tall = 0;                  // the first nitems_tall of them belong to graphs taller than any tier (> cap2 rows)
+  PipeItem* items = nullptr;            // pipelined kernel: graphs, tallest first: [n16 graphs of 625..1024 rows | n32 of <= 624]
+  int nitems = 0, n16 = 0;
+  int2* pipe_chunks = nullptr;          // ... and the 32-row chunks of the graphs too tall for it (> 1248 rows), for the rows kernel
+  int npipe_chunks = 0;
 };
 
 extern "C" {
@@ -1090,29 +1094,34 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
     }
-    // work items of the pipelined kernel: every graph, in output-row blocks of at most kPipeOutCap rows
+    // work items of the pipelined kernel: every graph of up to 1248 rows (costliest first); taller ones as 32-row chunks
+    // for the rows kernel (list appended behind the items' own chunk list below)
     std::vector<PipeItem> items;
+    std::vector<int2> tall;
     for (int g = 0; g < nblocks; ++g) {
       const int r0 = bp[g], ng = bp[g + 1] - bp[g];
       if (ng <= 0) continue;
-      const int nob = (ng + kPipeOutCap - 1) / kPipeOutCap, per = (ng + nob - 1) / nob;
-      for (int o = 0; o < ng; o += per) items.push_back(PipeItem{r0, ng, o, std::min(o + per, ng)});
+      if (ng <= kPipeCap16) items.push_back(PipeItem{r0, ng});
+      else for (int r = r0; r < r0 + ng; r += kRowsPerChunk) tall.push_back(make_int2(r, std::min(r + kRowsPerChunk, r0 + ng)));
     }
-    auto cost = [](const PipeItem& a) { return (long long)(a.o1 - a.o0) * (1 + (a.ng + kPipeChunk - 1) / kPipeChunk); };
-    std::sort(items.begin(), items.end(), [&](const PipeItem& a, const PipeItem& b) {
-      const bool ta = a.ng > cap2, tb = b.ng > cap2;          // tall graphs first: they are also a list of their own
-      if (ta != tb) return ta;
-      const long long ca = cost(a), cb = cost(b);
-      return ca != cb ? ca > cb : (a.row0 != b.row0 ? a.row0 < b.row0 : a.o0 < b.o0);
-    });
+    std::sort(items.begin(), items.end(), [&](const PipeItem& a, const PipeItem& b) { return a.ng != b.ng ? a.ng > b.ng : a.row0 < b.row0; });
     p->nitems = (int)items.size();
-    for (const PipeItem& it : items) p->nitems_tall += it.ng > cap2 ? 1 : 0;
+    for (const PipeItem& it : items) p->n16 += it.ng > kPipeCap32 ? 1 : 0;    // sorted by size: they come first
+    p->npipe_chunks = (int)tall.size();
+    if (!tall.empty()) {
+      hipError_t e = hipMalloc((void**)&p->pipe_chunks, tall.size() * sizeof(int2));
+      if (e == hipSuccess) e = hipMemcpyAsync(p->pipe_chunks, tall.data(), tall.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { if (p->pipe_chunks) (void)hipFree(p->pipe_chunks); if (p->dev) (void)hipFree(p->dev); delete p;
+                             return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
+    }
     if (!items.empty()) {
       hipError_t e = hipMalloc((void**)&p->items, items.size() * sizeof(PipeItem));
       if (e == hipSuccess) e = hipMemcpyAsync(p->items, items.data(), items.size() * sizeof(PipeItem), hipMemcpyHostToDevice, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) {
         if (p->items) (void)hipFree(p->items);
+        if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
         if (p->dev) (void)hipFree(p->dev);
         delete p;
         return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e));
@@ -1131,6 +1140,7 @@ int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
   (void)hipStreamSynchronize(ctx->stream);
   if (plan->dev) (void)hipFree(plan->dev);
   if (plan->items) (void)hipFree(plan->items);
+  if (plan->pipe_chunks) (void)hipFree(plan->pipe_chunks);
   delete plan;
   return GCNX_OK;
 }
@@ -1167,13 +1177,13 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
   // The pipelined kernel: any graph size, one 1024-thread workgroup per CU with two source buffers.  Opt-in
   // (GCNX_SPMM_KERNEL=pipe / gcnx_set_tuning): correct on every case the tier kernels are tested on, but at config 3 it
   // measures 690-750 us against 646 for the tiers, so the tier kernels stay the default.
-  auto launch_pipe = [&](int count) -> int {
+  auto launch_pipe = [&](const PipeItem* list, int count, int ft) -> int {
     static bool attr_set = false;
     if (!attr_set) {
-      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
-      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_pipe_kernel<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds));
       attr_set = true;
     }
     const int slabs = f / kSlab, full = ctx->num_cus;
@@ -1186,20 +1196,50 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
     const int grid = (int)(nunits < full ? nunits : full);
     int pdbg = 0;
+    unsigned long long* stamps = nullptr;
 #ifdef GCNX_TUNING
     if (const char* e = getenv("GCNX_SPMM_DBG")) pdbg = atoi(e);
+    static unsigned long long* stamp_buf = nullptr;
+    if (getenv("GCNX_SPMM_STAMPS")) {
+      if (!stamp_buf) (void)hipMalloc((void**)&stamp_buf, (size_t)full * 16 * 8 * sizeof(unsigned long long));
+      (void)hipMemsetAsync(stamp_buf, 0, (size_t)full * 16 * 8 * sizeof(unsigned long long), ctx->stream);
+      stamps = stamp_buf;
+    }
 #endif
-    if (vals)
-      hipLaunchKernelGGL((spmm_pipe_kernel<true>), dim3(grid), dim3(1024), kPipeLds, ctx->stream, rowptr, colidx, vals, h, ldh,
-                         bias, out, ldo, plan->items, upg, sg, act, (int)nunits, n, f, pdbg);
-    else
-      hipLaunchKernelGGL((spmm_pipe_kernel<false>), dim3(grid), dim3(1024), kPipeLds, ctx->stream, rowptr, colidx, vals, h, ldh,
-                         bias, out, ldo, plan->items, upg, sg, act, (int)nunits, n, f, pdbg);
+#define GCNX_PIPE_LAUNCH(W, FT_)                                                                                            \
+    hipLaunchKernelGGL((spmm_pipe_kernel<W, FT_>), dim3(grid), dim3(1024), kPipeLds, ctx->stream, rowptr, colidx, vals, h, ldh, \
+                       bias, out, ldo, list, upg, sg, act, (int)nunits, n, f, pdbg, stamps)
+    if (vals) { if (ft == 32) GCNX_PIPE_LAUNCH(true, 32); else GCNX_PIPE_LAUNCH(true, 16); }
+    else { if (ft == 32) GCNX_PIPE_LAUNCH(false, 32); else GCNX_PIPE_LAUNCH(false, 16); }
+#undef GCNX_PIPE_LAUNCH
     GCNX_LAUNCH_OK(ctx);
+#ifdef GCNX_TUNING
+    if (stamps) {      // segment times (100 MHz ticks) of wave 0 and wave 15, averaged over the workgroups, to stderr
+      std::vector<unsigned long long> hst((size_t)full * 16 * 8);
+      (void)hipMemcpyAsync(hst.data(), stamps, hst.size() * 8, hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+      const char* names[8] = {"prologue", "index burst", "-", "reduce+epilogue+dma issue", "dma wait", "barrier", "-", "-"};
+      for (int wv : {0, 15}) {
+        double sum[8] = {0};
+        for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)hst[((size_t)b * 16 + wv) * 8 + k];
+        fprintf(stderr, "[pipe stamps ft %d] wave %2d:", ft, wv);
+        for (int k = 0; k < 6; ++k) if (names[k][0] != '-') fprintf(stderr, "  %s %.1f us", names[k], sum[k] / grid * 0.01);
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
     return GCNX_OK;
   };
   const bool pipe_ok = f <= kPipeMaxF && (uint64_t)n * (uint64_t)ldo * 4u < 0xFFFFFFF0ull;
-  if (force == 3 && plan->nitems > 0 && pipe_ok) return launch_pipe(plan->nitems);
+  if (force == 3 && pipe_ok) {
+    if (plan->n16 > 0) { int rc = launch_pipe(plan->items, plan->n16, 16); if (rc) return rc; }
+    if (plan->nitems > plan->n16) { int rc = launch_pipe(plan->items + plan->n16, plan->nitems - plan->n16, 32); if (rc) return rc; }
+    if (plan->npipe_chunks > 0) {   // graphs of more than 1248 rows: 32-row chunks on the rows kernel
+      dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->pipe_chunks, plan->npipe_chunks);
+      GCNX_LAUNCH_OK(ctx);
+    }
+    return GCNX_OK;
+  }
   // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
   if (plan->n1 > 0) {
     int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1);
@@ -1210,8 +1250,6 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
                                      plan->n2);
     if (rc) return rc;
   }
-  // (the taller graphs through the pipelined kernel instead -- launch_pipe(plan->nitems_tall) -- measured 677 us against
-  // 649: ~100 work items do not fill 256 CUs)
   if (plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
                   plan->nchunks);
