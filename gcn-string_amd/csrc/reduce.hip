@@ -98,6 +98,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// Plain column sums of a tall matrix whose rows are at most 1 KiB (f <= 256, f / 4 a power of two): a workgroup covers
+// WHOLE rows -- f / 4 float4 lanes per row, 256 / (f / 4) row groups -- so that a wave instruction reads whole rows
+// (1 KiB contiguous at f = 256; the 64-column tiles of colsum_kernel read 256-byte quarters of four rows), eight loads
+// in flight per thread.  Config 3 (10^6 x 256): 321 -> ~190 us per launch, twice per training step (db1, db2).  Row
+// groups are combined through LDS in a fixed order; partial layout as colsum_kernel: part[chunk][f].
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int32_t f,
+                                                          int64_t rows_per_chunk, float* __restrict__ part) {
+  __shared__ float4 s[256];
+  const int lpr = f >> 2, nrg = 256 / lpr;          // lanes per row, row groups
+  const int cl = threadIdx.x % lpr, rg = threadIdx.x / lpr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+  const float* px = x + cl * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t r = r0 + rg;
+  for (; r + 7 * nrg < r1; r += 8 * nrg) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(px + (r + u * nrg) * ldx);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  for (; r < r1; r += nrg) {
+    const float4 v = *reinterpret_cast<const float4*>(px + r * ldx);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  if (rg == 0) {
+    float4 t = s[cl];
+    for (int q = 1; q < nrg; ++q) { const float4 o = s[q * lpr + cl]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * f + cl * 4) = t;
+  }
+}
+
 // Pool forward: block = (column tile of 64, graph); 16 float4 column lanes x 16 row groups.
 // RG = row groups per workgroup (16 x RG threads).  16 for the stand-alone pool; 64 (1024 threads, four times the
 // loads in flight per workgroup) where the slice count is kept low for the consumer's sake (the head reads them).
@@ -384,13 +418,26 @@ __global__ __launch_bounds__(256) void pool_mask_partial_kernel(const int32_t* _
   }
 }
 
+// Column sums of a few hundred partial rows in ONE launch.  colsum_kernel's shape (64 columns x 16 row groups per
+// workgroup) would leave this to f/64 workgroups walking rows/16 dependent trips each (config 2: 2 workgroups, 40
+// trips, 22 us); here a workgroup owns 8 columns (two float4 lanes) x 128 row groups -- f/8 workgroups, rows/128
+// trips -- and folds the 128 partial sums in a fixed tree through LDS.
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int64_t rows, int32_t f,
+                                                             float* __restrict__ out) {
+  __shared__ float4 s[128][2];
+  gcnx_colpart_reduce_body(part, rows, f, out, blockIdx.x, s);
+}
+
 int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float* out, const float* y,
                 int64_t ldy, float* dz, int64_t lddz, int act, const float* alpha, float* out_alpha,
                 size_t ws_off = 0) {   // ws_off: floats at the start of the workspace that belong to the caller
   const bool fuse = (dz != nullptr);
   auto al = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
   const int vec = al(x) && ldx % 4 == 0 && (!fuse || (al(y) && ldy % 4 == 0 && al(dz) && lddz % 4 == 0));
-  const int nchunks = gcnx_cdiv(n, kColsumRows);
+  // tall plain sums of rows of at most 1 KiB: whole-row workgroups, 1024-row chunks (fewer partial rows to fold)
+  const bool wide = !fuse && vec && out && n >= 65536 && f >= 16 && f <= 256 && (f & (f - 1)) == 0;
+  const int64_t chunk_rows = wide ? 1024 : kColsumRows;
+  const int nchunks = gcnx_cdiv(n, chunk_rows);
   const bool want_alpha = fuse && act == GCNX_ACT_PRELU && out_alpha;
   const size_t need = (size_t)nchunks * f * sizeof(float) * (want_alpha ? 2 : 1);
   float* part = nullptr;
@@ -407,7 +454,9 @@ int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f
     }
   }
   dim3 grid(gcnx_cdiv(f, 64), nchunks);
-  if (fuse)
+  if (wide)
+    hipLaunchKernelGGL(colsum_wide_kernel, dim3(nchunks), dim3(256), 0, ctx->stream, x, ldx, n, f, chunk_rows, part);
+  else if (fuse)
     hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, ctx->stream, x, ldx, n, f, (int64_t)kColsumRows,
                        part, y, ldy, dz, lddz, act, alpha, part_a, vec);
   else
@@ -417,7 +466,11 @@ int colsum_impl(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f
   if (nchunks > 1) {
     const int vec2 = f % 4 == 0;   // the partials live in the 256-B aligned workspace with row stride f
     dim3 g2(gcnx_cdiv(f, 64), 1);
-    if (out) {
+    if (out && wide && nchunks <= 4096 && al(out)) {
+      hipLaunchKernelGGL(colpart_reduce_kernel, dim3(gcnx_cdiv(f, 8)), dim3(256), 0, ctx->stream, (const float*)part,
+                         (int64_t)nchunks, f, out);
+      GCNX_LAUNCH_OK(ctx);
+    } else if (out) {
       hipLaunchKernelGGL((colsum_kernel<false>), g2, dim3(256), 0, ctx->stream, (const float*)part, (int64_t)f,
                          (int64_t)nchunks, f, (int64_t)nchunks, out, nullptr, (int64_t)0, nullptr, (int64_t)0, 0,
                          nullptr, nullptr, vec2);
@@ -464,17 +517,7 @@ int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, 
   return GCNX_OK;
 }
 
-constexpr int64_t kPartialsOneLaunch = 4096;   // partial rows one launch of the kernel below still walks quickly
-
-// Column sums of a few hundred partial rows in ONE launch.  colsum_kernel's shape (64 columns x 16 row groups per
-// workgroup) would leave this to f/64 workgroups walking rows/16 dependent trips each (config 2: 2 workgroups, 40
-// trips, 22 us); here a workgroup owns 8 columns (two float4 lanes) x 128 row groups -- f/8 workgroups, rows/128
-// trips -- and folds the 128 partial sums in a fixed tree through LDS.
-__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int64_t rows, int32_t f,
-                                                             float* __restrict__ out) {
-  __shared__ float4 s[128][2];
-  gcnx_colpart_reduce_body(part, rows, f, out, blockIdx.x, s);
-}
+constexpr int64_t kPartialsOneLaunch = 4096;   // partial rows one launch of colpart_reduce_kernel still walks quickly
 
 size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f) {
   const size_t mine = (size_t)rows * f;

@@ -776,6 +776,22 @@ def test_act_bias_grad(ctx, act):
         assert rel_err(dal.numpy(), (dy.astype(np.float64) * np.minimum(y, 0)).sum(0)) < TIGHT
 
 
+@pytest.mark.parametrize("n,f", [(70001, 256), (65536, 64), (131075, 16), (70001, 48)])
+def test_colsum_tall(ctx, n, f):
+    """Plain column sums of a tall matrix (db of a million-row layer): the whole-row kernel (f a power of two) and the
+    64-column-tile kernel (f = 48) against float64 sums."""
+    from gcnx import device as D
+    rng = np.random.default_rng(n + f)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    dx = ctx.to_device(x); db = ctx.empty(f)
+    D.act_bias_grad(ctx, dx, None, dx, None, db=db)
+    ref = x.astype(np.float64).sum(0)
+    assert np.abs(db.numpy() - ref).max() < 1e-5 * np.abs(x).sum(0).max()
+    first = db.numpy().copy()
+    D.act_bias_grad(ctx, dx, None, dx, None, db=db)
+    assert np.array_equal(db.numpy(), first)          # fixed-order reduction: run-to-run identical
+
+
 def test_graph_prep_coo_to_csr_norm_transpose(ctx):
     from gcnx import _lib, synth
     from gcnx.device import DeviceCSR
