@@ -1,0 +1,368 @@
+// GCNConv as ONE launch in the small-feature regime (F <= 128: config 2's E. coli batches).
+//
+// Spektral's GCNConv.call (the layer behind gcn.py:334) computes A (X W): a dense product, then the aggregation --
+// two launches here (gemm.hip, spmm.hip) with the [N, F] intermediate written and read back in between, each ~12-15 us
+// at N = 22 576 where neither is anywhere near a throughput bound.  (A X) W is the same product; in that order a
+// workgroup can own 32 rows end to end:
+//     gather + weight the neighbours' rows of X  ->  S tile [32, K] in LDS  ->  MFMA with W  ->  bias / ReLU  ->  out
+// and the backward of the layer above the pool runs the same way with the transposed operator:
+//     gather [Y2 > 0] rows, scale by the graph's dPooled row (pool' and ReLU' folded: dZ2 is what is being gathered)
+//     ->  T tile  ->  MFMA with W2^T  ->  [Y1 > 0] mask  ->  dZ1, plus the tile's column sums (db1 partials).
+// S = A X is saved by the forward: the weight gradient of this order is dW = S^T dZ (gcnx_gemm_dw2).
+//
+// Shape of a workgroup: 512 threads, 32 rows.
+//   gather   K / 4 lanes per row (float4 each), 64 / (K / 4) rows per wave instruction, every row group walks its two
+//            rows together, four entries each per trip: eight 16-byte loads in flight per lane.  Range-checked buffer
+//            loads: slots past a row's end fetch nothing.  The tile's CSR entries are staged in LDS first.
+//   product  v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate): wave w owns output columns [16w, 16w + 16)
+//            of both 16-row halves.  Its slice of W sits in REGISTERS (K / 4 per lane, loaded straight from L2 in the
+//            B-operand layout: lane l holds k = 4 kk + (l >> 4), column l & 15) -- no LDS image of W, so a workgroup
+//            needs only the 17 KiB tile and three fit a CU.  A operand: S[row = l & 15][k] from the row-major tile,
+//            row stride K + 4 floats (4 row + k spreads the 64 lanes over the 64 banks).
+//   epilogue the 32 x NC result goes back through the tile (now dead) so that global stores are whole 512-byte rows.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kFRows = 32;        // rows per workgroup
+constexpr int kFCap = 1024;       // CSR entries of a tile staged in LDS (the rest is read from global memory)
+constexpr int kFLd = 132;         // tile row stride in floats (128 + 4)
+
+struct FusedArgs {
+  const int32_t* rowptr; const int32_t* colidx; const float* vals;
+  const float* x; int64_t ldx;           // the gathered matrix [n, K]
+  int32_t n;
+  const float* w; int32_t ldw;           // forward: W [K, nc];  backward: W2 [nc, K]
+  int32_t nc;                            // output columns (multiple of 16, <= 128)
+  const float* bias; int act;            // forward epilogue
+  float* s; int64_t lds;                 // forward: S = A X (may be NULL)
+  float* out; int64_t ldo;
+  // backward only
+  const int32_t* node_graph; const int32_t* gp; const float* dp; int64_t lddp; int avg;
+  const float* mask; int64_t ldmask;     // Y1 (ReLU output of the layer below)
+  float* dz2; int64_t lddz2;             // dZ2 rows of this tile (may be NULL)
+  float* colpart;                        // [tiles, nc] column sums of what was written to out (may be NULL)
+};
+
+__device__ __forceinline__ float4 fbuf4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const f32x4v r = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+  return make_float4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ float4 f4fma(float v, float4 h, float4 a) {
+  const f32x2 w = {v, v};
+  const f32x2 lo = __builtin_elementwise_fma(w, f32x2{h.x, h.y}, f32x2{a.x, a.y});
+  const f32x2 hi = __builtin_elementwise_fma(w, f32x2{h.z, h.w}, f32x2{a.z, a.w});
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+// [a > 0] of a saved ReLU output (a >= 0): see f4_step in spmm.hip
+__device__ __forceinline__ float4 f4step(float4 a) {
+  const f32x2 big = {0x1p127f, 0x1p127f};
+  f32x2 lo = {a.x, a.y}, hi = {a.z, a.w}, t0, t1;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(lo), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(hi), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(t0), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(t1), "v"(big));
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+
+template <int K, bool WEIGHTED, bool BWD>
+__global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
+  constexpr int LPR = K / 4;                 // lanes per gathered row
+  constexpr int GW = 64 / LPR;               // row groups per wave
+  constexpr int NG = 8 * GW;                 // row groups per workgroup
+  constexpr int RPG = NG >= kFRows ? 1 : kFRows / NG;   // rows per group (2 at K = 128)
+  constexpr int U = 4;                       // entries per row per trip
+  static_assert(K == 32 || K == 64 || K == 128, "gather width");
+  __shared__ __attribute__((aligned(16))) float tile[kFRows][kFLd];
+  __shared__ __attribute__((aligned(16))) int32_t s_col[kFCap];        // later: the per-wave column sums [8][128]
+  __shared__ float s_val[WEIGHTED ? kFCap : 1];
+  __shared__ int32_t s_rp[kFRows + 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = gridDim.x;
+  const int t = gcnx_xcd_remap(blockIdx.x, ntiles);
+  const int r0 = t * kFRows, nr = min(p.n - r0, kFRows);
+  if (tid <= nr) s_rp[tid] = p.rowptr[r0 + tid];
+  const int e0 = p.rowptr[r0], e1 = p.rowptr[r0 + nr];
+  const int staged = min(e1 - e0, kFCap);
+  for (int i = tid; i < staged; i += 512) {
+    s_col[i] = p.colidx[e0 + i];
+    if (WEIGHTED) s_val[i] = p.vals[e0 + i];
+  }
+  // ---- gather ------------------------------------------------------------------------------------------------
+  const int gid = wave * GW + lane / LPR, sub = lane % LPR;
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((unsigned)p.n * (unsigned)p.ldx * 4u), 0x00020000);
+  const unsigned ld4 = (unsigned)p.ldx * 4u;
+  // backward: the row's dPooled vector (pool', with 1 / n_g for the average pool) and its own [Y2 > 0] row (dZ2)
+  float4 dscale[RPG];
+  if (BWD) {
+#pragma unroll
+    for (int j = 0; j < RPG; ++j) {
+      const int r = gid + j * NG;
+      dscale[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nr && gid < kFRows) {
+        const int g = p.node_graph[r0 + r];
+        float4 d = *reinterpret_cast<const float4*>(p.dp + (int64_t)g * p.lddp + sub * 4);
+        if (p.avg) {
+          const float sc = 1.0f / (float)(p.gp[g + 1] - p.gp[g]);
+          d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+        }
+        dscale[j] = d;
+      }
+    }
+  }
+  __syncthreads();
+  float4 acc[RPG];
+  int ea[RPG], eb[RPG];
+  int len = 0;
+#pragma unroll
+  for (int j = 0; j < RPG; ++j) {
+    const int r = gid + j * NG;
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = r < nr && gid < kFRows;
+    ea[j] = live ? s_rp[r] - e0 : 0;
+    eb[j] = live ? s_rp[r + 1] - e0 : 0;
+    len = max(len, eb[j] - ea[j]);
+  }
+  // fast part: the entries staged in LDS.  Branch-free on purpose -- a load inside a branch makes hipcc close the trip
+  // with s_waitcnt vmcnt(0), i.e. the eight row loads would complete one after the other.
+  for (int tt = 0; __builtin_amdgcn_ballot_w64(tt < len) != 0; tt += U) {
+    float4 hv[RPG][U];
+    float wv[RPG][U];
+#pragma unroll
+    for (int j = 0; j < RPG; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = ea[j] + tt + u;
+        const bool ok = e < min(eb[j], kFCap);
+        const int ec_ = min(e, kFCap - 1);
+        const int c = s_col[ec_];
+        const float v = WEIGHTED ? s_val[ec_] : 1.0f;
+        wv[j][u] = ok ? v : 0.f;
+        hv[j][u] = fbuf4(xr, ok ? (unsigned)c * ld4 + (unsigned)sub * 16u : 0xFFFFFFF0u);
+      }
+#pragma unroll
+    for (int j = 0; j < RPG; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[j] = f4fma(wv[j][u], BWD ? f4step(hv[j][u]) : hv[j][u], acc[j]);
+  }
+  if (e1 - e0 > kFCap) {       // uniform per workgroup, rare: entries beyond the staged ones, one at a time from global memory
+#pragma unroll
+    for (int j = 0; j < RPG; ++j)
+      for (int e = max(ea[j], kFCap); e < eb[j]; ++e) {
+        const int c = p.colidx[e0 + e];
+        const float v = WEIGHTED ? p.vals[e0 + e] : 1.0f;
+        const float4 h = fbuf4(xr, (unsigned)c * ld4 + (unsigned)sub * 16u);
+        acc[j] = f4fma(v, BWD ? f4step(h) : h, acc[j]);
+      }
+  }
+  float4 own[RPG];             // backward: the row's own [Y2 > 0] row (dZ2 is written for the rows of the tile)
+  if (BWD && p.dz2) {
+#pragma unroll
+    for (int j = 0; j < RPG; ++j) {
+      const int r = gid + j * NG;
+      own[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nr && gid < kFRows) own[j] = *reinterpret_cast<const float4*>(p.x + (int64_t)(r0 + r) * p.ldx + sub * 4);
+    }
+  }
+  // ---- this wave's slice of W, in the MFMA B layout; in flight while the tile is written -------------------------
+  const int c16 = lane & 15, kq = lane >> 4;
+  const bool wave_on = 16 * wave < p.nc;
+  float wreg[K / 4];
+  if (wave_on) {
+#pragma unroll
+    for (int kk = 0; kk < K / 4; ++kk)
+      wreg[kk] = BWD ? p.w[(int64_t)(16 * wave + c16) * p.ldw + 4 * kk + kq]
+                     : p.w[(int64_t)(4 * kk + kq) * p.ldw + 16 * wave + c16];
+  }
+  if (gid < kFRows) {
+#pragma unroll
+    for (int j = 0; j < RPG; ++j) {
+      const int r = gid + j * NG;
+      float4 a = acc[j];
+      if (BWD) {
+        a.x *= dscale[j].x; a.y *= dscale[j].y; a.z *= dscale[j].z; a.w *= dscale[j].w;
+        if (p.dz2 && r < nr) {
+          const float4 m = f4step(own[j]);
+          *reinterpret_cast<float4*>(p.dz2 + (int64_t)(r0 + r) * p.lddz2 + sub * 4) =
+              make_float4(m.x * dscale[j].x, m.y * dscale[j].y, m.z * dscale[j].z, m.w * dscale[j].w);
+        }
+      } else if (p.s && r < nr) {
+        *reinterpret_cast<float4*>(p.s + (int64_t)(r0 + r) * p.lds + sub * 4) = a;
+      }
+      *reinterpret_cast<float4*>(&tile[r][sub * 4]) = a;      // rows past the end hold zeros
+    }
+  }
+  __syncthreads();
+  // ---- product ---------------------------------------------------------------------------------------------------
+  const int er = tid >> 5, ec = (tid & 31) * 4;      // epilogue: this thread's rows er, er + 16 and its 4 columns
+  const bool col_on = ec < p.nc;
+  float4 mk0 = make_float4(1.f, 1.f, 1.f, 1.f), mk1 = mk0;
+  if (BWD && col_on) {                               // the ReLU mask rows, in flight under the MFMAs
+    if (er < nr) mk0 = *reinterpret_cast<const float4*>(p.mask + (int64_t)(r0 + er) * p.ldmask + ec);
+    if (er + 16 < nr) mk1 = *reinterpret_cast<const float4*>(p.mask + (int64_t)(r0 + er + 16) * p.ldmask + ec);
+  }
+  f32x4v c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+  if (wave_on) {
+#pragma unroll
+    for (int kk = 0; kk < K / 4; ++kk) {
+      const float a0 = tile[c16][4 * kk + kq];
+      const float a1 = tile[16 + c16][4 * kk + kq];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[kk], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[kk], c1, 0, 0, 0);
+    }
+  }
+  __syncthreads();                                   // every wave is done reading the tile
+  if (wave_on) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tile[4 * kq + r][16 * wave + c16] = c0[r];
+      tile[16 + 4 * kq + r][16 * wave + c16] = c1[r];
+    }
+  }
+  __syncthreads();
+  // ---- epilogue --------------------------------------------------------------------------------------------------
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (col_on) {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!BWD && p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + ec);
+    auto fin = [&](float4 v, float4 mk) {
+      if (BWD) {
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      } else {
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (p.act == GCNX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      return v;
+    };
+    if (er < nr) {
+      v0 = fin(*reinterpret_cast<const float4*>(&tile[er][ec]), mk0);
+      *reinterpret_cast<float4*>(p.out + (int64_t)(r0 + er) * p.ldo + ec) = v0;
+    }
+    if (er + 16 < nr) {
+      v1 = fin(*reinterpret_cast<const float4*>(&tile[er + 16][ec]), mk1);
+      *reinterpret_cast<float4*>(p.out + (int64_t)(r0 + er + 16) * p.ldo + ec) = v1;
+    }
+  }
+  if (BWD && p.colpart) {
+    // column sums of the tile in a fixed order: rows (er, er + 16), then the wave's two row pairs, then the 8 waves
+    float4 cs = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
+    cs.x += __shfl_xor(cs.x, 32); cs.y += __shfl_xor(cs.y, 32); cs.z += __shfl_xor(cs.z, 32); cs.w += __shfl_xor(cs.w, 32);
+    float4* wsum = reinterpret_cast<float4*>(s_col);          // [8][32] float4: the staged entries are dead
+    if (lane < 32) wsum[wave * 32 + lane] = cs;
+    __syncthreads();
+    if (tid < 32 && col_on) {
+      float4 a = wsum[tid];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) { const float4 o = wsum[w * 32 + tid]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+      *reinterpret_cast<float4*>(p.colpart + (int64_t)t * p.nc + ec) = a;
+    }
+  }
+}
+
+template <bool BWD>
+int launch_fused(gcnx_ctx* ctx, const FusedArgs& a, int k) {
+  const int tiles = gcnx_cdiv(a.n, kFRows);
+#define GCNX_FUSED_LAUNCH(K_)                                                                                         \
+  do {                                                                                                                \
+    if (a.vals) hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, true, BWD>), dim3(tiles), dim3(512), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, false, BWD>), dim3(tiles), dim3(512), 0, ctx->stream, a);      \
+  } while (0)
+  if (k == 128) GCNX_FUSED_LAUNCH(128);
+  else if (k == 64) GCNX_FUSED_LAUNCH(64);
+  else GCNX_FUSED_LAUNCH(32);
+#undef GCNX_FUSED_LAUNCH
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+inline bool fal16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool fused_shape_ok(int64_t n, int32_t k, int32_t nc, int64_t ldx) {
+  return n > 0 && (k == 32 || k == 64 || k == 128) && nc >= 16 && nc <= 128 && nc % 16 == 0 && ldx >= k && ldx % 4 == 0 &&
+         (uint64_t)n * (uint64_t)ldx * 4u < 0xFFFFFFF0ull;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcnx_gcn_conv_fused_ok(int64_t n, int32_t fi, int32_t fo, int64_t ldx) { return fused_shape_ok(n, fi, fo, ldx) ? 1 : 0; }
+
+int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* x,
+                      int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo, const float* bias, int act, float* s,
+                      int64_t lds, float* out, int64_t ldo) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gcn_conv_fwd: negative size");
+  GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_gcn_conv_fwd: activation %d not supported here", act);
+  if (n == 0 || fo == 0) return GCNX_OK;
+  if (!fused_shape_ok(n, fi, fo, ldx))
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_fwd: needs fi in {32, 64, 128}, fo a multiple of 16 up to 128 and "
+                     "n * ldx * 4 < 2^32 (got n=%d fi=%d fo=%d): use gcnx_gemm + gcnx_spmm_csr", n, fi, fo);
+  GCNX_REQUIRE(ctx, rowptr && colidx && x && w && out, "gcnx_gcn_conv_fwd: NULL pointer");
+  GCNX_REQUIRE(ctx, ldo >= fo && ldo % 4 == 0 && fal16(x) && fal16(out) && (!bias || fal16(bias)) &&
+                        (!s || (lds >= fi && lds % 4 == 0 && fal16(s))),
+               "gcnx_gcn_conv_fwd: operands must be 16-byte aligned with leading dimensions in multiples of 4 floats");
+  GCNX_REQUIRE(ctx, x != out && x != s, "gcnx_gcn_conv_fwd: in-place aggregation is not possible");
+  FusedArgs a{};
+  a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.x = x; a.ldx = ldx; a.n = n; a.w = w; a.ldw = fo; a.nc = fo;
+  a.bias = bias; a.act = act; a.s = s; a.lds = lds; a.out = out; a.ldo = ldo;
+  return launch_fused<false>(ctx, a, fi);
+}
+
+int64_t gcnx_gcn_conv_bwd_scratch_floats(int64_t n, int32_t f1) { return n <= 0 || f1 <= 0 ? 0 : (int64_t)gcnx_cdiv(n, kFRows) * f1; }
+
+int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* vals_t,
+                           const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
+                           const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
+                           const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
+                           float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending) {
+  GCNX_CHECK_CTX(ctx);
+  if (pending) *pending = gcnx_pending_reduce{nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr};
+  GCNX_REQUIRE(ctx, n >= 0 && f1 >= 0 && f2 >= 0 && b >= 0, "gcnx_gcn_conv_bwd_pool: negative size");
+  GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
+               "gcnx_gcn_conv_bwd_pool: pool mode %d has no folded form", mode);
+  if (n == 0 || f1 == 0) {
+    if (db1 && f1 > 0) GCNX_HIP(ctx, hipMemsetAsync(db1, 0, (size_t)f1 * 4, ctx->stream));
+    return GCNX_OK;
+  }
+  if (!fused_shape_ok(n, f2, f1, ldy2))
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_bwd_pool: needs f2 in {32, 64, 128}, f1 a multiple of 16 up to 128 "
+                     "and n * ldy2 * 4 < 2^32 (got n=%d f1=%d f2=%d)", n, f1, f2);
+  GCNX_REQUIRE(ctx, b > 0 && rowptr_t && colidx_t && y2 && node_graph && graph_ptr && dpooled && w2 && y1 && dz1,
+               "gcnx_gcn_conv_bwd_pool: NULL pointer");
+  GCNX_REQUIRE(ctx, lddp >= f2 && lddp % 4 == 0 && ldy1 >= f1 && ldy1 % 4 == 0 && lddz1 >= f1 && lddz1 % 4 == 0 && fal16(y2) &&
+                        fal16(dpooled) && fal16(y1) && fal16(dz1) && (!dz2 || (fal16(dz2) && lddz2 >= f2 && lddz2 % 4 == 0)),
+               "gcnx_gcn_conv_bwd_pool: operands must be 16-byte aligned with leading dimensions in multiples of 4 floats");
+  GCNX_REQUIRE(ctx, y2 != dz1 && y2 != dz2 && y1 != dz1, "gcnx_gcn_conv_bwd_pool: outputs must not alias the saved activations");
+  const int64_t tiles = gcnx_cdiv(n, kFRows);
+  float* colpart = nullptr;
+  bool defer = false;
+  if (db1) {
+    GCNX_REQUIRE(ctx, fal16(db1) && f1 % 4 == 0, "gcnx_gcn_conv_bwd_pool: db1 must be 16-byte aligned");
+    defer = pending && scratch && fal16(scratch) && scratch_floats >= tiles * f1 && tiles <= 4096;
+    if (defer) colpart = scratch;
+    else {
+      int rc = gcnx_ws_reserve(ctx, gcnx_colsum_partials_ws(tiles, f1));
+      if (rc) return rc;
+      colpart = (float*)ctx->ws;
+    }
+  }
+  FusedArgs a{};
+  a.rowptr = rowptr_t; a.colidx = colidx_t; a.vals = vals_t; a.x = y2; a.ldx = ldy2; a.n = n; a.w = w2; a.ldw = f2; a.nc = f1;
+  a.out = dz1; a.ldo = lddz1; a.node_graph = node_graph; a.gp = graph_ptr; a.dp = dpooled; a.lddp = lddp;
+  a.avg = mode == GCNX_POOL_AVG ? 1 : 0; a.mask = y1; a.ldmask = ldy1; a.dz2 = dz2; a.lddz2 = lddz2; a.colpart = colpart;
+  int rc = launch_fused<true>(ctx, a, f2);
+  if (rc) return rc;
+  if (db1) {
+    if (defer) *pending = gcnx_pending_reduce{colpart, tiles, f1, db1, nullptr, 0, 0, nullptr};
+    else return gcnx_colsum_partials(ctx, tiles, f1, db1);
+  }
+  return GCNX_OK;
+}
+
+}  // extern "C"

@@ -305,6 +305,24 @@ __global__ __launch_bounds__(256) void gemm_f32_duo_kernel(GemmJob dx, GemmJob d
   }
 }
 
+// Two weight gradients X^T dH over the same rows in one launch (gcnx_gemm_dw2): workgroups [0, n_a) are the split-K
+// tiles of job a, the rest those of job b.
+__global__ __launch_bounds__(256) void gemm_f32_dw2_kernel(GemmJob ja, GemmJob jb, int n_a) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  int bid = blockIdx.x;                      // uniform per workgroup
+  if (bid < n_a) {
+    const int bx = bid % ja.gx, t = bid / ja.gx;
+    gemm_f32_tile<false, false>(ja.a, ja.lda, ja.b, ja.ldb, ja.c, ja.ldc, ja.M, ja.Nc, ja.K, ja.kchunk, ja.ep, ja.vec_a,
+                                ja.vec_b, bx, t % ja.gy, t / ja.gy, ja.gz, As, Bs);
+  } else {
+    bid -= n_a;
+    const int bx = bid % jb.gx, t = bid / jb.gx;
+    gemm_f32_tile<false, false>(jb.a, jb.lda, jb.b, jb.ldb, jb.c, jb.ldc, jb.M, jb.Nc, jb.K, jb.kchunk, jb.ep, jb.vec_a,
+                                jb.vec_b, bx, t % jb.gy, t / jb.gy, jb.gz, As, Bs);
+  }
+}
+
 // Second stage of the deterministic split-K: out[i] = sum_s part[s][i].  Block = 64 outputs x 4
 // split groups; each group sums its splits in ascending order, the 4 group sums are combined in
 // a fixed order -- the result does not depend on scheduling.
@@ -1028,6 +1046,84 @@ int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh
   const int n_s = gcnx_cdiv(total, 64), n_o = gcnx_cdiv(n_params, 256);
   hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
                      total, nsplit, total, n_s, params, grads, (int64_t)(dw - grads), n_params, lr, pd);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha, int64_t lddha, float* dwa, int32_t fia,
+                  int32_t foa, const float* xb, int64_t ldxb, const float* dhb, int64_t lddhb, float* dwb, int32_t fib,
+                  int32_t fob, int64_t n, int prec, float* params, float* grads, int64_t n_params, float lr,
+                  const gcnx_pending_reduce* pending) {
+  GCNX_CHECK_CTX(ctx);
+  if (pending && !pending->colpart && !pending->slabs) pending = nullptr;
+  GCNX_REQUIRE(ctx, n >= 0 && fia >= 0 && foa >= 0 && fib >= 0 && fob >= 0 && n_params >= 0, "gcnx_gemm_dw2: negative size");
+  GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dw2: unknown precision %d", prec);
+  const int64_t ta = (int64_t)fia * foa, tb = (int64_t)fib * fob;
+  GCNX_REQUIRE(ctx, (ta == 0 || dwa) && (tb == 0 || dwb), "gcnx_gemm_dw2: NULL gradient pointer");
+  if (params) {
+    GCNX_REQUIRE(ctx, grads != nullptr, "gcnx_gemm_dw2: params without grads");
+    GCNX_REQUIRE(ctx, (ta == 0 || (dwa >= grads && dwa + ta <= grads + n_params)) &&
+                          (tb == 0 || (dwb >= grads && dwb + tb <= grads + n_params)),
+                 "gcnx_gemm_dw2: both gradients must lie inside the flat gradient buffer");
+    GCNX_REQUIRE(ctx, !pending || !pending->colpart || (pending->cout >= grads && pending->cout + pending->cf <= grads + n_params &&
+                                                        pending->cf % 4 == 0 && al16(pending->cout)),
+                 "gcnx_gemm_dw2: the pending column sums must land (16-byte aligned) inside the flat gradient buffer");
+  }
+  int nsplit = 1;
+  int64_t kchunk = 0;
+  const bool shapes_ok = prec == GCNX_PREC_F32 && n > 0 && ta > 0 && tb > 0 && foa % 4 == 0 && fob % 4 == 0 &&
+                         (!pending || !pending->slabs);
+  if (shapes_ok) {
+    const int tiles = gcnx_cdiv(fia, BM) * gcnx_cdiv(foa, BN) + gcnx_cdiv(fib, BM) * gcnx_cdiv(fob, BN);
+    nsplit = (int)((4LL * ctx->num_cus + tiles - 1) / tiles);   // ~4 workgroups per CU over both products
+    const int64_t ksteps = (n + BK - 1) / BK;
+    if (nsplit > ksteps / kMinSliceSteps) nsplit = (int)(ksteps / kMinSliceSteps);
+    if (nsplit < 1) nsplit = 1;
+    kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
+    nsplit = (int)((n + kchunk - 1) / kchunk);
+  }
+  if (!shapes_ok || nsplit <= 1) {   // bf16 precisions, empty or short inputs: the separate calls
+    int rc = flush_pending(ctx, pending);
+    if (rc) return rc;
+    rc = gcnx_gemm_dw(ctx, xa, ldxa, dha, lddha, dwa, n, fia, foa, prec);
+    if (rc) return rc;
+    rc = gcnx_gemm_dw(ctx, xb, ldxb, dhb, lddhb, dwb, n, fib, fob, prec);
+    if (rc) return rc;
+    return params ? gcnx_sgd(ctx, params, grads, n_params, lr) : GCNX_OK;
+  }
+  GCNX_REQUIRE(ctx, xa && dha && xb && dhb, "gcnx_gemm_dw2: NULL pointer");
+  GCNX_REQUIRE(ctx, ldxa >= fia && lddha >= foa && ldxb >= fib && lddhb >= fob, "gcnx_gemm_dw2: leading dimension too small");
+  const size_t slab_a = ((size_t)nsplit * ta + 63) & ~(size_t)63;
+  int rc = gcnx_ws_reserve(ctx, (slab_a + (size_t)nsplit * tb) * sizeof(float));
+  if (rc) return rc;
+  float* sa = (float*)ctx->ws;
+  float* sb = sa + slab_a;
+  const Epilogue ep{nullptr, nullptr, nullptr, 0, GCNX_ACT_NONE, 0, 1, nullptr};
+  GemmJob ja{xa, ldxa, dha, lddha, sa, (int64_t)foa, (int64_t)fia, foa, n, kchunk, ep,
+             al16(xa) && ldxa % 4 == 0, al16(dha) && lddha % 4 == 0, gcnx_cdiv(foa, BN), gcnx_cdiv(fia, BM), nsplit};
+  GemmJob jb{xb, ldxb, dhb, lddhb, sb, (int64_t)fob, (int64_t)fib, fob, n, kchunk, ep,
+             al16(xb) && ldxb % 4 == 0, al16(dhb) && lddhb % 4 == 0, gcnx_cdiv(fob, BN), gcnx_cdiv(fib, BM), nsplit};
+  const int n_a = ja.gx * ja.gy * ja.gz, n_b = jb.gx * jb.gy * jb.gz;
+  hipLaunchKernelGGL(gemm_f32_dw2_kernel, dim3(n_a + n_b), dim3(256), 0, ctx->stream, ja, jb, n_a);
+  GCNX_LAUNCH_OK(ctx);
+  if (params) {
+    SgdPending pd{nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0, 0};
+    if (pending && pending->colpart) { pd.cpart = pending->colpart; pd.crows = pending->crows; pd.cf = pending->cf;
+                                       pd.coff = pending->cout - grads; pd.n_pc = gcnx_cdiv(pending->cf, 8); }
+    pd.slabs = sb; pd.total = tb; pd.nsplit = nsplit; pd.soff = dwb - grads; pd.n_ps = gcnx_cdiv(tb, 64);
+    const int n_s = gcnx_cdiv(ta, 64), n_o = gcnx_cdiv(n_params, 256);
+    hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)sa,
+                       ta, nsplit, ta, n_s, params, grads, (int64_t)(dwa - grads), n_params, lr, pd);
+    GCNX_LAUNCH_OK(ctx);
+    return GCNX_OK;
+  }
+  // gradients only: [pending column sums | slabs a] in one launch, slabs b in another
+  const int n_c = pending && pending->colpart ? gcnx_cdiv(pending->cf, 8) : 0;
+  hipLaunchKernelGGL(reduce_duo_kernel, dim3(n_c + gcnx_cdiv(ta, 64)), dim3(256), 0, ctx->stream,
+                     n_c ? pending->colpart : (const float*)nullptr, n_c ? pending->crows : (int64_t)0, n_c ? pending->cf : 0,
+                     n_c ? pending->cout : (float*)nullptr, n_c, (const float*)sa, ta, nsplit, dwa, ta);
+  GCNX_LAUNCH_OK(ctx);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(tb, 64)), dim3(256), 0, ctx->stream, (const float*)sb, tb, nsplit, dwb, tb);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

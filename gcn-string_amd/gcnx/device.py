@@ -359,6 +359,13 @@ class Segments:
         self.ctx, self.n_graphs, self.n, self.host, self.dev = ctx, len(gp) - 1, int(gp[-1]), gp, dev
         return self
 
+    @property
+    def ids(self):
+        """The DisjointLoader id vector i[N] (graph of every row) on the device, built on first use."""
+        if getattr(self, "_ids", None) is None:
+            self._ids = self.ctx.to_device(np.repeat(np.arange(self.n_graphs, dtype=np.int32), np.diff(self.host)), np.int32)
+        return self._ids
+
     @classmethod
     def from_ids(cls, ctx, i, n_graphs=None):
         i = np.asarray(i)
@@ -436,6 +443,55 @@ def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum"):
     ctx._ck(ctx.lib.gcnx_spmm_csr_pool_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y), y.ld, seg.dev.ptr,
                                            seg.n_graphs, _p(dpooled), dpooled.ld, _p(out), out.ld, n, f, L.POOLS[mode]))
     return out
+
+
+def gcn_conv_fused_ok(ctx, n, fi, fo, ldx=None):
+    """True if gcn_conv_fwd / gcn_conv_bwd_pool serve these shapes (gcnx_gcn_conv_fused_ok)."""
+    return bool(ctx.lib.gcnx_gcn_conv_fused_ok(int(n), int(fi), int(fo), int(ldx if ldx is not None else fi)))
+
+
+def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None):
+    """out = act((A x) w + bias) in one launch; s (optional) receives A x (gcnx_gcn_conv_fwd)."""
+    n, fi = x.shape
+    fo = w.shape[1]
+    assert a.n == n and w.shape[0] == fi and w.contiguous and out.shape == (n, fo) and (s is None or s.shape == (n, fi))
+    ctx._ck(ctx.lib.gcnx_gcn_conv_fwd(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(x), x.ld, n, fi, _p(w), fo, _p(bias),
+                                      L.ACTS[act], _p(s), s.ld if s is not None else 0, _p(out), out.ld))
+    return out
+
+
+def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mode="sum", scratch=None):
+    """dz2 = pool'(dpooled) * [y2 > 0], dz1 = ((A^T dz2) w2^T) * [y1 > 0], db1 = column sums of dz1 -- one launch
+    (gcnx_gcn_conv_bwd_pool).  With ``scratch`` the db1 reduction is left pending: returns the PendingReduce for
+    gemm_dw2 (all zeros when nothing is pending)."""
+    n, f2 = y2.shape
+    f1 = w2.shape[0]
+    assert at.n == n and w2.shape == (f1, f2) and w2.contiguous and y1.shape == (n, f1) and dz1.shape == (n, f1)
+    assert dpooled.shape == (seg.n_graphs, f2) and (dz2 is None or dz2.shape == (n, f2))
+    pend = L.PendingReduce()
+    ctx._ck(ctx.lib.gcnx_gcn_conv_bwd_pool(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y2), y2.ld, seg.ids.ptr,
+                                           seg.dev.ptr, seg.n_graphs, _p(dpooled), dpooled.ld, L.POOLS[mode], n, f2, _p(w2), f1,
+                                           _p(y1), y1.ld, _p(dz2), dz2.ld if dz2 is not None else 0, _p(dz1), dz1.ld, _p(db1),
+                                           _p(scratch), scratch.size if scratch is not None else 0,
+                                           C.byref(pend) if scratch is not None else None))
+    return pend
+
+
+def gcn_conv_bwd_scratch_floats(ctx, n, f1):
+    return int(ctx.lib.gcnx_gcn_conv_bwd_scratch_floats(int(n), int(f1)))
+
+
+def gemm_dw2(ctx, xa, dha, dwa, xb, dhb, dwb, prec="f32", params=None, grads=None, lr=0.0, pending=None):
+    """dwa = xa^T dha and dwb = xb^T dhb in one launch; with params / grads (the flat buffers both gradients are
+    views of) the reduction also applies the SGD step and finishes ``pending`` (gcnx_gemm_dw2)."""
+    n, fia = xa.shape
+    foa = dha.shape[1]
+    fib, fob = xb.shape[1], dhb.shape[1]
+    assert xb.shape[0] == n and dha.shape[0] == n and dhb.shape[0] == n and dwa.shape == (fia, foa) and dwb.shape == (fib, fob)
+    ctx._ck(ctx.lib.gcnx_gemm_dw2(ctx.h, _p(xa), xa.ld, _p(dha), dha.ld, _p(dwa), fia, foa, _p(xb), xb.ld, _p(dhb), dhb.ld,
+                                  _p(dwb), fib, fob, n, L.PRECS[prec], _p(params), _p(grads),
+                                  params.size if params is not None else (grads.size if grads is not None else 0), float(lr),
+                                  C.byref(pending) if pending is not None else None))
 
 
 def pool_bwd_colsum(ctx, seg, dpooled, y, db, mode="sum"):

@@ -190,6 +190,8 @@ class GCN2(_GraphRunner):
         self._bufs = {"key": key}
         for k in ("h", "y1", "y2", "dz", "h2", "dz2"):          # h2 / dz2: the side section still reads h / dz
             self._bufs[k] = v(k, n, h)
+        if self._fused(batch):                                  # one-launch layers: S1 = A X, S2 = A Y1 (operands of dW)
+            self._bufs["s1"], self._bufs["s2"] = v("s1", n, self.f_in), v("s2", n, h)
         for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
             self._bufs[k] = v(k, b, w)
         self._bufs["arg"] = v("arg", b, h, np.int32) if self.pool == "max" else None
@@ -198,10 +200,17 @@ class GCN2(_GraphRunner):
     # ---- the call sequences --------------------------------------------------------------------
     def _forward(self, batch, bufs, with_loss, denom):
         ctx, p, prec = self.ctx, self.p, self.prec
-        D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
-        D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
-        D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
-        D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
+        if self._fused(batch):
+            # small-feature regime: each GCNConv is one launch, evaluated as (A X) W (gcnx_gcn_conv_fwd); A X is kept
+            # for the weight gradient when a backward pass follows
+            keep = with_loss == "grads"
+            D.gcn_conv_fwd(ctx, batch.a, batch.x, p["w1"], p["b1"], bufs["y1"], act="relu", s=bufs["s1"] if keep else None)
+            D.gcn_conv_fwd(ctx, batch.a, bufs["y1"], p["w2"], p["b2"], bufs["y2"], act="relu", s=bufs["s2"] if keep else None)
+        else:
+            D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
+            D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
+            D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
+            D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
         # Global pool, then Dense(softmax) + CCE + accuracy + the head gradients in one launch; with few graphs the
         # head also combines the pool's row-slice partial sums (gcnx_pool_dense_softmax_cce)
         head = dict(mode=self.pool, argmax=bufs["arg"])
@@ -230,6 +239,18 @@ class GCN2(_GraphRunner):
         # Batches without a tile plan (the latency regime): dZ2 = pool'(dPooled) * [Y2 > 0] is never materialised --
         # the aggregation gathers the mask from Y2 and scales by the row's dPooled vector, db2 counts the mask.
         fold = self._fold(batch)
+        if self._fused(batch):
+            # pool' + ReLU' + A^T + W2^T + ReLU' in one launch (dZ2 and dZ1 out, db1 partials pending; db2 came out of
+            # the head), then both weight gradients -- dW1 = S1^T dZ1, dW2 = S2^T dZ2 -- and the update in the last two
+            pend = D.gcn_conv_bwd_pool(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], p["w2"], bufs["y1"], bufs["dz"],
+                                       bufs["dz2"], db1=g["b1"], mode=self.pool, scratch=self._defer_scratch(batch))
+            if lr is None:
+                D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec=prec,
+                           grads=self.flat_g.flat(0, self.n_params), pending=pend)
+                return False
+            D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec=prec, params=self.flat_p,
+                       grads=self.flat_g.flat(0, self.n_params), lr=lr, pending=pend)
+            return True
         if fold:
             D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool)   # dH2 = A^T dZ2
         else:
@@ -263,7 +284,8 @@ class GCN2(_GraphRunner):
 
     def _defer_scratch(self, batch):
         """Device buffer that holds the deferred partial results of layer 2's dense backward (grow-only)."""
-        need = D.dense_bwd_scratch_floats(self.ctx, batch.n, self.hidden, self.hidden)
+        need = max(D.dense_bwd_scratch_floats(self.ctx, batch.n, self.hidden, self.hidden),
+                   D.gcn_conv_bwd_scratch_floats(self.ctx, batch.n, self.hidden))
         cur = getattr(self, "_defer_buf", None)
         if cur is None or cur.size < need:
             self._defer_buf = self.ctx.empty(max(need, 4))
@@ -274,6 +296,14 @@ class GCN2(_GraphRunner):
         the backward aggregation and db2 into the head."""
         return (batch.a.plan is None and self.pool in ("sum", "avg") and self.hidden % 4 == 0
                 and os.environ.get("GCNX_FOLD", "1") != "0" and int(os.environ.get("GCNX_SIDE", "1")) == 1)
+
+    def _fused(self, batch):
+        """The small-feature regime (config 2): every GCNConv and the backward from the pool down to dZ1 are single
+        launches (csrc/fused.hip).  Needs the folded backward's conditions, fp32 products and F, H in {32, 64, 128}."""
+        return (self.built and self._fold(batch) and self.prec == "f32" and os.environ.get("GCNX_FUSED", "1") != "0"
+                and os.environ.get("GCNX_DUO", "1") != "0" and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
+                and D.gcn_conv_fused_ok(self.ctx, batch.n, self.f_in, self.hidden)
+                and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))
 
     def _backward_knob(self, batch, bufs, side):
         """The same backward with individual side sections switched off (GCNX_SIDE bits; measurement only)."""

@@ -36,6 +36,7 @@ for rnd in range(args.rounds):
         if "GCNX_SPMM_KERNEL" not in os.environ:
             ctx.set_tuning("spmm_slab", 0)
             if slab in ("rows", "tile", "pipe"): ctx.set_tuning("spmm_kernel", slab)
+            elif slab[0] == "t": ctx.set_tuning("spmm_slab", int(slab[1:])); ctx.set_tuning("spmm_kernel", "auto")   # tiers, tall graphs' row chunks in slabs
             elif slab != "0": ctx.set_tuning("spmm_slab", int(slab)); ctx.set_tuning("spmm_kernel", "rows")
             else: ctx.set_tuning("spmm_kernel", "auto")
         for _ in range(3): D.spmm(ctx, a, h, bias, out, act="relu")

@@ -851,3 +851,93 @@ def test_sgd_and_graph_capture_replay(ctx):
     assert t1.elapsed_ms_since(t0) >= 0.0
     info = ctx.info()
     assert info["arch"].startswith("gfx950") and info["cus"] >= 200
+
+
+# ---- GCNConv as one launch (csrc/fused.hip) -------------------------------------------------------------------------
+
+@pytest.mark.parametrize("fi,fo", [(128, 128), (64, 128), (32, 16), (128, 48), (64, 64)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gcn_conv_fused_forward(ctx, fi, fo, weighted):
+    """gcnx_gcn_conv_fwd = relu((A X) W + b) and S = A X against the float64 oracle chain dense -> aggregation
+    (GCNConv.call order A (X W)); ragged last tile (N % 32 != 0), rows with more than 4 entries per trip."""
+    from gcnx import device as D, synth
+    o = O()
+    hb = synth.ecoli_batch(3, fi, seed=fi + fo)
+    assert hb.n % 32 != 0
+    a, vals = _csr(ctx, hb, weighted)
+    rng = np.random.default_rng(fi * fo)
+    w = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
+    bias = rng.standard_normal(fo).astype(np.float32)
+    assert D.gcn_conv_fused_ok(ctx, hb.n, fi, fo)
+    out = ctx.empty((hb.n, fo)); s = ctx.empty((hb.n, fi))
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), ctx.to_device(bias), out, act="relu", s=s)
+    ref = _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64), bias, True)
+    assert rel_err(out.numpy(), ref) < TIGHT
+    assert rel_err(s.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), None, out, act=None)      # inference surface: no S
+    assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64))) < TIGHT
+
+
+def test_gcn_conv_fused_long_rows_and_refusals(ctx):
+    """A hub row with 4096 entries overflows the tile's LDS staging (1024 entries): the overflow path; widths the
+    kernel does not serve are refused with GCNX_ERR_UNSUPPORTED."""
+    from gcnx import device as D, synth
+    from gcnx._lib import GcnxError
+    hb = synth.power_law_batch(n_graphs=1, graph_size=8192, f=64, seed=3)
+    a, vals = _csr(ctx, hb, True)
+    rng = np.random.default_rng(1)
+    w = (rng.standard_normal((64, 32)) / 8).astype(np.float32)
+    out = ctx.empty((hb.n, 32))
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), None, out, act="relu")
+    assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64), None, True)) < TIGHT
+    assert not D.gcn_conv_fused_ok(ctx, hb.n, 96, 32) and not D.gcn_conv_fused_ok(ctx, hb.n, 64, 256)
+    with pytest.raises(GcnxError, match="gcnx_gemm \\+ gcnx_spmm_csr"):
+        D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.zeros((64, 256)), None, ctx.empty((hb.n, 256)))
+
+
+@pytest.mark.parametrize("f1,f2", [(128, 128), (64, 128), (128, 32)])
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode):
+    """gcnx_gcn_conv_bwd_pool + gcnx_gemm_dw2 against the oracle's unfused chain: pool' -> ReLU' -> A^T -> W2^T -> ReLU',
+    column sums, the two weight gradients and the SGD step; non-symmetric values so that the transpose matters; the db1
+    reduction both immediate and pending."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    o = O()
+    hb = synth.ecoli_batch(4, f2, seed=f1 + f2)
+    n, b = hb.n, len(hb.graph_ptr) - 1
+    rng = np.random.default_rng(17)
+    vals = (rng.random(len(hb.colidx)) + 0.25).astype(np.float32)
+    y2 = np.maximum(rng.standard_normal((n, f2), dtype=np.float32), 0)
+    y1 = np.maximum(rng.standard_normal((n, f1), dtype=np.float32), 0)
+    dp = rng.standard_normal((b, f2), dtype=np.float32)
+    w2 = (rng.standard_normal((f1, f2)) / np.sqrt(f1)).astype(np.float32)
+    s1 = rng.standard_normal((n, 32), dtype=np.float32); s2 = rng.standard_normal((n, f1), dtype=np.float32)
+    rdz2 = o.global_pool_bwd(dp.astype(np.float64), hb.graph_ptr, n, mode, None) * (y2 > 0)
+    rdh = o.spmm_csr_T(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals.astype(np.float64), rdz2)
+    rdz1 = (rdh @ w2.astype(np.float64).T) * (y1 > 0)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr, symmetric=False)
+    seg = Segments(ctx, hb.graph_ptr)
+    dz2 = ctx.empty((n, f2)); dz1 = ctx.empty((n, f1)); db1 = ctx.empty(f1)
+    args = (ctx, a.transpose(), ctx.to_device(y2), seg, ctx.to_device(dp), ctx.to_device(w2), ctx.to_device(y1), dz2, dz1)
+    pend = D.gcn_conv_bwd_pool(*args, db1=db1, mode=mode)
+    assert not pend.colpart                                              # no scratch: db1 is final
+    assert rel_err(dz2.numpy(), rdz2) < TIGHT and rel_err(dz1.numpy(), rdz1) < TIGHT
+    assert rel_err(db1.numpy(), rdz1.sum(0)) < TIGHT
+    # pending form + both weight gradients + SGD in the flat buffers
+    n_par = 32 * f1 + f1 * f2 + f1
+    params = ctx.to_device(rng.standard_normal(n_par, dtype=np.float32)); grads = ctx.zeros(n_par)
+    p0 = params.numpy().copy()
+    gw1, gw2, gb1 = grads.flat(0, 32 * f1, (32, f1)), grads.flat(32 * f1, f1 * f2, (f1, f2)), grads.flat(32 * f1 + f1 * f2, f1)
+    scratch = ctx.empty(D.gcn_conv_bwd_scratch_floats(ctx, n, f1))
+    pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch)
+    assert pend.colpart
+    D.gemm_dw2(ctx, ctx.to_device(s1), dz1, gw1, ctx.to_device(s2), dz2, gw2, params=params, grads=grads, lr=0.05, pending=pend)
+    rg = np.concatenate([(s1.astype(np.float64).T @ rdz1).ravel(), (s2.astype(np.float64).T @ rdz2).ravel(), rdz1.sum(0)])
+    assert rel_err(grads.numpy(), rg) < TIGHT
+    assert rel_err(params.numpy(), p0 - 0.05 * rg) < TIGHT
+    # gradients only (the multi-GPU path: all-reduce first, update later)
+    grads.fill_zero()
+    pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch)
+    D.gemm_dw2(ctx, ctx.to_device(s1), dz1, gw1, ctx.to_device(s2), dz2, gw2, grads=grads, pending=pend)
+    assert rel_err(grads.numpy(), rg) < TIGHT
