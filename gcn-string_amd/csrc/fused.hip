@@ -19,7 +19,7 @@
 //            B-operand layout: lane l holds k = 4 kk + (l >> 4), column l & 15) -- no LDS image of W, so a workgroup
 //            needs only the 17 KiB tile and three fit a CU.  A operand: S[row = l & 15][k] from the row-major tile,
 //            row stride K + 4 floats (4 row + k spreads the 64 lanes over the 64 banks).
-//   epilogue the 32 x NC result goes back through the tile (now dead) so that global stores are whole 512-byte rows.
+//   epilogue in registers (bias / ReLU, or the ReLU mask and the tile's column sums): no barrier after the last MFMA.
 #include "common.h"
 
 namespace {
@@ -29,7 +29,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kFRows = 32;        // rows per workgroup
 constexpr int kFCap = 1024;       // CSR entries of a tile staged in LDS (the rest is read from global memory)
-constexpr int kFLd = 132;         // tile row stride in floats (128 + 4)
 
 struct FusedArgs {
   const int32_t* rowptr; const int32_t* colidx; const float* vals;
@@ -39,6 +38,9 @@ struct FusedArgs {
   int32_t nc;                            // output columns (multiple of 16, <= 128)
   const float* bias; int act;            // forward epilogue
   float* s; int64_t lds;                 // forward: S = A X (may be NULL)
+  float* wt_out;                         // forward: W^T [nc, K] written by workgroup 0 (may be NULL) -- the layout the
+                                         // backward launch wants its weight operand in
+  int w_t;                               // backward: w already holds W2^T [K, nc] (that by-product)
   float* out; int64_t ldo;
   // backward only
   const int32_t* node_graph; const int32_t* gp; const float* dp; int64_t lddp; int avg;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   constexpr int RPG = NG >= kFRows ? 1 : kFRows / NG;   // rows per group (2 at K = 128)
   constexpr int U = 4;                       // entries per row per trip
   static_assert(K == 32 || K == 64 || K == 128, "gather width");
-  __shared__ __attribute__((aligned(16))) float tile[kFRows][kFLd];
-  __shared__ __attribute__((aligned(16))) int32_t s_col[kFCap];        // later: the per-wave column sums [8][128]
+  __shared__ __attribute__((aligned(16))) float tile[kFRows][K + 4];   // row stride K + 4: see the A-operand read
+  __shared__ int32_t s_col[kFCap];
   __shared__ float s_val[WEIGHTED ? kFCap : 1];
   __shared__ int32_t s_rp[kFRows + 1];
 
@@ -97,22 +99,13 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   const __amdgpu_buffer_rsrc_t xr =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((unsigned)p.n * (unsigned)p.ldx * 4u), 0x00020000);
   const unsigned ld4 = (unsigned)p.ldx * 4u;
-  // backward: the row's dPooled vector (pool', with 1 / n_g for the average pool) and its own [Y2 > 0] row (dZ2)
-  float4 dscale[RPG];
+  // backward: the graph of each row (its dPooled vector is fetched after the gather: fewer live registers in the loop)
+  int grow[RPG];
   if (BWD) {
 #pragma unroll
     for (int j = 0; j < RPG; ++j) {
       const int r = gid + j * NG;
-      dscale[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nr && gid < kFRows) {
-        const int g = p.node_graph[r0 + r];
-        float4 d = *reinterpret_cast<const float4*>(p.dp + (int64_t)g * p.lddp + sub * 4);
-        if (p.avg) {
-          const float sc = 1.0f / (float)(p.gp[g + 1] - p.gp[g]);
-          d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
-        }
-        dscale[j] = d;
-      }
+      grow[j] = (r < nr && gid < kFRows) ? p.node_graph[r0 + r] : -1;
     }
   }
   __syncthreads();
@@ -160,13 +153,21 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
         acc[j] = f4fma(v, BWD ? f4step(h) : h, acc[j]);
       }
   }
-  float4 own[RPG];             // backward: the row's own [Y2 > 0] row (dZ2 is written for the rows of the tile)
-  if (BWD && p.dz2) {
+  float4 own[RPG], dscale[RPG];   // backward: pool'(dPooled) of the row's graph, and the row's own [Y2 > 0] row (dZ2 out)
+  if (BWD) {
 #pragma unroll
     for (int j = 0; j < RPG; ++j) {
       const int r = gid + j * NG;
-      own[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nr && gid < kFRows) own[j] = *reinterpret_cast<const float4*>(p.x + (int64_t)(r0 + r) * p.ldx + sub * 4);
+      own[j] = dscale[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow[j] >= 0) {
+        float4 d = *reinterpret_cast<const float4*>(p.dp + (int64_t)grow[j] * p.lddp + sub * 4);
+        if (p.avg) {
+          const float sc = 1.0f / (float)(p.gp[grow[j] + 1] - p.gp[grow[j]]);
+          d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+        }
+        dscale[j] = d;
+        if (p.dz2) own[j] = *reinterpret_cast<const float4*>(p.x + (int64_t)(r0 + r) * p.ldx + sub * 4);
+      }
     }
   }
   // ---- this wave's slice of W, in the MFMA B layout; in flight while the tile is written -------------------------
@@ -176,8 +177,13 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   if (wave_on) {
 #pragma unroll
     for (int kk = 0; kk < K / 4; ++kk)
-      wreg[kk] = BWD ? p.w[(int64_t)(16 * wave + c16) * p.ldw + 4 * kk + kq]
-                     : p.w[(int64_t)(4 * kk + kq) * p.ldw + 16 * wave + c16];
+      wreg[kk] = (BWD && !p.w_t) ? p.w[(int64_t)(16 * wave + c16) * p.ldw + 4 * kk + kq]     // W2 [nc, K]: strided
+                                 : p.w[(int64_t)(4 * kk + kq) * p.ldw + 16 * wave + c16];    // [K, nc]: 64-byte row pieces
+    if (!BWD && p.wt_out && (int)blockIdx.x < K / 4) {   // W^T, dealt over the first K / 4 workgroups (uniform tests: wreg
+#pragma unroll                                          // stays in registers)
+      for (int kk = 0; kk < K / 4; ++kk)
+        if (kk % ntiles == (int)blockIdx.x) p.wt_out[(int64_t)(16 * wave + c16) * K + 4 * kk + kq] = wreg[kk];
+    }
   }
   if (gid < kFRows) {
 #pragma unroll
@@ -198,69 +204,43 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
     }
   }
   __syncthreads();
-  // ---- product ---------------------------------------------------------------------------------------------------
-  const int er = tid >> 5, ec = (tid & 31) * 4;      // epilogue: this thread's rows er, er + 16 and its 4 columns
-  const bool col_on = ec < p.nc;
-  float4 mk0 = make_float4(1.f, 1.f, 1.f, 1.f), mk1 = mk0;
-  if (BWD && col_on) {                               // the ReLU mask rows, in flight under the MFMAs
-    if (er < nr) mk0 = *reinterpret_cast<const float4*>(p.mask + (int64_t)(r0 + er) * p.ldmask + ec);
-    if (er + 16 < nr) mk1 = *reinterpret_cast<const float4*>(p.mask + (int64_t)(r0 + er + 16) * p.ldmask + ec);
+  // ---- product and epilogue, in registers: wave w owns output columns [16w, 16w + 16) of all 32 rows ---------------
+  // C layout of the 16 x 16 tile: column = lane & 15, rows 4 (lane >> 4) + reg.  A store instruction therefore
+  // writes 4 rows x 64 bytes -- narrower than a staged row-major epilogue would, but with no barrier and no LDS
+  // round trip behind the last MFMA; the column sums need no other wave.
+  if (!wave_on) return;
+  const int col = 16 * wave + c16;
+  float mk[8];
+  if (BWD) {                                          // the ReLU mask (saved Y1), in flight under the MFMAs
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = 16 * (r >> 2) + 4 * kq + (r & 3);
+      mk[r] = row < nr ? p.mask[(int64_t)(r0 + row) * p.ldmask + col] : 0.f;
+    }
   }
+  const float bcol = (!BWD && p.bias) ? p.bias[col] : 0.f;
   f32x4v c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-  if (wave_on) {
 #pragma unroll
-    for (int kk = 0; kk < K / 4; ++kk) {
-      const float a0 = tile[c16][4 * kk + kq];
-      const float a1 = tile[16 + c16][4 * kk + kq];
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[kk], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[kk], c1, 0, 0, 0);
-    }
+  for (int kk = 0; kk < K / 4; ++kk) {
+    const float a0 = tile[c16][4 * kk + kq];
+    const float a1 = tile[16 + c16][4 * kk + kq];
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[kk], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[kk], c1, 0, 0, 0);
   }
-  __syncthreads();                                   // every wave is done reading the tile
-  if (wave_on) {
+  float cs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      tile[4 * kq + r][16 * wave + c16] = c0[r];
-      tile[16 + 4 * kq + r][16 * wave + c16] = c1[r];
-    }
+  for (int r = 0; r < 8; ++r) {
+    const int row = 16 * (r >> 2) + 4 * kq + (r & 3);
+    float v = r < 4 ? c0[r & 3] : c1[r & 3];
+    if (BWD) v = mk[r] > 0.f ? v : 0.f;               // rows past the end: mask 0 (and an all-zero gathered row)
+    else { v += bcol; if (p.act == GCNX_ACT_RELU) v = fmaxf(v, 0.f); }
+    if (row < nr) p.out[(int64_t)(r0 + row) * p.ldo + col] = v;
+    cs += v;                                          // rows in ascending order within the lane
   }
-  __syncthreads();
-  // ---- epilogue --------------------------------------------------------------------------------------------------
-  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-  if (col_on) {
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!BWD && p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + ec);
-    auto fin = [&](float4 v, float4 mk) {
-      if (BWD) {
-        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-      } else {
-        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        if (p.act == GCNX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      }
-      return v;
-    };
-    if (er < nr) {
-      v0 = fin(*reinterpret_cast<const float4*>(&tile[er][ec]), mk0);
-      *reinterpret_cast<float4*>(p.out + (int64_t)(r0 + er) * p.ldo + ec) = v0;
-    }
-    if (er + 16 < nr) {
-      v1 = fin(*reinterpret_cast<const float4*>(&tile[er + 16][ec]), mk1);
-      *reinterpret_cast<float4*>(p.out + (int64_t)(r0 + er + 16) * p.ldo + ec) = v1;
-    }
-  }
-  if (BWD && p.colpart) {
-    // column sums of the tile in a fixed order: rows (er, er + 16), then the wave's two row pairs, then the 8 waves
-    float4 cs = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
-    cs.x += __shfl_xor(cs.x, 32); cs.y += __shfl_xor(cs.y, 32); cs.z += __shfl_xor(cs.z, 32); cs.w += __shfl_xor(cs.w, 32);
-    float4* wsum = reinterpret_cast<float4*>(s_col);          // [8][32] float4: the staged entries are dead
-    if (lane < 32) wsum[wave * 32 + lane] = cs;
-    __syncthreads();
-    if (tid < 32 && col_on) {
-      float4 a = wsum[tid];
-#pragma unroll
-      for (int w = 1; w < 8; ++w) { const float4 o = wsum[w * 32 + tid]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
-      *reinterpret_cast<float4*>(p.colpart + (int64_t)t * p.nc + ec) = a;
-    }
+  if (BWD && p.colpart) {                             // ... then the four row groups (lane >> 4) in a fixed tree
+    cs += __shfl_xor(cs, 16);
+    cs += __shfl_xor(cs, 32);
+    if (lane < 16) p.colpart[(int64_t)t * p.nc + col] = cs;
   }
 }
 
@@ -295,7 +275,7 @@ int gcnx_gcn_conv_fused_ok(int64_t n, int32_t fi, int32_t fo, int64_t ldx) { ret
 
 int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* x,
                       int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo, const float* bias, int act, float* s,
-                      int64_t lds, float* out, int64_t ldo) {
+                      int64_t lds, float* out, int64_t ldo, float* wt_out) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gcn_conv_fwd: negative size");
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_gcn_conv_fwd: activation %d not supported here", act);
@@ -310,7 +290,7 @@ int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colid
   GCNX_REQUIRE(ctx, x != out && x != s, "gcnx_gcn_conv_fwd: in-place aggregation is not possible");
   FusedArgs a{};
   a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.x = x; a.ldx = ldx; a.n = n; a.w = w; a.ldw = fo; a.nc = fo;
-  a.bias = bias; a.act = act; a.s = s; a.lds = lds; a.out = out; a.ldo = ldo;
+  a.bias = bias; a.act = act; a.s = s; a.lds = lds; a.out = out; a.ldo = ldo; a.wt_out = wt_out;
   return launch_fused<false>(ctx, a, fi);
 }
 
@@ -319,7 +299,7 @@ int64_t gcnx_gcn_conv_bwd_scratch_floats(int64_t n, int32_t f1) { return n <= 0 
 int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* vals_t,
                            const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
                            const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
-                           const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
+                           int w2_transposed, const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
                            float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending) {
   GCNX_CHECK_CTX(ctx);
   if (pending) *pending = gcnx_pending_reduce{nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr};
@@ -353,7 +333,7 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
     }
   }
   FusedArgs a{};
-  a.rowptr = rowptr_t; a.colidx = colidx_t; a.vals = vals_t; a.x = y2; a.ldx = ldy2; a.n = n; a.w = w2; a.ldw = f2; a.nc = f1;
+  a.rowptr = rowptr_t; a.colidx = colidx_t; a.vals = vals_t; a.x = y2; a.ldx = ldy2; a.n = n; a.w = w2; a.ldw = w2_transposed ? f1 : f2; a.w_t = w2_transposed ? 1 : 0; a.nc = f1;
   a.out = dz1; a.ldo = lddz1; a.node_graph = node_graph; a.gp = graph_ptr; a.dp = dpooled; a.lddp = lddp;
   a.avg = mode == GCNX_POOL_AVG ? 1 : 0; a.mask = y1; a.ldmask = ldy1; a.dz2 = dz2; a.lddz2 = lddz2; a.colpart = colpart;
   int rc = launch_fused<true>(ctx, a, f2);

@@ -192,6 +192,7 @@ class GCN2(_GraphRunner):
             self._bufs[k] = v(k, n, h)
         if self._fused(batch):                                  # one-launch layers: S1 = A X, S2 = A Y1 (operands of dW)
             self._bufs["s1"], self._bufs["s2"] = v("s1", n, self.f_in), v("s2", n, h)
+            self._bufs["w2t"] = v("w2t", h, h)                  # W2^T, a by-product of layer 2's forward launch
         for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
             self._bufs[k] = v(k, b, w)
         self._bufs["arg"] = v("arg", b, h, np.int32) if self.pool == "max" else None
@@ -205,7 +206,8 @@ class GCN2(_GraphRunner):
             # for the weight gradient when a backward pass follows
             keep = with_loss == "grads"
             D.gcn_conv_fwd(ctx, batch.a, batch.x, p["w1"], p["b1"], bufs["y1"], act="relu", s=bufs["s1"] if keep else None)
-            D.gcn_conv_fwd(ctx, batch.a, bufs["y1"], p["w2"], p["b2"], bufs["y2"], act="relu", s=bufs["s2"] if keep else None)
+            D.gcn_conv_fwd(ctx, batch.a, bufs["y1"], p["w2"], p["b2"], bufs["y2"], act="relu", s=bufs["s2"] if keep else None,
+                           wt=bufs["w2t"] if keep else None)
         else:
             D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
             D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
@@ -243,7 +245,8 @@ class GCN2(_GraphRunner):
             # pool' + ReLU' + A^T + W2^T + ReLU' in one launch (dZ2 and dZ1 out, db1 partials pending; db2 came out of
             # the head), then both weight gradients -- dW1 = S1^T dZ1, dW2 = S2^T dZ2 -- and the update in the last two
             pend = D.gcn_conv_bwd_pool(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], p["w2"], bufs["y1"], bufs["dz"],
-                                       bufs["dz2"], db1=g["b1"], mode=self.pool, scratch=self._defer_scratch(batch))
+                                       bufs["dz2"], db1=g["b1"], mode=self.pool, scratch=self._defer_scratch(batch),
+                                       w2t=bufs["w2t"])
             if lr is None:
                 D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec=prec,
                            grads=self.flat_g.flat(0, self.n_params), pending=pend)

@@ -360,16 +360,18 @@ GCNX_API int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const 
  * n * ldx * 4 < 2^32); the entry points return GCNX_ERR_UNSUPPORTED otherwise -- use the two-launch form then. */
 GCNX_API int gcnx_gcn_conv_fused_ok(int64_t n, int32_t fi, int32_t fo, int64_t ldx);
 /* out[n, fo] = act((A x) w + bias), A in CSR (vals NULL: all ones); s (may be NULL) receives S = A x [n, fi], the
- * operand of the weight gradient dW = S^T dZ (gcnx_gemm_dw2).  act: GCNX_ACT_NONE / GCNX_ACT_RELU. */
+ * operand of the weight gradient dW = S^T dZ (gcnx_gemm_dw2).  wt_out (may be NULL) receives w^T [fo, fi], the layout
+ * gcnx_gcn_conv_bwd_pool reads its weight operand fastest in.  act: GCNX_ACT_NONE / GCNX_ACT_RELU. */
 GCNX_API int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                       const float* x, int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo,
-                      const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo);
+                      const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out);
 /* Backward from the global pool down to the pre-activation gradient of the layer below, one launch:
  *   dZ2[j] = pool'(dpooled)[graph(j)] * [y2[j] > 0]                      (GlobalSumPool / GlobalAvgPool', ReLU')
  *   dz1    = ((A^T dZ2) w2^T) * [y1 > 0]                                 (aggregation', MatMul', ReLU' of layer 1)
  *   db1    = column sums of dz1                                          (BiasAddGrad)
  * rowptr_t / colidx_t / vals_t: A^T in CSR; node_graph: the DisjointLoader id vector i[n] (graph of every row);
- * w2 [f1, f2]; y2 [n, f2], y1 [n, f1]: the saved ReLU outputs.  dz2 (may be NULL) receives dZ2 [n, f2] (the operand
+ * w2 [f1, f2], or with w2_transposed != 0 its transpose [f2, f1] (the forward's wt_out: coalesced operand loads);
+ * y2 [n, f2], y1 [n, f1]: the saved ReLU outputs.  dz2 (may be NULL) receives dZ2 [n, f2] (the operand
  * of dW2 = S2^T dZ2).  db1 (may be NULL): with `pending` and a scratch of >= gcnx_gcn_conv_bwd_scratch_floats(n, f1)
  * floats the per-tile partial sums stay in scratch and *pending describes the reduction (gcnx_gemm_dw2 finishes it);
  * otherwise db1 is complete on return.  mode: GCNX_POOL_SUM / GCNX_POOL_AVG. */
@@ -377,7 +379,7 @@ GCNX_API int64_t gcnx_gcn_conv_bwd_scratch_floats(int64_t n, int32_t f1);
 GCNX_API int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* vals_t,
                       const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
                       const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
-                      const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
+                      int w2_transposed, const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
                       float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending);
 /* Two weight gradients in one launch, dwa = xa^T dha [fia, foa] and dwb = xb^T dhb [fib, fob] over the same n rows
  * (MatMul grads wrt the kernels, gcn.py:337), both inside the flat gradient buffer `grads`; with params != NULL the

@@ -1,6 +1,7 @@
-cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "spmm" 2>&1 | tail -5
-for k in pipe tile; do echo "== $k"; GCNX_SPMM_KERNEL=$k timeout -k 10 200 python scripts/spmm_bench.py --workload block1m --rounds 2 --iters 10 --slabs 0 2>&1 | tail -2; done
-export GCNX_LIB=$GRAFT_REPO_ROOT/scripts/variants/lib_tune.so
-GCNX_SPMM_STAMPS=1 GCNX_SPMM_KERNEL=pipe timeout -k 10 200 python scripts/spmm_bench.py --workload block1m --rounds 1 --iters 2 --slabs 0 2>&1 | tail -5
-for d in 1 2 4 7; do echo "== pipe DBG=$d"; GCNX_SPMM_DBG=$d GCNX_SPMM_KERNEL=pipe timeout -k 10 200 python scripts/spmm_bench.py --workload block1m --rounds 1 --iters 10 --slabs 0 2>&1 | tail -1; done
+#!/bin/bash
+# scratch: config-2 step time against the split-K chunk of gcnx_gemm_dw2
+for kc in 0 10 11 12 16 23 24; do
+  GCNX_DW2_KC=$kc python bench.py --allow-knobs --steps 300 --warmup 30 --cpu-seconds 0 --no-config3 > gpurun_out/kc.json 2>gpurun_out/kc.err || { tail -3 gpurun_out/kc.err; exit 1; }
+  python -c "
+import json; d=json.load(open('gpurun_out/kc.json')); print('kc', $kc, d['ms_per_step'], d['m1_median']['ms_per_step'])"
+done

@@ -869,8 +869,9 @@ def test_gcn_conv_fused_forward(ctx, fi, fo, weighted):
     w = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
     bias = rng.standard_normal(fo).astype(np.float32)
     assert D.gcn_conv_fused_ok(ctx, hb.n, fi, fo)
-    out = ctx.empty((hb.n, fo)); s = ctx.empty((hb.n, fi))
-    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), ctx.to_device(bias), out, act="relu", s=s)
+    out = ctx.empty((hb.n, fo)); s = ctx.empty((hb.n, fi)); wt = ctx.zeros((fo, fi))
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), ctx.to_device(bias), out, act="relu", s=s, wt=wt)
+    assert np.array_equal(wt.numpy(), w.T)                                # the transposed weight by-product
     ref = _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64), bias, True)
     assert rel_err(out.numpy(), ref) < TIGHT
     assert rel_err(s.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT
@@ -924,6 +925,9 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode):
     assert not pend.colpart                                              # no scratch: db1 is final
     assert rel_err(dz2.numpy(), rdz2) < TIGHT and rel_err(dz1.numpy(), rdz1) < TIGHT
     assert rel_err(db1.numpy(), rdz1.sum(0)) < TIGHT
+    first = (dz2.numpy().copy(), dz1.numpy().copy(), db1.numpy().copy())
+    D.gcn_conv_bwd_pool(*args, db1=db1, mode=mode, w2t=ctx.to_device(np.ascontiguousarray(w2.T)))   # weight operand pre-transposed
+    assert all(np.array_equal(x, y) for x, y in zip(first, (dz2.numpy(), dz1.numpy(), db1.numpy())))
     # pending form + both weight gradients + SGD in the flat buffers
     n_par = 32 * f1 + f1 * f2 + f1
     params = ctx.to_device(rng.standard_normal(n_par, dtype=np.float32)); grads = ctx.zeros(n_par)
