@@ -47,6 +47,7 @@ struct FusedArgs {
   const float* mask; int64_t ldmask;     // Y1 (ReLU output of the layer below)
   float* dz2; int64_t lddz2;             // dZ2 rows of this tile (may be NULL)
   float* colpart;                        // [tiles, nc] column sums of what was written to out (may be NULL)
+  int dbg;                               // tuning builds: phase-ablation bits (1 no gather, 2 no MFMA, 4 no weight load)
 };
 
 __device__ __forceinline__ float4 fbuf4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
@@ -79,9 +80,17 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   constexpr int U = 4;                       // entries per row per trip
   static_assert(K == 32 || K == 64 || K == 128, "gather width");
   __shared__ __attribute__((aligned(16))) float tile[kFRows][K + 4];   // row stride K + 4: see the A-operand read
-  __shared__ int32_t s_col[kFCap];
-  __shared__ float s_val[WEIGHTED ? kFCap : 1];
+  // staged CSR entries: {byte offset of the gathered row = column * ldx * 4, weight}.  One multiply per entry here
+  // instead of one per lane and entry in the gather loop, and one ds_read_b64 for both: the gather loop is bound by VALU
+  // issue, not by memory (bit-image experiment: 2-byte loads in place of the 16-byte ones ran no faster), so every
+  // instruction per (lane, entry) shows.  2 U slack entries: the loop reads up to U - 1 past a row's end unclamped.
+  __shared__ __attribute__((aligned(8))) int2 s_ent[kFCap + 2 * U];
   __shared__ int32_t s_rp[kFRows + 1];
+#ifdef GCNX_TUNING
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = gridDim.x;
@@ -90,15 +99,19 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   if (tid <= nr) s_rp[tid] = p.rowptr[r0 + tid];
   const int e0 = p.rowptr[r0], e1 = p.rowptr[r0 + nr];
   const int staged = min(e1 - e0, kFCap);
-  for (int i = tid; i < staged; i += 512) {
-    s_col[i] = p.colidx[e0 + i];
-    if (WEIGHTED) s_val[i] = p.vals[e0 + i];
+  const unsigned ld4 = (unsigned)p.ldx * 4u;
+  for (int i = tid; i < staged + 2 * U; i += 512) {       // the slack entries carry weight 0: never NaN * 0
+    int2 en = make_int2(0, 0);
+    if (i < staged) {
+      en.x = (int)((unsigned)p.colidx[e0 + i] * ld4);
+      en.y = WEIGHTED ? __float_as_int(p.vals[e0 + i]) : 0x3f800000;
+    }
+    s_ent[i] = en;
   }
   // ---- gather ------------------------------------------------------------------------------------------------
   const int gid = wave * GW + lane / LPR, sub = lane % LPR;
   const __amdgpu_buffer_rsrc_t xr =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((unsigned)p.n * (unsigned)p.ldx * 4u), 0x00020000);
-  const unsigned ld4 = (unsigned)p.ldx * 4u;
   // backward: the graph of each row (its dPooled vector is fetched after the gather: fewer live registers in the loop)
   int grow[RPG];
   if (BWD) {
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   }
   __syncthreads();
   float4 acc[RPG];
-  int ea[RPG], eb[RPG];
+  int ea[RPG], eb[RPG], ebf[RPG];
   int len = 0;
 #pragma unroll
   for (int j = 0; j < RPG; ++j) {
@@ -119,25 +132,30 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
     const bool live = r < nr && gid < kFRows;
     ea[j] = live ? s_rp[r] - e0 : 0;
     eb[j] = live ? s_rp[r + 1] - e0 : 0;
-    len = max(len, eb[j] - ea[j]);
+    ebf[j] = min(eb[j], kFCap);                      // the staged part of the row ...
+    ea[j] = min(ea[j], kFCap);                       // ... (empty if the row starts past it)
+    len = max(len, ebf[j] - ea[j]);
   }
-  // fast part: the entries staged in LDS.  Branch-free on purpose -- a load inside a branch makes hipcc close the trip
-  // with s_waitcnt vmcnt(0), i.e. the eight row loads would complete one after the other.
+  if (dbg & 1) len = 0;
+  const unsigned sub16 = (unsigned)sub * 16u;
+  // Branch-free on purpose -- a load inside a branch makes hipcc close the trip with s_waitcnt vmcnt(0), i.e. the eight
+  // row loads would complete one after the other.  Slots past the row's end get an out-of-range offset (the buffer load
+  // returns zeros without a fetch); their weight is whatever the next row's entry holds -- finite -- times zero.
   for (int tt = 0; __builtin_amdgcn_ballot_w64(tt < len) != 0; tt += U) {
     float4 hv[RPG][U];
     float wv[RPG][U];
 #pragma unroll
-    for (int j = 0; j < RPG; ++j)
+    for (int j = 0; j < RPG; ++j) {
+      // a row that is done while others of the wave are not stays at its end: the reads stay inside the slack
+      const int eb_ = min(ea[j] + tt, ebf[j]);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = ea[j] + tt + u;
-        const bool ok = e < min(eb[j], kFCap);
-        const int ec_ = min(e, kFCap - 1);
-        const int c = s_col[ec_];
-        const float v = WEIGHTED ? s_val[ec_] : 1.0f;
-        wv[j][u] = ok ? v : 0.f;
-        hv[j][u] = fbuf4(xr, ok ? (unsigned)c * ld4 + (unsigned)sub * 16u : 0xFFFFFFF0u);
+        const int e = eb_ + u;
+        const int2 en = s_ent[e];
+        wv[j][u] = __int_as_float(en.y);
+        hv[j][u] = fbuf4(xr, e < ebf[j] ? (unsigned)en.x + sub16 : 0xFFFFFFF0u);
       }
+    }
 #pragma unroll
     for (int j = 0; j < RPG; ++j)
 #pragma unroll
@@ -146,10 +164,10 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   if (e1 - e0 > kFCap) {       // uniform per workgroup, rare: entries beyond the staged ones, one at a time from global memory
 #pragma unroll
     for (int j = 0; j < RPG; ++j)
-      for (int e = max(ea[j], kFCap); e < eb[j]; ++e) {
+      for (int e = max(eb[j] > 0 ? s_rp[gid + j * NG] - e0 : 0, kFCap); e < eb[j]; ++e) {   // (ea is clamped: the row's true start)
         const int c = p.colidx[e0 + e];
         const float v = WEIGHTED ? p.vals[e0 + e] : 1.0f;
-        const float4 h = fbuf4(xr, (unsigned)c * ld4 + (unsigned)sub * 16u);
+        const float4 h = fbuf4(xr, (unsigned)c * ld4 + sub16);
         acc[j] = f4fma(v, BWD ? f4step(h) : h, acc[j]);
       }
   }
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   const int c16 = lane & 15, kq = lane >> 4;
   const bool wave_on = 16 * wave < p.nc;
   float wreg[K / 4];
-  if (wave_on) {
+  if (wave_on && !(dbg & 4)) {
 #pragma unroll
     for (int kk = 0; kk < K / 4; ++kk)
       wreg[kk] = (BWD && !p.w_t) ? p.w[(int64_t)(16 * wave + c16) * p.ldw + 4 * kk + kq]     // W2 [nc, K]: strided
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   }
   const float bcol = (!BWD && p.bias) ? p.bias[col] : 0.f;
   f32x4v c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+  if (!(dbg & 2))
 #pragma unroll
   for (int kk = 0; kk < K / 4; ++kk) {
     const float a0 = tile[c16][4 * kk + kq];
@@ -245,7 +264,11 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
 }
 
 template <bool BWD>
-int launch_fused(gcnx_ctx* ctx, const FusedArgs& a, int k) {
+int launch_fused(gcnx_ctx* ctx, const FusedArgs& a_in, int k) {
+  FusedArgs a = a_in;
+#ifdef GCNX_TUNING
+  if (const char* e = getenv("GCNX_FUSED_DBG")) a.dbg = atoi(e);
+#endif
   const int tiles = gcnx_cdiv(a.n, kFRows);
 #define GCNX_FUSED_LAUNCH(K_)                                                                                         \
   do {                                                                                                                \

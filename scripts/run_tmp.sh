@@ -1,7 +1,9 @@
 #!/bin/bash
-# scratch: config-2 step time against the split-K chunk of gcnx_gemm_dw2
-for kc in 0 10 11 12 16 23 24; do
-  GCNX_DW2_KC=$kc python bench.py --allow-knobs --steps 300 --warmup 30 --cpu-seconds 0 --no-config3 > gpurun_out/kc.json 2>gpurun_out/kc.err || { tail -3 gpurun_out/kc.err; exit 1; }
-  python -c "
-import json; d=json.load(open('gpurun_out/kc.json')); print('kc', $kc, d['ms_per_step'], d['m1_median']['ms_per_step'])"
-done
+timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "fused" > gpurun_out/t.log 2>&1 || { tail -20 gpurun_out/t.log; exit 1; }
+tail -2 gpurun_out/t.log
+cp gcn-string_amd/gcnx/libgcnx.so /tmp/libgcnx_release.so
+cp scripts/variants/libgcnx_tuning.so gcn-string_amd/gcnx/libgcnx.so
+for d in 0 1; do echo "== dbg $d"; GCNX_FUSED_DBG=$d python scripts/fused_bench.py || exit 1; done
+cp /tmp/libgcnx_release.so gcn-string_amd/gcnx/libgcnx.so
+python bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-config3 > gpurun_out/b2.json 2>gpurun_out/b2.err && python -c "
+import json; d=json.load(open('gpurun_out/b2.json')); print(d['ms_per_step'], d['m1_median']['ms_per_step'])"
