@@ -156,6 +156,8 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
         hv[j][u] = fbuf4(xr, e < ebf[j] ? (unsigned)en.x + sub16 : 0xFFFFFFF0u);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);   // all eight loads go out before the first is consumed (hipcc otherwise reuses the
+                                         // destination registers of the first loads for the last and waits in between)
 #pragma unroll
     for (int j = 0; j < RPG; ++j)
 #pragma unroll
@@ -270,10 +272,14 @@ int launch_fused(gcnx_ctx* ctx, const FusedArgs& a_in, int k) {
   if (const char* e = getenv("GCNX_FUSED_DBG")) a.dbg = atoi(e);
 #endif
   const int tiles = gcnx_cdiv(a.n, kFRows);
+  int dyn = 0;                          // extra dynamic LDS: caps the resident workgroups per CU (tuning builds)
+#ifdef GCNX_TUNING
+  if (const char* e = getenv("GCNX_FUSED_LDS")) dyn = atoi(e);
+#endif
 #define GCNX_FUSED_LAUNCH(K_)                                                                                         \
   do {                                                                                                                \
-    if (a.vals) hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, true, BWD>), dim3(tiles), dim3(512), 0, ctx->stream, a); \
-    else hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, false, BWD>), dim3(tiles), dim3(512), 0, ctx->stream, a);      \
+    if (a.vals) hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, true, BWD>), dim3(tiles), dim3(512), dyn, ctx->stream, a); \
+    else hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, false, BWD>), dim3(tiles), dim3(512), dyn, ctx->stream, a);      \
   } while (0)
   if (k == 128) GCNX_FUSED_LAUNCH(128);
   else if (k == 64) GCNX_FUSED_LAUNCH(64);

@@ -12,6 +12,8 @@ All arithmetic runs in libgcnx (HIP); these classes only own buffers and sequenc
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import device as D
@@ -120,22 +122,41 @@ class GCNConv(Layer):
         if not self.built:
             self.build(x.ctx, x.shape[1])
         n = x.shape[0]
-        h = self._buf("h", (n, self.channels))
         y = out if out is not None else self._buf("y", (n, self.channels))
+        if self._one_launch(x, a):
+            # small-feature regime: (A x) W in one launch (csrc/fused.hip); S = A x is kept for dW = S^T dZ
+            s = self._buf("s", (n, x.shape[1]))
+            D.gcn_conv_fwd(self.ctx, a, x, self.params["kernel"], self.params.get("bias"), y, act=self.activation, s=s)
+            self._saved = (x, a, y, s)
+            return y
+        h = self._buf("h", (n, self.channels))
         D.gemm(self.ctx, x, self.params["kernel"], None, h, prec=self.prec)
         D.spmm(self.ctx, a, h, self.params.get("bias"), y, act=self.activation)
-        self._saved = (x, a, y)
+        self._saved = (x, a, y, None)
         return y
+
+    def _one_launch(self, x, a):
+        return (self.prec == "f32" and getattr(a, "plan", None) is None and x.contiguous and os.environ.get("GCNX_FUSED", "1") != "0"
+                and D.gcn_conv_fused_ok(self.ctx, x.shape[0], x.shape[1], self.channels, x.ld))
 
     def backward(self, dy, need_dx=True, dy_is_dz=False):
         """dy: gradient wrt the layer output.  dy_is_dz=True when the caller already applied the
         activation mask and filled grads['bias'] (fused upstream)."""
-        x, a, y = self._saved
+        x, a, y, s = self._saved
         n = x.shape[0]
         dz = dy
         if not dy_is_dz:
             dz = self._buf("dz", (n, self.channels))
             D.act_bias_grad(self.ctx, dy, y, dz, self.activation, db=self.grads.get("bias"))
+        if s is not None:                        # forward was (A x) W: dW = S^T dZ, dx = A^T (dZ W^T)
+            D.gemm_dw(self.ctx, s, dz, self.grads["kernel"], prec=self.prec)
+            if not need_dx:
+                return None
+            t = self._buf("t", (n, self.in_dim))
+            D.gemm_dx(self.ctx, dz, self.params["kernel"], t, prec=self.prec)
+            dx = self._buf("dx", (n, self.in_dim))
+            D.spmm(self.ctx, a.transpose(), t, None, dx)
+            return dx
         dh = self._buf("h", (n, self.channels))  # forward scratch is dead by now
         D.spmm(self.ctx, a.transpose(), dz, None, dh)
         D.gemm_dw(self.ctx, x, dh, self.grads["kernel"], prec=self.prec)

@@ -1,9 +1,9 @@
 #!/bin/bash
-timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "fused" > gpurun_out/t.log 2>&1 || { tail -20 gpurun_out/t.log; exit 1; }
-tail -2 gpurun_out/t.log
-cp gcn-string_amd/gcnx/libgcnx.so /tmp/libgcnx_release.so
-cp scripts/variants/libgcnx_tuning.so gcn-string_amd/gcnx/libgcnx.so
-for d in 0 1; do echo "== dbg $d"; GCNX_FUSED_DBG=$d python scripts/fused_bench.py || exit 1; done
-cp /tmp/libgcnx_release.so gcn-string_amd/gcnx/libgcnx.so
-python bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-config3 > gpurun_out/b2.json 2>gpurun_out/b2.err && python -c "
-import json; d=json.load(open('gpurun_out/b2.json')); print(d['ms_per_step'], d['m1_median']['ms_per_step'])"
+for sl in 64 128 192 256 384; do echo "== slices $sl"; GCNX_DW_SLICES=$sl python scripts/fused_bench.py | grep dw2; done
+GCNX_GEMM_STREAM=0 python scripts/fused_bench.py | grep dw2
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tr_f -- python3 scripts/fused_bench.py > gpurun_out/tr_f.log 2>&1; find gpurun_out/tr_f -name "*kernel_trace.csv" -delete; python3 - <<EOF2
+import csv,glob,os
+f=sorted(glob.glob("gpurun_out/tr_f/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
+for r in list(csv.DictReader(open(f)))[:10]:
+    print(r["Name"][:90].ljust(90), r["Calls"], r["AverageNs"])
+EOF2
