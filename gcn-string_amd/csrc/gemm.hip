@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //   [.., + n_pc)    fold a PENDING column-sum reduction (gcnx_dense_bwd_deferred) and update its parameters;
 //   [.., + n_ps)    fold a PENDING split-K reduction and update its parameters;
 //   the rest        p -= lr * g for every parameter outside those three intervals, 256 per workgroup.
+// params == NULL: the reductions only (gcnx_gemm_dw2 in a multi-GPU step: the all-reduce comes before the update).
 struct SgdPending {
   const float* cpart; int64_t crows; int32_t cf; int64_t coff;      // partial rows -> grads[coff, coff + cf)
   const float* slabs; int64_t total; int32_t nsplit; int64_t soff;  // slabs -> grads[soff, soff + total)
@@ -384,14 +385,14 @@ __global__ __launch_bounds__(256) void reduce_sgd_kernel(const float* __restrict
   if (bid < n_s) {
     const int64_t i = (int64_t)bid * 64 + (threadIdx.x & 63);
     const float g = splitk_sum(part, slab, nsplit, i, total, s);
-    if ((threadIdx.x >> 6) == 0 && i < total) { grads[off + i] = g; params[off + i] = params[off + i] - lr * g; }
+    if ((threadIdx.x >> 6) == 0 && i < total) { grads[off + i] = g; if (params) params[off + i] = params[off + i] - lr * g; }
     return;
   }
   bid -= n_s;
   if (bid < pd.n_pc) {
     gcnx_colpart_reduce_body(pd.cpart, pd.crows, pd.cf, grads + pd.coff, bid, s4);       // writes grads (all threads sync inside)
     const int cl = threadIdx.x & 1, c = bid * 8 + cl * 4;
-    if ((threadIdx.x >> 1) == 0 && c < pd.cf) {
+    if ((threadIdx.x >> 1) == 0 && c < pd.cf && params) {
       const float4 g = s4[0][cl];
       float* p = params + pd.coff + c;
       p[0] -= lr * g.x; p[1] -= lr * g.y; p[2] -= lr * g.z; p[3] -= lr * g.w;
@@ -402,12 +403,12 @@ __global__ __launch_bounds__(256) void reduce_sgd_kernel(const float* __restrict
   if (bid < pd.n_ps) {
     const int64_t i = (int64_t)bid * 64 + (threadIdx.x & 63);
     const float g = splitk_sum(pd.slabs, pd.total, pd.nsplit, i, pd.total, s);
-    if ((threadIdx.x >> 6) == 0 && i < pd.total) { grads[pd.soff + i] = g; params[pd.soff + i] = params[pd.soff + i] - lr * g; }
+    if ((threadIdx.x >> 6) == 0 && i < pd.total) { grads[pd.soff + i] = g; if (params) params[pd.soff + i] = params[pd.soff + i] - lr * g; }
     return;
   }
   bid -= pd.n_ps;
   const int64_t i = (int64_t)bid * 256 + threadIdx.x;
-  if (i >= n_params) return;
+  if (i >= n_params || !params) return;
   if (i >= off && i < off + total) return;
   if (pd.n_pc && i >= pd.coff && i < pd.coff + pd.cf) return;
   if (pd.n_ps && i >= pd.soff && i < pd.soff + pd.total) return;
@@ -1106,24 +1107,16 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
   const int n_a = ja.gx * ja.gy * ja.gz, n_b = jb.gx * jb.gy * jb.gz;
   hipLaunchKernelGGL(gemm_f32_dw2_kernel, dim3(n_a + n_b), dim3(256), 0, ctx->stream, ja, jb, n_a);
   GCNX_LAUNCH_OK(ctx);
-  if (params) {
-    SgdPending pd{nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0, 0};
-    if (pending && pending->colpart) { pd.cpart = pending->colpart; pd.crows = pending->crows; pd.cf = pending->cf;
-                                       pd.coff = pending->cout - grads; pd.n_pc = gcnx_cdiv(pending->cf, 8); }
-    pd.slabs = sb; pd.total = tb; pd.nsplit = nsplit; pd.soff = dwb - grads; pd.n_ps = gcnx_cdiv(tb, 64);
-    const int n_s = gcnx_cdiv(ta, 64), n_o = gcnx_cdiv(n_params, 256);
-    hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)sa,
-                       ta, nsplit, ta, n_s, params, grads, (int64_t)(dwa - grads), n_params, lr, pd);
-    GCNX_LAUNCH_OK(ctx);
-    return GCNX_OK;
-  }
-  // gradients only: [pending column sums | slabs a] in one launch, slabs b in another
-  const int n_c = pending && pending->colpart ? gcnx_cdiv(pending->cf, 8) : 0;
-  hipLaunchKernelGGL(reduce_duo_kernel, dim3(n_c + gcnx_cdiv(ta, 64)), dim3(256), 0, ctx->stream,
-                     n_c ? pending->colpart : (const float*)nullptr, n_c ? pending->crows : (int64_t)0, n_c ? pending->cf : 0,
-                     n_c ? pending->cout : (float*)nullptr, n_c, (const float*)sa, ta, nsplit, dwa, ta);
-  GCNX_LAUNCH_OK(ctx);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(tb, 64)), dim3(256), 0, ctx->stream, (const float*)sb, tb, nsplit, dwb, tb);
+  // one reduction launch either way: with params == NULL reduce_sgd_kernel only folds (offsets relative to `base`)
+  float* base = params ? grads : std::min(dwa, dwb);
+  if (!params && pending && pending->colpart) base = std::min(base, pending->cout);
+  SgdPending pd{nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0, 0};
+  if (pending && pending->colpart) { pd.cpart = pending->colpart; pd.crows = pending->crows; pd.cf = pending->cf;
+                                     pd.coff = pending->cout - base; pd.n_pc = gcnx_cdiv(pending->cf, 8); }
+  pd.slabs = sb; pd.total = tb; pd.nsplit = nsplit; pd.soff = dwb - base; pd.n_ps = gcnx_cdiv(tb, 64);
+  const int n_s = gcnx_cdiv(ta, 64), n_o = params ? gcnx_cdiv(n_params, 256) : 0;
+  hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)sa,
+                     ta, nsplit, ta, n_s, params, base, (int64_t)(dwa - base), n_params, lr, pd);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
