@@ -560,12 +560,23 @@ template <int THREADS, int FT> struct DuoShape {
     }                                                                                                          \
   }
 
-template <int THREADS, int FT, int LPR, bool WEIGHTED>
+// FOLD (gcnx_spmm_csr_pool_bwd with a plan): h is the saved ReLU output Y of the pooled layer and the kernel computes
+// A^T (pool'(dPooled) * [Y > 0]) -- the landed tile is turned into its 0 / 1 mask in place (one pass over the tile:
+// every element is gathered ~degree times, so masking it once is that much cheaper than masking every use), and the
+// graph's dPooled row (x 1 / n_g for the average pool) multiplies the finished sums where the bias is added otherwise.
+struct DuoFold {
+  const int32_t* gids;     // graph index of every entry of `graphs`
+  const float* dp;         // dPooled [b, f]
+  int64_t lddp;
+  int avg;
+};
+
+template <int THREADS, int FT, int LPR, bool WEIGHTED, bool FOLD = false>
 __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
     const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
     const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */,
-    int sg /* column slabs per unit */, int act, int nunits, int n, int dbg_rt) {
+    int sg /* column slabs per unit */, int act, int nunits, int n, int dbg_rt, DuoFold fo) {
 #ifdef GCNX_TUNING
   const int dbg = dbg_rt;                       // phase-ablation bits of a tuning build (results are wrong by design)
 #else
@@ -630,8 +641,17 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
       asm volatile("" : "+s"(ld32));            // opaque per step: the piece offsets are recomputed, not hoisted and spilled
       if (!(dbg & 1)) tile_dma32<FT / 4, THREADS, CAP * (FT / 4)>(lds, h + (int64_t)g.x * ldh + c0, ld32, g.y);
       if (s == 0) for (int i = tid; i <= g.y; i += THREADS) rp[i] = rowptr[g.x + i];
-      if (tid < FT) lbias[tid] = bias ? bias[c0 + tid] : 0.f;
+      if (FOLD) {
+        if (tid < FT) lbias[tid] = fo.dp[(int64_t)fo.gids[u / upg] * fo.lddp + c0 + tid] * (fo.avg ? 1.0f / (float)g.y : 1.0f);
+      } else {
+        if (tid < FT) lbias[tid] = bias ? bias[c0 + tid] : 0.f;
+      }
       __syncthreads();                          // the tile (and on s == 0 the index burst) has landed
+      if (FOLD) {                               // Y -> [Y > 0], in place
+        float4* t4 = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < g.y * (FT / 4); i += THREADS) t4[i] = f4_step(t4[i]);
+        __syncthreads();
+      }
 #pragma unroll
       for (int t = 0; t < NI; ++t) if (t * SPAN < g.y) {
         __builtin_amdgcn_sched_barrier(0);      // one row group at a time: bounded live ranges
@@ -662,8 +682,9 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
             const float4 bvj = *reinterpret_cast<const float4*>(lbias + (sub + LPR * (j ^ csw)) * 4);
-            float4 o = make_float4(acc[j][0][0] + bvj.x, acc[j][0][1] + bvj.y, acc[j][1][0] + bvj.z, acc[j][1][1] + bvj.w);
-            if (act == GCNX_ACT_RELU) {
+            float4 o = FOLD ? make_float4(acc[j][0][0] * bvj.x, acc[j][0][1] * bvj.y, acc[j][1][0] * bvj.z, acc[j][1][1] * bvj.w)
+                            : make_float4(acc[j][0][0] + bvj.x, acc[j][0][1] + bvj.y, acc[j][1][0] + bvj.z, acc[j][1][1] + bvj.w);
+            if (!FOLD && act == GCNX_ACT_RELU) {
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
             *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
@@ -994,13 +1015,17 @@ void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, 
 template <int THREADS, int FT, int LPR>
 int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-               const int2* graphs, int ngraphs) {
+               const int2* graphs, int ngraphs, const DuoFold* fold = nullptr) {
   constexpr int lds_bytes = DuoShape<THREADS, FT>::LDSF * 4;
   static bool attr_set = false;
   if (!attr_set) {
     GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
@@ -1021,12 +1046,20 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, cons
   const long long nunits = (long long)ngraphs * upg;
   if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
   const int grid = (int)(nunits < full ? nunits : full);
-  if (vals)
+  const DuoFold nofold{nullptr, nullptr, 0, 0};
+  if (fold) {
+    if (vals)
+      hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
+                         colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, *fold);
+    else
+      hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, false, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
+                         colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, *fold);
+  } else if (vals)
     hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
-                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg);
+                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, nofold);
   else
     hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, false>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
-                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg);
+                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, nofold);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -1042,6 +1075,7 @@ struct gcnx_spmm_plan {
   long long tile_rows = 0;
   int cap1 = kDuoCap32, cap2 = kSoloCap32;   // tier limits the lists were built for
   int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
+  int32_t* gids = nullptr;              // graph index of the n1 + n2 tile records (the folded backward's dPooled row)
   PipeItem* items = nullptr;            // pipelined kernel: graphs, tallest first: [n16 graphs of 625..1024 rows | n32 of <= 624]
   int nitems = 0, n16 = 0;
   int2* pipe_chunks = nullptr;          // ... and the 32-row chunks of the graphs too tall for it (> 1248 rows), for the rows kernel
@@ -1063,19 +1097,25 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
       GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     std::vector<int2> t1, t2, ch;
+    std::vector<std::pair<int, int>> by_row;       // (row0, graph index) of the tile graphs
     long long tile_rows = 0;
     int cap1 = kDuoCap32, cap2 = kSoloCap32;
     for (int g = 0; g < nblocks; ++g) {
       const int r0 = bp[g], ng = bp[g + 1] - bp[g];
       if (ng < 0) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g);
       if (ng == 0) continue;
-      if (ng <= cap1) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; }
-      else if (ng <= cap2) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; }
+      if (ng <= cap1) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
+      else if (ng <= cap2) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
       else for (int r = r0; r < r0 + ng; r += kRowsPerChunk) ch.push_back(make_int2(r, std::min(r + kRowsPerChunk, r0 + ng)));
     }
     auto by_size = [](const int2& x, const int2& y) { return x.y != y.y ? x.y > y.y : x.x < y.x; };
     std::sort(t1.begin(), t1.end(), by_size);
     std::sort(t2.begin(), t2.end(), by_size);
+    std::vector<int32_t> gids;                     // by_row is sorted by row0 (graphs come in row order): look the records up
+    gids.reserve(t1.size() + t2.size());
+    for (const std::vector<int2>* tv : {&t1, &t2})
+      for (const int2& rec : *tv)
+        gids.push_back(std::lower_bound(by_row.begin(), by_row.end(), std::make_pair(rec.x, 0))->second);
     gcnx_spmm_plan* p = new gcnx_spmm_plan();
     p->nblocks = nblocks;
     p->n1 = (int)t1.size(); p->n2 = (int)t2.size(); p->nchunks = (int)ch.size();
@@ -1093,6 +1133,13 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
       e = hipMemcpyAsync(p->dev, all.data(), total * sizeof(int2), hipMemcpyHostToDevice, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
+    }
+    if (!gids.empty()) {
+      hipError_t e = hipMalloc((void**)&p->gids, gids.size() * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMemcpyAsync(p->gids, gids.data(), gids.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { if (p->gids) (void)hipFree(p->gids); if (p->dev) (void)hipFree(p->dev); delete p;
+                             return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
     }
     // work items of the pipelined kernel: every graph of up to 1248 rows (costliest first); taller ones as 32-row chunks
     // for the rows kernel (list appended behind the items' own chunk list below)
@@ -1139,6 +1186,7 @@ int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
   if (!plan) return GCNX_OK;
   (void)hipStreamSynchronize(ctx->stream);
   if (plan->dev) (void)hipFree(plan->dev);
+  if (plan->gids) (void)hipFree(plan->gids);
   if (plan->items) (void)hipFree(plan->items);
   if (plan->pipe_chunks) (void)hipFree(plan->pipe_chunks);
   delete plan;
@@ -1260,7 +1308,8 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
 
 int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                            const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
-                           int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode) {
+                           int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode,
+                           const gcnx_spmm_plan* plan) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0 && b >= 0, "gcnx_spmm_csr_pool_bwd: negative size");
   GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
@@ -1275,8 +1324,30 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
                "gcnx_spmm_csr_pool_bwd: needs f and the leading dimensions in multiples of 4 floats and 16-byte aligned "
                "operands (use gcnx_segment_pool_bwd + gcnx_spmm_csr otherwise)");
   const FoldArgs fo{graph_ptr, dpooled, lddp, b, mode == GCNX_POOL_AVG ? 1 : 0};
-  dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo);
-  GCNX_LAUNCH_OK(ctx);
+  // with a plan (throughput regime): the tile kernels in their folded form, taller graphs' row chunks on the rows kernel
+  const bool tiles = plan && plan->nblocks == b && f % kSlab == 0 && ctx->knob_spmm_kernel != 1 &&
+                     ((long long)(plan->n1 + 2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus || ctx->knob_spmm_kernel >= 2);
+  if (!tiles) {
+    dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo);
+    GCNX_LAUNCH_OK(ctx);
+    return GCNX_OK;
+  }
+  if (plan->n1 > 0) {
+    const DuoFold df{plan->gids, dpooled, lddp, fo.avg};
+    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev, plan->n1, &df);
+    if (rc) return rc;
+  }
+  if (plan->n2 > 0) {
+    const DuoFold df{plan->gids + plan->n1, dpooled, lddp, fo.avg};
+    int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1,
+                                     plan->n2, &df);
+    if (rc) return rc;
+  }
+  if (plan->nchunks > 0) {
+    dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1 + plan->n2,
+                  plan->nchunks, &fo);
+    GCNX_LAUNCH_OK(ctx);
+  }
   return GCNX_OK;
 }
 

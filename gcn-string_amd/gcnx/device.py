@@ -441,7 +441,8 @@ def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum"):
     n, f = y.shape
     assert at.n == n and out.shape == (n, f) and dpooled.shape == (seg.n_graphs, f)
     ctx._ck(ctx.lib.gcnx_spmm_csr_pool_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y), y.ld, seg.dev.ptr,
-                                           seg.n_graphs, _p(dpooled), dpooled.ld, _p(out), out.ld, n, f, L.POOLS[mode]))
+                                           seg.n_graphs, _p(dpooled), dpooled.ld, _p(out), out.ld, n, f, L.POOLS[mode],
+                                           at.plan if at.n_blocks == seg.n_graphs else None))
     return out
 
 

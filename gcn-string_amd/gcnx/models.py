@@ -220,7 +220,8 @@ class GCN2(_GraphRunner):
             # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"],
-                                     db_relu=self.g["b2"] if self._fold(batch) else None, cce=self.cce_train, **head)
+                                     db_relu=self.g["b2"] if self._fold(batch) and batch.a.plan is None else None,
+                                     cce=self.cce_train, **head)
         elif with_loss:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, cce=self.cce_eval, **head)
@@ -238,8 +239,9 @@ class GCN2(_GraphRunner):
         side = int(os.environ.get("GCNX_SIDE", "1"))   # tuning knob: 0 = serial, 1 = one section, 7 = three sections
         if side != 1:
             return self._backward_knob(batch, bufs, 0 if side == 0 else 7)
-        # Batches without a tile plan (the latency regime): dZ2 = pool'(dPooled) * [Y2 > 0] is never materialised --
-        # the aggregation gathers the mask from Y2 and scales by the row's dPooled vector, db2 counts the mask.
+        # SUM / AVG pooling: dZ2 = pool'(dPooled) * [Y2 > 0] is never materialised -- the aggregation gathers the mask
+        # from Y2 (row gather in the latency regime, masked LDS tiles with a plan) and scales by the graph's dPooled
+        # vector; db2 counts the mask (in the head with few graphs, gcnx_pool_bwd_colsum on the side stream otherwise).
         fold = self._fold(batch)
         if self._fused(batch):
             # pool' + ReLU' + A^T + W2^T + ReLU' in one launch (dZ2 and dZ1 out, db1 partials pending; db2 came out of
@@ -259,7 +261,7 @@ class GCN2(_GraphRunner):
         else:
             D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
             D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                       # dH2 = A^T dZ2
-        if fold and os.environ.get("GCNX_DUO", "1") != "0":
+        if fold and batch.a.plan is None and os.environ.get("GCNX_DUO", "1") != "0":
             # db2 came out of the head, and dW2 shares dX's launch (gcnx_dense_bwd): one stream, no fork / join --
             # the second stream's signalling cost 25 us of a 194 us step
             if lr is None:
@@ -277,8 +279,10 @@ class GCN2(_GraphRunner):
                           pending=pend)
             return True
         with ctx.side():
-            if not fold:                                                       # (folded: db2 came out of the head)
+            if not fold:
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
+            elif batch.a.plan is not None:                                     # (folded, few graphs: db2 came out of the head)
+                D.pool_bwd_colsum(ctx, batch.seg, bufs["dpooled"], bufs["y2"], g["b2"], self.pool)   # db2 without dZ2
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
         D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
         D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1
@@ -295,9 +299,9 @@ class GCN2(_GraphRunner):
         return self._defer_buf
 
     def _fold(self, batch):
-        """Batches without a tile plan (the latency regime) and SUM / AVG pooling: pool' and the ReLU mask fold into
-        the backward aggregation and db2 into the head."""
-        return (batch.a.plan is None and self.pool in ("sum", "avg") and self.hidden % 4 == 0
+        """SUM / AVG pooling: pool' and the ReLU mask fold into the backward aggregation (dZ2 is never materialised) and
+        db2 = sum_g dPooled[g] * #[Y2_g > 0] comes out of the head (few graphs) or of gcnx_pool_bwd_colsum."""
+        return (self.pool in ("sum", "avg") and self.hidden % 4 == 0 and (batch.a.plan is None or self.hidden % 32 == 0)
                 and os.environ.get("GCNX_FOLD", "1") != "0" and int(os.environ.get("GCNX_SIDE", "1")) == 1)
 
     def _fused(self, batch):

@@ -268,11 +268,13 @@ GCNX_API int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, cons
  * -- replaces gcnx_segment_pool_bwd(y=...) + gcnx_spmm_csr for the gradient of GlobalSumPool (gcn.py:319) through
  * the ReLU of the last GCNConv (gcn.py:317) and its aggregation; tf.GradientTape materialises dZ there (gcn.py:337).
  * (rowptr, colidx, vals) is the TRANSPOSED operator, as for the unfused backward call.  Needs f, ldy, ldo, lddp in
- * multiples of 4 floats and 16-byte aligned y / out / dpooled; MAX pooling has no such form (GCNX_ERR_INVALID). */
+ * multiples of 4 floats and 16-byte aligned y / out / dpooled; MAX pooling has no such form (GCNX_ERR_INVALID).
+ * plan (may be NULL): the operator's gcnx_spmm_plan built over the same graph_ptr -- large batches then run on the tile
+ * kernels (the landed tile of y is masked in place, the graph's dPooled row scales the sums). */
 GCNX_API int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                            const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b,
                            const float* dpooled, int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f,
-                           int mode);
+                           int mode, const gcnx_spmm_plan* plan);
 /* db[f] = column sums of the same never-materialised dZ (BiasAddGrad of that layer):
  * sum_g scale_g * dPooled[g] * #{j in g : y[j] > 0}; deterministic (fixed summation order). */
 GCNX_API int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, const float* dpooled,

@@ -1,9 +1,7 @@
 #!/bin/bash
-for sl in 64 128 192 256 384; do echo "== slices $sl"; GCNX_DW_SLICES=$sl python scripts/fused_bench.py | grep dw2; done
-GCNX_GEMM_STREAM=0 python scripts/fused_bench.py | grep dw2
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tr_f -- python3 scripts/fused_bench.py > gpurun_out/tr_f.log 2>&1; find gpurun_out/tr_f -name "*kernel_trace.csv" -delete; python3 - <<EOF2
-import csv,glob,os
-f=sorted(glob.glob("gpurun_out/tr_f/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
-for r in list(csv.DictReader(open(f)))[:10]:
-    print(r["Name"][:90].ljust(90), r["Calls"], r["AverageNs"])
-EOF2
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "fold or config3 or config5 or spmm" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
+tail -2 gpurun_out/t.log
+python bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/b1.json 2>gpurun_out/b1.err && python -c "
+import json; d=json.load(open('gpurun_out/b1.json')); print(d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'])"
+GCNX_FOLD=0 python bench.py --allow-knobs --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/b1.json 2>gpurun_out/b1.err && python -c "
+import json; d=json.load(open('gpurun_out/b1.json')); print('nofold', d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'])"

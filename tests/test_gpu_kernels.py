@@ -630,6 +630,40 @@ def test_spmm_pool_bwd_fold_equals_pool_bwd_then_spmm(ctx, shape, mode):
     assert rel_err(out.numpy(), o.spmm_csr_T(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None, dz)) < TIGHT
 
 
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+def test_spmm_pool_bwd_fold_on_the_tile_kernels(ctx, mode):
+    """The folded backward aggregation with a tile plan (throughput regime: >= 128 graphs): both tile tiers mask their
+    LDS tile in place, graphs taller than a tile go through the rows kernel's chunk list; against the oracle's unfused
+    chain, non-symmetric values."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    o = O()
+    hb = synth.block_diag_batch(120_000, 1_200_000, 64, seed=4)
+    sizes = np.diff(hb.graph_ptr)
+    assert len(sizes) >= 128 and (sizes <= 604).any() and ((sizes > 604) & (sizes <= 1236)).any() and (sizes > 1236).any()
+    n, f, b = hb.n, 64, len(sizes)
+    rng = np.random.default_rng(8)
+    vals = (rng.random(len(hb.colidx)) + 0.25).astype(np.float32)
+    y = np.maximum(rng.standard_normal((n, f), dtype=np.float32), 0)
+    dp = rng.standard_normal((b, f), dtype=np.float32)
+    dz = o.global_pool_bwd(dp.astype(np.float64), hb.graph_ptr, n, mode, None) * (y > 0)
+    ref = o.spmm_csr_T(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals.astype(np.float64), dz)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr, symmetric=False)
+    at = a.transpose()
+    assert at.plan is not None
+    seg = Segments(ctx, hb.graph_ptr)
+    out = ctx.empty((n, f)); dy, ddp = ctx.to_device(y), ctx.to_device(dp)
+    D.spmm_pool_bwd(ctx, at, dy, seg, ddp, out, mode)
+    assert rel_err(out.numpy(), ref) < TIGHT
+    tiled = out.numpy().copy()
+    ctx.set_tuning("spmm_kernel", "rows")                                   # the same call on the row gather
+    try:
+        D.spmm_pool_bwd(ctx, at, dy, seg, ddp, out, mode)
+    finally:
+        ctx.set_tuning("spmm_kernel", "auto")
+    assert rel_err(out.numpy(), ref) < TIGHT and rel_err(out.numpy(), tiled) < TIGHT
+
+
 def test_spmm_pool_bwd_fold_argument_errors(ctx):
     from gcnx import device as D, synth
     from gcnx.device import Segments
