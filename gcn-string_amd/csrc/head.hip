@@ -261,6 +261,17 @@ static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const floa
                      float* dpooled, int64_t lddp, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
                      float* pooled_out, float* db_relu, int cce_mode);
 
+// prod[g][c] = pool'(dPooled)[g][c] * cnt[g][c]: the per-graph terms of the bias gradient of the ReLU layer under the pool
+__global__ __launch_bounds__(256) void dp_cnt_kernel(const float* __restrict__ dp, int64_t lddp, const float* __restrict__ cnt,
+                                                     const int32_t* __restrict__ gp, int32_t b, int32_t h, int avg,
+                                                     float* __restrict__ prod) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)b * h) return;
+  const int g = (int)(i / h), c = (int)(i % h);
+  const float sc = avg ? 1.0f / (float)max(gp[g + 1] - gp[g], 1) : 1.0f;
+  prod[i] = dp[(int64_t)g * lddp + c] * sc * cnt[i];
+}
+
 static size_t head_lds_floats(int32_t h, int32_t c, bool with_db_relu) {
   return (size_t)kHeadRows * (h + 1) + (size_t)h * c + (with_db_relu ? (size_t)kHeadRows * (h + 1) + 4 * (size_t)h : 0);
 }
@@ -288,6 +299,27 @@ int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const f
   const bool fused = b > 0 && h > 0 && h % 4 == 0 && c <= kHeadMaxC &&
                      head_lds_floats(h, c, db_relu != nullptr) <= (size_t)kHeadLdsFloats &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && gcnx_pool_split(ctx, b, h, pool_mode, 1) > 1;
+  if (!fused && db_relu && b > 0 && b <= 4096 && h > 0 && h % 4 == 0 && ldp == h && (reinterpret_cast<uintptr_t>(db_relu) & 15) == 0 &&
+      gcnx_pool_split(ctx, b, h, pool_mode, 4) == 1) {   // (the row order gcnx_segment_pool sums in: same pooled bits)
+    // Many graphs (a large batch): the pool's pass over x also counts the positive entries per (graph, column) -- all
+    // that db_relu = sum_g pool'(dPooled)[g] * #[x_g > 0] needs -- instead of a second pass over x
+    // (gcnx_pool_bwd_colsum: 1 GB at config 3).  Workspace: [head slabs, later the products b x h + their reduction's
+    // scratch | counts b x h]; reserved once, up front.
+    const int nblk = gcnx_cdiv(b, kHeadRows);
+    const size_t slab_floats = nblk > 1 ? (((size_t)nblk * ((size_t)h * c + c + 2) + 3) & ~(size_t)3) : 0;   // as head_impl
+    const size_t cnt_off = (std::max(slab_floats * sizeof(float), gcnx_colsum_partials_ws(b, h)) / sizeof(float) + 63) & ~(size_t)63;
+    int rc = gcnx_ws_reserve(ctx, (cnt_off + (size_t)b * h) * sizeof(float));
+    if (rc) return rc;
+    float* cnt = (float*)ctx->ws + cnt_off;
+    rc = gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, pool_mode, 1, pooled, cnt, 0);
+    if (rc) return rc;
+    rc = gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, cce_mode);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dp_cnt_kernel, dim3(gcnx_cdiv((int64_t)b * h, 256)), dim3(256), 0, ctx->stream, dpooled, lddp,
+                       (const float*)cnt, graph_ptr, b, h, pool_mode == GCNX_POOL_AVG ? 1 : 0, (float*)ctx->ws);
+    GCNX_LAUNCH_OK(ctx);
+    return gcnx_colsum_partials(ctx, b, h, db_relu);
+  }
   if (!fused) {   // MAX pooling, many graphs (no split), operands too large for LDS: the separate calls as they are
     int rc = gcnx_segment_pool(ctx, graph_ptr, x, ldx, pooled, b, h, pool_mode, argmax);
     if (rc) return rc;

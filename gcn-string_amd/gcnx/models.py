@@ -220,8 +220,7 @@ class GCN2(_GraphRunner):
             # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"],
-                                     db_relu=self.g["b2"] if self._fold(batch) and batch.a.plan is None else None,
-                                     cce=self.cce_train, **head)
+                                     db_relu=self.g["b2"] if self._fold(batch) else None, cce=self.cce_train, **head)
         elif with_loss:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, cce=self.cce_eval, **head)
@@ -281,8 +280,7 @@ class GCN2(_GraphRunner):
         with ctx.side():
             if not fold:
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
-            elif batch.a.plan is not None:                                     # (folded, few graphs: db2 came out of the head)
-                D.pool_bwd_colsum(ctx, batch.seg, bufs["dpooled"], bufs["y2"], g["b2"], self.pool)   # db2 without dZ2
+            # (folded: db2 came out of the head -- from the pool's own count of positive entries)
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
         D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
         D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1

@@ -752,10 +752,12 @@ def test_dense_softmax_cce_head(ctx, b, h, c, cce):
 
 
 @pytest.mark.parametrize("b,h,c,mode", [(32, 128, 2, "sum"), (5, 16, 3, "avg"), (100, 64, 2, "sum"), (100, 64, 2, "avg"),
-                                        (700, 64, 2, "sum"), (6, 32, 2, "max"), (3, 600, 2, "sum")])
+                                        (700, 64, 2, "sum"), (700, 64, 2, "avg"), (1500, 32, 3, "avg"), (6, 32, 2, "max"),
+                                        (3, 600, 2, "sum")])
 def test_pool_dense_softmax_cce_equals_the_two_calls(ctx, b, h, c, mode):
     """gcnx_pool_dense_softmax_cce: split pools (few graphs, sum/avg) are combined by the head itself; one or several
-    head workgroups (partials and dW slabs share the workspace), MAX / many graphs / wide operands take the two calls.
+    head workgroups (partials and dW slabs share the workspace), MAX / wide operands take the two calls, many graphs
+    the two calls with db_relu computed from the pool's own count of positive entries.
     Every output must equal gcnx_segment_pool + gcnx_dense_softmax_cce up to the pool's fp32 summation order (the
     fused form slices the rows differently), and two runs of the fused call must agree bit for bit."""
     from gcnx import device as D
