@@ -676,12 +676,20 @@ int gcnx_colsum(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f
 namespace {
 
 // X*W (transpose = 1) and dH*W^T (transpose = 0) on the bf16 MFMA path.
+// colsum_out / colsum_done (may be NULL): column sums of c wanted / set to 1 if this call produced them (the streaming
+// kernel sums what it writes; otherwise the caller runs a column-sum pass).
 int launch_bf16_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose,
-                   float* c, int64_t ldc, int64_t m, int prec, const Epilogue& ep) {
+                   float* c, int64_t ldc, int64_t m, int prec, const Epilogue& ep, float* colsum_out = nullptr,
+                   int* colsum_done = nullptr) {
   const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
+  if (colsum_done) *colsum_done = 0;
   if (ep.vec_c && !ep.colpart) {            // tall activations: the streaming kernel (weights resident in LDS)
     int rs = gcnx_gemm_stream_nn(ctx, a, lda, w, fi, fo, transpose, c, ldc, m, prec, ep.bias, ep.alpha, ep.act, ep.mask, ep.ldmask,
-                                 ep.accumulate);
+                                 ep.accumulate, colsum_done ? colsum_out : nullptr);
+    if (rs == GCNX_OK && colsum_done && colsum_out) *colsum_done = 1;
+    if (rs == GCNX_ERR_UNSUPPORTED && colsum_done && colsum_out)   // (e.g. an unaligned db): without the sums
+      rs = gcnx_gemm_stream_nn(ctx, a, lda, w, fi, fo, transpose, c, ldc, m, prec, ep.bias, ep.alpha, ep.act, ep.mask, ep.ldmask,
+                               ep.accumulate, nullptr);
     if (rs != GCNX_ERR_UNSUPPORTED) return rs;
   }
   const int kpad = ((K + HK - 1) / HK) * HK;
@@ -750,9 +758,10 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
   Epilogue ep{nullptr, nullptr, y_mask, ldy, GCNX_ACT_NONE, accumulate,
               al16(dx) && lddx % 4 == 0 && (!y_mask || (al16(y_mask) && ldy % 4 == 0))};
   if (prec != GCNX_PREC_F32) {
-    int rc = launch_bf16_nn(ctx, dh, lddh, w, fi, fo, 0, dx, lddx, n, prec, ep);
+    int db_done = 0;
+    int rc = launch_bf16_nn(ctx, dh, lddh, w, fi, fo, 0, dx, lddx, n, prec, ep, db, &db_done);
     if (rc) return rc;
-    if (db) return gcnx_colsum(ctx, dx, lddx, n, fi, db);
+    if (db && !db_done) return gcnx_colsum(ctx, dx, lddx, n, fi, db);
     return GCNX_OK;
   }
   dim3 grid(gcnx_cdiv(fi, BN), gcnx_cdiv(n, BM), 1);

@@ -48,6 +48,7 @@ struct StreamEpi {
   int64_t ldmask;
   int act;
   int accumulate;
+  float* colpart;         // [pairs, ncol] column sums of what each workgroup wrote (BiasAddGrad partials) or null
 };
 
 // Weight operand -> bf16 planes in MFMA-fragment order.  Element (col, k) of plane p of column half h lives at
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   static_assert(KSTEPS % kSDepth == 0 && NB % NF == 0 && RT * CT == 16, "pipeline shape");
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   float* lbias = reinterpret_cast<float*>(lds + IMG);    // [CW] bias, [CW] alpha
+  float* wsum = lbias + 2 * CW;                          // [waves][CW] column sums of the rows each wave wrote (ep.colpart)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, q = lane >> 4;
 
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
       lbias[i] = (ep.bias && c0 + i < ncol) ? ep.bias[c0 + i] : 0.f;
       lbias[CW + i] = (ep.alpha && c0 + i < ncol) ? ep.alpha[c0 + i] : 0.f;
     }
+    for (int i = tid; i < kSWaves * CW; i += 512) wsum[i] = 0.f;
   }
   __syncthreads();
 
@@ -312,10 +315,35 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
         // (a load or store inside a branch makes hipcc drain the whole prefetch ring with vmcnt(0))
         const unsigned off = (row < M && col < ncol) ? (unsigned)row * ldc4 + (unsigned)col * 4u : 0xFFFFFFE0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(si32x4, sf32x4{v.x, v.y, v.z, v.w}), crs, off, 0, GCNX_STREAM_STORE_AUX);
+        if (ep.colpart) {
+          // column sums of what was written, without reading it back: the 16 rows of the tile are summed across the
+          // lanes rl = 0 .. 15 (fixed tree), lane rl = 0 adds the result to its wave's LDS row -- the same lane in
+          // the same order every time (units, tiles ascending): deterministic.  LDS only: nothing here waits on vmcnt.
+          float4 sv = row < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1) {
+            sv.x += __shfl_xor(sv.x, sh); sv.y += __shfl_xor(sv.y, sh); sv.z += __shfl_xor(sv.z, sh); sv.w += __shfl_xor(sv.w, sh);
+          }
+          if (rl == 0) {
+            float4* ws4 = reinterpret_cast<float4*>(wsum + wave * CW + ct * 16 + q * 4);
+            float4 o = *ws4;
+            o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
+            *ws4 = o;
+          }
+        }
       }
     }
     mbits = mnext;                                       // the first two mask pieces of the next unit are already in
     mnext = 0;
+  }
+  if (ep.colpart) {                                      // the workgroup's column sums: its 8 waves in a fixed order
+    __syncthreads();
+    for (int i = tid; i < CW; i += 512) {
+      float t = wsum[i];
+#pragma unroll
+      for (int w = 1; w < kSWaves; ++w) t += wsum[w * CW + i];
+      if (c0 + i < ncol) ep.colpart[(int64_t)pair * ncol + c0 + i] = t;
+    }
   }
 #undef GS_ISSUE
 #undef GS_CONVERT
@@ -327,7 +355,7 @@ inline bool sal16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 template <int NP, int CW, int RT, int KSTEPS>
 int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img, float* c, int64_t ldc, int64_t m, int ncol,
                   const StreamEpi& ep, int halves) {
-  constexpr size_t lds_bytes = (size_t)NP * KSTEPS * CW * 32 * 2 + 2 * CW * 4;
+  constexpr size_t lds_bytes = (size_t)NP * KSTEPS * CW * 32 * 2 + 2 * CW * 4 + (size_t)kSWaves * CW * 4;
   static_assert(lds_bytes <= 160 * 1024, "weight image must fit the CU's LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -358,7 +386,7 @@ int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img,
 // setting an error message) when the shape is not one it is built for; the caller then takes the tiled kernel.
 int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose, float* c,
                         int64_t ldc, int64_t m, int prec, const float* bias, const float* alpha, int act, const float* mask,
-                        int64_t ldmask, int accumulate) {
+                        int64_t ldmask, int accumulate, float* colsum_out) {
   const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
   const int np = prec == GCNX_PREC_BF16X3 ? 2 : 1;
   if (accumulate) return GCNX_ERR_UNSUPPORTED;   // (a read-modify-write epilogue would drain the prefetch ring: tiled kernel)
@@ -375,15 +403,26 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
   const int cw = np == 2 ? 128 : 256;
   const int halves = gcnx_cdiv(ncol, cw);
   const size_t img_elems = (size_t)halves * np * ksteps * cw * 32;
-  int rc = gcnx_ws_reserve(ctx, img_elems * sizeof(__bf16) + 256);
+  // colsum_out (BiasAddGrad of the layer below, db = column sums of what is written): per-workgroup partial rows at the
+  // START of the workspace (where gcnx_colsum_partials looks for them), the weight image behind them
+  int grid_wgs = ctx->num_cus;
+  if (halves == 2) grid_wgs &= ~1;
+  const int64_t prow = colsum_out ? grid_wgs / halves : 0;
+  if (colsum_out && (ncol % 4 != 0 || !sal16(colsum_out))) return GCNX_ERR_UNSUPPORTED;
+  const size_t part_bytes = colsum_out ? ((gcnx_colsum_partials_ws(prow, ncol) + 255) & ~(size_t)255) : 0;
+  int rc = gcnx_ws_reserve(ctx, part_bytes + img_elems * sizeof(__bf16) + 256);
   if (rc) return rc;
-  __bf16* img = (__bf16*)ctx->ws;
+  __bf16* img = (__bf16*)((char*)ctx->ws + part_bytes);
   hipLaunchKernelGGL(stream_wprep_kernel, dim3(gcnx_cdiv((long long)img_elems, 256)), dim3(256), 0, ctx->stream, w, fi, fo, transpose,
                      np, cw, ksteps, ncol, img);
   GCNX_LAUNCH_OK(ctx);
-  const StreamEpi ep{bias, alpha, mask, ldmask, act, accumulate};
-  if (np == 2) return launch_stream<2, 128, 2, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves);
-  return launch_stream<1, 256, 1, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves);
+  const StreamEpi ep{bias, alpha, mask, ldmask, act, accumulate, colsum_out ? (float*)ctx->ws : nullptr};
+  if (colsum_out)   // workgroups without row blocks (short inputs) do not run: their partial rows must read as zero
+    GCNX_HIP(ctx, hipMemsetAsync(ctx->ws, 0, (size_t)prow * ncol * sizeof(float), ctx->stream));
+  rc = np == 2 ? launch_stream<2, 128, 2, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves)
+               : launch_stream<1, 256, 1, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves);
+  if (rc || !colsum_out) return rc;
+  return gcnx_colsum_partials(ctx, prow, ncol, colsum_out);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 #!/bin/bash
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "fold or config3 or config5 or spmm" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "stream or gemm or config3 or config5 or dense" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
 tail -2 gpurun_out/t.log
-python bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/b1.json 2>gpurun_out/b1.err && python -c "
-import json; d=json.load(open('gpurun_out/b1.json')); print(d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'])"
-GCNX_FOLD=0 python bench.py --allow-knobs --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/b1.json 2>gpurun_out/b1.err && python -c "
-import json; d=json.load(open('gpurun_out/b1.json')); print('nofold', d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'])"
+for p in bf16x3 bf16 f32; do
+python bench.py --workload block1m --prec $p --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/b1.json 2>gpurun_out/b1.err && python -c "
+import json; d=json.load(open('gpurun_out/b1.json')); print('$p', d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'])"
+done
