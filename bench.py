@@ -366,6 +366,28 @@ def main():
     alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, hidden, weighted=True)
     achieved = alg / (spmm_ms * 1e-3) / 1e9
 
+    # ---- small-feature regime (config 2): the step does not launch gcnx_spmm_csr at all -- every GCNConv is ONE launch,
+    # aggregation + dense product (csrc/fused.hip).  Its launch time and bytes, measured the same way, next to the
+    # stand-alone aggregation above (which stays the `roofline` entry: it is the kernel the metric names).
+    fused = None
+    if getattr(model, "_fused", None) and model._fused(batch):
+        s_buf = ctx.empty((hb.n, hb.f)); y_buf = ctx.empty((hb.n, hidden))
+        for _ in range(5):
+            D.gcn_conv_fwd(ctx, a, batch.x, model.p["w1"], model.p["b1"], y_buf, act="relu", s=s_buf)
+        e0 = ctx.event().record()
+        for _ in range(iters):
+            D.gcn_conv_fwd(ctx, a, batch.x, model.p["w1"], model.p["b1"], y_buf, act="relu", s=s_buf)
+        e1 = ctx.event().record()
+        f_ms = e1.elapsed_ms_since(e0) / iters
+        f_alg = 4 * (hb.n + 1) + 8 * hb.nnz + 4 * hb.n * hb.f * 2 + 4 * hb.n * hidden + 4 * hb.f * hidden
+        fused = {"kernel": "gcn_conv_fused_kernel: gather + fp32 MFMA (16x16x4) dense + bias/ReLU, S = A X saved; what the "
+                           "training step launches per GCNConv at this config instead of gcnx_gemm + gcnx_spmm_csr",
+                 "bound": "hbm", "achieved": f_alg / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": f_alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": f_alg,
+                 "avg_launch_us": 1e3 * f_ms, "launches": iters,
+                 "note": "latency regime: the gather moves nnz x 4F bytes through the CUs' L1 paths (64 B/clk each), the dense "
+                         "product is fp32-MFMA-bound per CU; neither phase is near HBM's rate at 37 MB per launch"}
+
     # ---- the same kernel at BASELINE config 3 size (1M nodes / 10M entries / F=256), where the launch is long
     # enough for a bandwidth reading; reported next to the primary roofline, never as `value`
     big = None
@@ -415,6 +437,8 @@ def main():
         }
         if knobs:
             rec["env_knobs"] = knobs
+        if fused is not None:
+            rec["roofline_step_kernel"] = fused
         if big is not None:
             rec["roofline_config3"] = big
         if world == 1 and args.cpu_seconds > 0:
