@@ -715,6 +715,160 @@ int launch_bf16_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, i
 
 }  // namespace
 
+// ----------------------------------------------------------------------------------------------
+// fp32 row-tile GEMM, weights in registers (r2): X W and dH W^T for K <= 256, <= 256 output columns.
+// The 64 x 64-tile kernel above reaches 51-66 % of the fp32 MFMA peak at config 3 and 30 % at GeneralGNN's sizes
+// (N = 22 576, 256 x 256: 62 us for 2.96 GFLOP): per K step every workgroup pays a barrier, two transposing LDS stores
+// and 2 LDS reads per MFMA.  Here the small operand never touches LDS: wave w owns output columns [16w, 16w + 16) and
+// keeps its K x 16 slice of W in REGISTERS (K / 4 per lane, the v_mfma_f32_16x16x4_f32 B layout: lane l holds
+// k = 4 kk + (l >> 4), column l & 15), loaded once per persistent workgroup.  The streamed operand goes through LDS
+// untransposed -- a 32-row tile, row stride K + 4 floats, so that the A read S[l & 15][4 kk + (l >> 4)] is
+// conflict-free -- double-buffered: the rows of tile t + 1 are in flight while tile t's MFMAs run, one barrier per tile.
+// One LDS read per MFMA, epilogue (bias, ReLU / PReLU, ReLU mask, accumulate, column sums) from the accumulator
+// layout.  The same structure as the product phase of csrc/fused.hip, which measures 80 % of the fp32 MFMA peak.
+// ----------------------------------------------------------------------------------------------
+constexpr int kRtRows = 32;
+
+template <int K>
+__global__ __launch_bounds__(1024, 4) void gemm_f32_rowtile_kernel(const float* __restrict__ a, int64_t lda,
+                                                                   const float* __restrict__ w, int64_t ldw,
+                                                                   float* __restrict__ c, int64_t ldc, int64_t M, int32_t nc,
+                                                                   Epilogue ep, int ntiles) {
+  constexpr int LD = K + 4;
+  constexpr int F4 = kRtRows * K / 4;                  // float4 pieces of a tile
+  constexpr int NL = (F4 + 1023) / 1024;               // ... per thread
+  extern __shared__ __attribute__((aligned(16))) float rt_lds[];
+  float (*tile)[kRtRows][LD] = reinterpret_cast<float (*)[kRtRows][LD]>(rt_lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int col = 16 * wave + c16;
+  const bool wave_on = 16 * wave < nc;
+  typedef float rtf4 __attribute__((ext_vector_type(4)));
+
+  float wreg[K / 4];
+  if (wave_on) {
+#pragma unroll
+    for (int kk = 0; kk < K / 4; ++kk)
+      wreg[kk] = w[(int64_t)(4 * kk + kq) * ldw + col];   // 64-byte row pieces (dH W^T hands in a transposed copy of W)
+  }
+  const float bcol = (ep.bias && wave_on) ? ep.bias[col] : 0.f;
+  const float acol = (ep.alpha && wave_on) ? ep.alpha[col] : 0.f;
+
+  float4 pa[NL];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const int i = tid + q * 1024;
+      const int row = i / (K / 4), c4 = i % (K / 4);
+      const int64_t gr = (int64_t)t * kRtRows + row;
+      pa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < F4 && t < ntiles && gr < M) pa[q] = *reinterpret_cast<const float4*>(a + gr * lda + 4 * c4);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const int i = tid + q * 1024;
+      if (i < F4) *reinterpret_cast<float4*>(&tile[buf][i / (K / 4)][4 * (i % (K / 4))]) = pa[q];
+    }
+  };
+  int t = blockIdx.x;
+  fetch(t);
+  stash(0);
+  __syncthreads();
+  float cs = 0.f;                                       // column sum over this workgroup's tiles (ep.colpart)
+  int cur = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    fetch(t + gridDim.x);                               // the next tile's rows fly under this tile's MFMAs
+    const int64_t r0 = (int64_t)t * kRtRows;
+    float mk[8];
+    if (ep.mask && wave_on) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t row = r0 + 16 * (r >> 2) + 4 * kq + (r & 3);
+        mk[r] = row < M ? ep.mask[row * ep.ldmask + col] : 0.f;
+      }
+    }
+    float old[8];
+    if (ep.accumulate && wave_on) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t row = r0 + 16 * (r >> 2) + 4 * kq + (r & 3);
+        old[r] = row < M ? c[row * ldc + col] : 0.f;
+      }
+    }
+    rtf4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    if (wave_on) {
+#pragma unroll
+      for (int kk = 0; kk < K / 4; ++kk) {
+        const float a0 = tile[cur][c16][4 * kk + kq];
+        const float a1 = tile[cur][16 + c16][4 * kk + kq];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[kk], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[kk], c1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t row = r0 + 16 * (r >> 2) + 4 * kq + (r & 3);
+        float v = (r < 4 ? c0[r & 3] : c1[r & 3]) + bcol;
+        if (ep.act == GCNX_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (ep.act == GCNX_ACT_PRELU) v = v > 0.f ? v : acol * v;
+        if (ep.mask) v = mk[r] > 0.f ? v : 0.f;
+        if (ep.accumulate) v += old[r];
+        if (row < M) { c[row * ldc + col] = v; cs += v; }
+      }
+    }
+    stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (ep.colpart && wave_on) {                          // rows ascending within the lane, then the four row groups: fixed order
+    cs += __shfl_xor(cs, 16);
+    cs += __shfl_xor(cs, 32);
+    if (lane < 16) ep.colpart[(int64_t)blockIdx.x * nc + col] = cs;
+  }
+}
+
+// 1 if the row-tile kernel serves the shape (dispatches below); K is the reduction width, nc the output width
+static bool rowtile_ok(const gcnx_ctx* ctx, int64_t m, int k, int nc, const float* a, int64_t lda) {
+  // (>= 192 columns: at least 12 of the 16 waves have a column tile; narrower products measured no faster than the tiles)
+  return ctx->knob_gemm_stream && m >= 2048 && (k == 16 || k == 32 || k == 64 || k == 128 || k == 256) && nc >= 192 && nc <= 256 &&
+         nc % 16 == 0 && lda % 4 == 0 && al16(a);
+}
+
+// out[o][i] = w[i][o]: the [K, nc] operand of the row-tile kernel for dH W^T (a strided read of W in the kernel costs
+// 16 lines per load instruction, once per workgroup: 20 us at N = 22 576 where a workgroup sees three tiles)
+__global__ __launch_bounds__(256) void transpose_small_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rows * cols) out[(int64_t)(i % cols) * rows + i / cols] = w[i];
+}
+
+static int launch_rowtile(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int64_t ldw, float* c, int64_t ldc,
+                          int64_t m, int k, int nc, const Epilogue& ep, int grid) {
+  const int ntiles = gcnx_cdiv(m, kRtRows);
+#define GCNX_RT(K_)                                                                                                      \
+  do {                                                                                                                   \
+    constexpr int lds_bytes = 2 * kRtRows * (K_ + 4) * 4;                                                                \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_rowtile_kernel<K_>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                         \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_f32_rowtile_kernel<K_>), dim3(grid), dim3(1024), lds_bytes, ctx->stream, a, lda, w,          \
+                       ldw, c, ldc, m, nc, ep, ntiles);                                                                  \
+  } while (0)
+  switch (k) {
+    case 16: GCNX_RT(16); break;
+    case 32: GCNX_RT(32); break;
+    case 64: GCNX_RT(64); break;
+    case 128: GCNX_RT(128); break;
+    default: GCNX_RT(256); break;
+  }
+#undef GCNX_RT
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
 // Split-K slices of the f32 dW products are at least this many K steps deep (32 rows each): with loads and MFMAs
 // overlapped, short slices only add slab traffic and reduction work (config 2, 641 steps: 256 slices of 2-3 steps ->
 // 64 of 10: step 0.1496 -> 0.143 ms); long inputs still get ~4 workgroups per CU.
@@ -734,6 +888,8 @@ int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const 
   GCNX_REQUIRE(ctx, ldx >= fi && ldo >= fo, "gcnx_gemm: leading dimension too small");
   Epilogue ep{bias, act == GCNX_ACT_PRELU ? alpha : nullptr, nullptr, 0, act, 0, al16(out) && ldo % 4 == 0};
   if (prec != GCNX_PREC_F32) return launch_bf16_nn(ctx, x, ldx, w, fi, fo, 1, out, ldo, n, prec, ep);
+  if (rowtile_ok(ctx, n, fi, fo, x, ldx))
+    return launch_rowtile(ctx, x, ldx, w, (int64_t)fo, out, ldo, n, fi, fo, ep, std::min(gcnx_cdiv(n, kRtRows), ctx->num_cus));
   dim3 grid(gcnx_cdiv(fo, BN), gcnx_cdiv(n, BM), 1);
   const int va = al16(x) && ldx % 4 == 0, vb = al16(w) && fo % 4 == 0;
   hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, ctx->stream, x, ldx, w, (int64_t)fo, out,
@@ -763,6 +919,20 @@ int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, f
     if (rc) return rc;
     if (db && !db_done) return gcnx_colsum(ctx, dx, lddx, n, fi, db);
     return GCNX_OK;
+  }
+  if (rowtile_ok(ctx, n, fo, fi, dh, lddh) && (!db || al16(db))) {   // dX[n, i] = sum_o dH[n, o] W[i, o]: K = fo, columns = fi
+    const int wgs = std::min(gcnx_cdiv(n, kRtRows), ctx->num_cus);
+    // workspace: [db partial rows + their reduction's scratch | W^T]
+    const size_t part_bytes = db ? (((size_t)gcnx_colsum_partials_ws(wgs, fi) + 255) & ~(size_t)255) : 0;
+    int rc = gcnx_ws_reserve(ctx, part_bytes + (size_t)fi * fo * sizeof(float));
+    if (rc) return rc;
+    if (db) ep.colpart = (float*)ctx->ws;
+    float* wt = (float*)((char*)ctx->ws + part_bytes);
+    hipLaunchKernelGGL(transpose_small_kernel, dim3(gcnx_cdiv((int64_t)fi * fo, 256)), dim3(256), 0, ctx->stream, w, fi, fo, wt);
+    GCNX_LAUNCH_OK(ctx);
+    rc = launch_rowtile(ctx, dh, lddh, wt, (int64_t)fi, dx, lddx, n, fo, fi, ep, wgs);
+    if (rc || !db) return rc;
+    return gcnx_colsum_partials(ctx, wgs, fi, db);
   }
   dim3 grid(gcnx_cdiv(fi, BN), gcnx_cdiv(n, BM), 1);
   const int va = al16(dh) && lddh % 4 == 0, vb = al16(w) && fo % 4 == 0;

@@ -1,7 +1,8 @@
 #!/bin/bash
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "stream or gemm or config3 or config5 or dense" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
 tail -2 gpurun_out/t.log
-for p in bf16x3 bf16 f32; do
-python bench.py --workload block1m --prec $p --steps 20 --warmup 3 --cpu-seconds 0 > gpurun_out/b1.json 2>gpurun_out/b1.err && python -c "
-import json; d=json.load(open('gpurun_out/b1.json')); print('$p', d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'])"
-done
+python bench.py --model generalgnn --steps 50 --warmup 5 > gpurun_out/bg.json 2>gpurun_out/bg.err && python -c "
+import json; d=json.load(open('gpurun_out/bg.json')); print('generalgnn', d['ms_per_step'], d['value'])"
+python scripts/gemm_bench.py --n 1000000 --shapes 256x256 --prec f32 --iters 5
+python scripts/gemm_bench.py --n 22576 --shapes 256x256,16x256 --prec f32 --iters 20
+GCNX_GEMM_STREAM=0 python scripts/gemm_bench.py --n 22576 --shapes 256x256,16x256 --prec f32 --iters 20
