@@ -508,6 +508,54 @@ def test_gemm_bf16_mfma_paths(ctx, n, fi, fo):
     assert rel_err(out.numpy(), x64 @ w64) < 2e-2
 
 
+@pytest.mark.parametrize("n,fi,fo", [(5003, 256, 256), (2100, 16, 256), (9000, 128, 192), (40000, 64, 256)])
+def test_gemm_f32_rowtile_kernel(ctx, n, fi, fo):
+    """The fp32 row-tile kernel (weight slice in registers, 16x16x4 MFMA; >= 2048 rows, K in {16 .. 256}, 192 - 256
+    output columns): X W with bias / ReLU / PReLU, dH W^T (K = fo, columns = fi: served when fi >= 192) with the ReLU
+    mask, accumulate and the fused column sums; ragged last tile; column-slice views; against float64, and equal to
+    the tiled kernel to rounding."""
+    from gcnx import device as D
+    rng = np.random.default_rng(n + fi + fo)
+    x = rng.standard_normal((n, fi), dtype=np.float32); w = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
+    b = rng.standard_normal(fo).astype(np.float32); al = rng.random(fo).astype(np.float32)
+    d_x, d_w, d_b, d_al = (ctx.to_device(v) for v in (x, w, b, al))
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    out = ctx.empty((n, fo))
+    z = x64 @ w64 + b
+    D.gemm(ctx, d_x, d_w, d_b, out, act="relu")
+    got = out.numpy()
+    assert rel_err(got, np.maximum(z, 0)) < TIGHT
+    D.gemm(ctx, d_x, d_w, d_b, out, act="prelu", alpha=d_al)
+    assert rel_err(out.numpy(), np.where(z > 0, z, al * z)) < TIGHT
+    D.gemm(ctx, d_x, d_w, None, out)
+    assert rel_err(out.numpy(), x64 @ w64) < TIGHT
+    ctx.set_tuning("gemm_stream", 0)                                   # the 64 x 64-tile kernel
+    try:
+        D.gemm(ctx, d_x, d_w, d_b, out, act="relu")
+    finally:
+        ctx.set_tuning("gemm_stream", 1)
+    assert rel_err(out.numpy(), got) < TIGHT
+    # dH W^T: here dH is [n, fo'] with fo' = fi of this case and W [fo, fi] -> dX [n, fo]
+    w2 = (rng.standard_normal((fo, fi)) / np.sqrt(fi)).astype(np.float32)
+    ym = rng.standard_normal((n, fo), dtype=np.float32)
+    d_w2, d_ym = ctx.to_device(w2), ctx.to_device(ym)
+    dx = ctx.zeros((n, fo)); db = ctx.empty(fo)
+    ref = (x64 @ w2.astype(np.float64).T) * (ym > 0)
+    D.gemm_dx(ctx, d_x, d_w2, dx, y_mask=d_ym, db=db)
+    assert rel_err(dx.numpy(), ref) < TIGHT and rel_err(db.numpy(), ref.sum(0)) < TIGHT
+    first = (dx.numpy().copy(), db.numpy().copy())
+    D.gemm_dx(ctx, d_x, d_w2, dx, y_mask=d_ym, db=db)
+    assert np.array_equal(dx.numpy(), first[0]) and np.array_equal(db.numpy(), first[1])       # fixed-order sums
+    base = rng.standard_normal((n, fo), dtype=np.float32)
+    dx.copy_from_host(base)
+    D.gemm_dx(ctx, d_x, d_w2, dx, accumulate=True)                     # skip-connection gradients add up in place
+    assert rel_err(dx.numpy(), base + x64 @ w2.astype(np.float64).T) < TIGHT
+    wide_in, wide_out = ctx.to_device(np.concatenate([x, x], 1)), ctx.zeros((n, fo + 64))
+    D.gemm(ctx, wide_in.cols(fi, 2 * fi), d_w, d_b, wide_out.cols(64, 64 + fo))
+    wo = wide_out.numpy()
+    assert rel_err(wo[:, 64:], z) < TIGHT and not wo[:, :64].any()
+
+
 @pytest.mark.parametrize("n,fi,fo", [(40000, 256, 256), (33001, 256, 192), (70000, 128, 128), (36000, 128, 256), (50000, 256, 64)])
 def test_gemm_bf16_streaming_kernel(ctx, n, fi, fo, monkeypatch):
     """The streaming form of the bf16 weight GEMM (csrc/gemm_stream.hip: weight planes resident in LDS, activation
