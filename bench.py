@@ -33,7 +33,9 @@ for _p in (ROOT, os.path.join(ROOT, "gcn-string_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
-CONFIG_PREC = {"ecoli": "f32", "block1m": "bf16x3", "powerlaw": "bf16x3"}   # config 2 is quoted in fp32; config 3 names the bf16 MFMA GEMM
+# config 2 is quoted in fp32; config 3 / 4 state "bf16 MFMA weight GEMM": plain bf16 operands, fp32 accumulate and fp32
+# activations (--prec bf16x3 = split-bf16, fp32-grade results at three MFMA passes; --prec f32 = the fp32 MFMA path)
+CONFIG_PREC = {"ecoli": "f32", "block1m": "bf16", "powerlaw": "bf16x3"}
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void collate_kernel(const int32_t* __restrict_
                                                       int64_t ldx, int32_t f, const float* __restrict__ y, int32_t c,
                                                       int32_t* __restrict__ o_rowptr, int32_t* __restrict__ o_colidx,
                                                       float* __restrict__ o_vals, float* __restrict__ o_x, int64_t ldo,
-                                                      float* __restrict__ o_y, int32_t* __restrict__ o_gp) {
+                                                      float* __restrict__ o_y, int32_t* __restrict__ o_gp,
+                                                      int32_t* __restrict__ o_ids) {
   const int g = blockIdx.y;                       // position in the batch
   const int src = desc[g];
   const int bn = desc[(b + 1) + g], be = desc[2 * (b + 1) + g];
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(256) void collate_kernel(const int32_t* __restrict_
   const int e0 = rowptr[n0], ne = rowptr[n0 + ng] - e0;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   // CSR rows: row pointers re-based to the batch's entry offset
-  for (int i = tid; i < ng; i += nth) o_rowptr[bn + i] = rowptr[n0 + i] - e0 + be;
+  for (int i = tid; i < ng; i += nth) {
+    o_rowptr[bn + i] = rowptr[n0 + i] - e0 + be;
+    if (o_ids) o_ids[bn + i] = g;                 // DisjointLoader's id vector i
+  }
   // entries: column indices re-based to the batch's node offset
   for (int e = tid; e < ne; e += nth) {
     o_colidx[be + e] = colidx[e0 + e] - n0 + bn;
@@ -284,7 +288,7 @@ int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* coli
 int gcnx_collate(gcnx_ctx* ctx, const int32_t* desc, int32_t b, const int32_t* node_ptr, const int32_t* rowptr,
                  const int32_t* colidx, const float* vals, const float* x, int64_t ldx, int32_t f, const float* y, int32_t c,
                  int32_t* o_rowptr, int32_t* o_colidx, float* o_vals, float* o_x, int64_t ldo, float* o_y,
-                 int32_t* o_graph_ptr) {
+                 int32_t* o_graph_ptr, int32_t* o_node_graph) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, b >= 0 && f >= 0 && c >= 0, "gcnx_collate: negative size");
   if (b == 0) return GCNX_OK;
@@ -293,7 +297,7 @@ int gcnx_collate(gcnx_ctx* ctx, const int32_t* desc, int32_t b, const int32_t* n
   GCNX_REQUIRE(ctx, (vals == nullptr) == (o_vals == nullptr), "gcnx_collate: values in and out go together");
   GCNX_REQUIRE(ctx, !y || o_y, "gcnx_collate: labels need an output");
   hipLaunchKernelGGL(collate_kernel, dim3(16, b), dim3(256), 0, ctx->stream, desc, b, node_ptr, rowptr, colidx, vals, x, ldx,
-                     f, y, c, o_rowptr, o_colidx, o_vals, o_x, ldo, o_y, o_graph_ptr);
+                     f, y, c, o_rowptr, o_colidx, o_vals, o_x, ldo, o_y, o_graph_ptr, o_node_graph);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -58,7 +58,7 @@ SIGNATURES = {
     "gcnx_graph_launch": [_vp, _vp],
     "gcnx_graph_destroy": [_vp, _vp],
     "gcnx_coo_to_csr": [_vp, _vp, _vp, _i64, _i64, _vp, _vp],
-    "gcnx_collate": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "gcnx_collate": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "gcnx_gcn_norm": [_vp, _vp, _vp, _vp, _i32, _int, _vp],
     "gcnx_set_tuning": [_vp, C.c_char_p, _int],
     "gcnx_csr_inspect": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, C.POINTER(C.c_int)],

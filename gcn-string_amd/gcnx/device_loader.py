@@ -65,6 +65,7 @@ class _BatchBuffers:
         self.vals = ctx.empty(max(ecap, 1), np.float32) if ds.csr.vals is not None else None
         self.y = ctx.empty((batch_size, ds.n_labels))
         self.gp = ctx.empty(batch_size + 1, np.int32)
+        self.ids = ctx.empty(max(ncap, 1), np.int32)     # DisjointLoader's id vector i, written by the collate launch
         self.desc = ctx.empty(3 * (batch_size + 1), np.int32)
 
 
@@ -85,8 +86,9 @@ def collate_on_device(ds, indices, bufs=None):
     ctx._ck(ctx.lib.gcnx_collate(ctx.h, dview.ptr, b, ds.node_ptr.ptr, csr.rowptr.ptr, csr.colidx.ptr,
                                  csr.vals.ptr if csr.vals is not None else None, ds.x.ptr, ds.x.ld, f, ds.y.ptr, c,
                                  bufs.rowptr.ptr, bufs.colidx.ptr, bufs.vals.ptr if bufs.vals is not None else None,
-                                 bufs.x.ptr, bufs.x.ld, bufs.y.ptr, bufs.gp.ptr))
+                                 bufs.x.ptr, bufs.x.ld, bufs.y.ptr, bufs.gp.ptr, bufs.ids.ptr))
     seg = D.Segments.from_device(ctx, bufs.gp.flat(0, b + 1), bn)
+    seg._ids = bufs.ids.flat(0, max(n, 1))               # (otherwise built on the host on first use and uploaded)
     a = D.DeviceCSR(ctx, n, nnz, bufs.rowptr.flat(0, n + 1), bufs.colidx.flat(0, max(nnz, 1)),
                     bufs.vals.flat(0, max(nnz, 1)) if bufs.vals is not None else None, seg.dev, b, ds.symmetric)
     batch = DeviceBatch(ctx, bufs.x.flat(0, n * f, (n, f)), a, seg, bufs.y.flat(0, b * c, (b, c)))

@@ -132,11 +132,12 @@ GCNX_API int gcnx_coo_to_csr(gcnx_ctx* ctx, const int64_t* rows, const int64_t* 
  * colidx int32, optional vals), features x[Ntot, f], labels y[G, c].  desc int32[3(b+1)] = the b selected graph
  * ids (one pad), then the batch's node offsets [b+1], then its entry offsets [b+1] (host prefix sums over the
  * selected sizes).  Writes the batch: o_x[N, f], o_rowptr[N+1], o_colidx / o_vals[nnz], o_y[b, c],
- * o_graph_ptr[b+1].  Integer outputs are exact; floats are copies. */
+ * o_graph_ptr[b+1], and (o_node_graph may be NULL) DisjointLoader's id vector i[N] = the batch position of every row's
+ * graph.  Integer outputs are exact; floats are copies. */
 GCNX_API int gcnx_collate(gcnx_ctx* ctx, const int32_t* desc, int32_t b, const int32_t* node_ptr, const int32_t* rowptr,
                  const int32_t* colidx, const float* vals, const float* x, int64_t ldx, int32_t f, const float* y,
                  int32_t c, int32_t* o_rowptr, int32_t* o_colidx, float* o_vals, float* o_x, int64_t ldo, float* o_y,
-                 int32_t* o_graph_ptr);
+                 int32_t* o_graph_ptr, int32_t* o_node_graph);
 /* Spektral GCNConv.preprocess = gcn_filter on a CSR whose every row stores its
  * diagonal entry (true for the reference's data: gcn_utills.py:224-227 keeps the 0-Angstrom
  * diagonal).  vals_in NULL = ones.  SPEKTRAL: diag += 1; PYG: existing loops kept.

@@ -9,7 +9,7 @@ O=gpurun_out/$R; mkdir -p $O
 python3 bench.py --steps 200 --warmup 20 > $O/bench_ecoli.json 2> $O/bench_ecoli.err || { tail -5 $O/bench_ecoli.err; exit 1; }
 python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > $O/bench_block1m.json 2> $O/bench_block1m.err || { tail -5 $O/bench_block1m.err; exit 1; }
 python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec f32 > $O/bench_block1m_f32.json 2> $O/bench_block1m_f32.err
-python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec bf16 > $O/bench_block1m_bf16.json 2> $O/bench_block1m_bf16.err
+python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec bf16x3 > $O/bench_block1m_bf16x3.json 2> $O/bench_block1m_bf16x3.err
 python3 bench.py --workload powerlaw --steps 20 --warmup 3 --cpu-seconds 0 > $O/bench_powerlaw.json 2> $O/bench_powerlaw.err
 python3 bench.py --model generalgnn --steps 50 --warmup 5 > $O/bench_generalgnn.json 2> $O/bench_generalgnn.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ecoli -- python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 > $O/trace_ecoli.log 2>&1

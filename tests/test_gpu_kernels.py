@@ -191,10 +191,10 @@ def test_new_entry_points_zero_sizes_and_argument_errors(ctx):
     # BN moments need rows
     assert lib.gcnx_bn_moments(h, buf.ptr, 4, 0, 4, 0.99, 1e-3, buf.ptr, buf.ptr, None, None) == 1
     # collate: b == 0 is a no-op; values in without values out is refused
-    assert lib.gcnx_collate(h, None, 0, None, None, None, None, None, 0, 0, None, 0, None, None, None, None, 0, None, None) == 0
+    assert lib.gcnx_collate(h, None, 0, None, None, None, None, None, 0, 0, None, 0, None, None, None, None, 0, None, None, None) == 0
     ib = ctx.zeros(8, np.int32)
     assert lib.gcnx_collate(h, ib.ptr, 1, ib.ptr, ib.ptr, ib.ptr, buf.ptr, buf.ptr, 4, 4, None, 0, ib.ptr, ib.ptr, None, buf.ptr, 4,
-                            None, ib.ptr) == 1
+                            None, ib.ptr, None) == 1
     assert "values in and out" in _lib.last_error(h)
 
 

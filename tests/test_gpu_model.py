@@ -146,6 +146,8 @@ def test_device_side_collate_equals_host_loader(ctx):
         assert np.array_equal(dbatch.a.vals.numpy()[:dbatch.a.nnz], hbatch.a.vals.numpy()[:hbatch.a.nnz])
         assert np.array_equal(dbatch.y.numpy(), hbatch.y.numpy())
         assert np.array_equal(dbatch.seg.dev.numpy(), hbatch.seg.dev.numpy())
+        assert np.array_equal(dbatch.seg.ids.numpy(), np.asarray(inputs[2], np.int32))      # the id vector i, written by the collate
+        assert np.array_equal(hbatch.seg.ids.numpy(), np.asarray(inputs[2], np.int32))      # ... and rebuilt from graph_ptr
         l1 = m1.train_step(hbatch, None, lr=0.05)
         l2 = m2.train_step(dbatch, None, lr=0.05)
         assert l1 == l2
