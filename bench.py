@@ -375,14 +375,15 @@ def main():
     if getattr(model, "_fused", None) and model._fused(batch):
         s_buf = ctx.empty((hb.n, hb.f)); y_buf = ctx.empty((hb.n, hidden))
         for _ in range(5):
-            D.gcn_conv_fwd(ctx, a, batch.x, model.p["w1"], model.p["b1"], y_buf, act="relu", s=s_buf)
+            D.gcn_conv_fwd(ctx, a, batch.x, model.p["w1"], model.p["b1"], y_buf, act="relu", s=s_buf, prec=args.prec)
         e0 = ctx.event().record()
         for _ in range(iters):
-            D.gcn_conv_fwd(ctx, a, batch.x, model.p["w1"], model.p["b1"], y_buf, act="relu", s=s_buf)
+            D.gcn_conv_fwd(ctx, a, batch.x, model.p["w1"], model.p["b1"], y_buf, act="relu", s=s_buf, prec=args.prec)
         e1 = ctx.event().record()
         f_ms = e1.elapsed_ms_since(e0) / iters
         f_alg = 4 * (hb.n + 1) + 8 * hb.nnz + 4 * hb.n * hb.f * 2 + 4 * hb.n * hidden + 4 * hb.f * hidden
-        fused = {"kernel": "gcn_conv_fused_kernel: gather + fp32 MFMA (16x16x4) dense + bias/ReLU, S = A X saved; what the "
+        fused = {"kernel": "gcn_conv_fused_kernel: gather + " + ("fp32 MFMA (16x16x4)" if args.prec == "f32" else "split-bf16 MFMA (16x16x32 x 3)") +
+                           " dense + bias/ReLU, S = A X saved; what the "
                            "training step launches per GCNConv at this config instead of gcnx_gemm + gcnx_spmm_csr",
                  "bound": "hbm", "achieved": f_alg / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": f_alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": f_alg,

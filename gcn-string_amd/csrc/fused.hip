@@ -26,6 +26,7 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fbf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kFRows = 32;        // rows per workgroup
 constexpr int kFCap = 1024;       // CSR entries of a tile staged in LDS (the rest is read from global memory)
@@ -71,7 +72,10 @@ __device__ __forceinline__ float4 f4step(float4 a) {
   return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
 
-template <int K, bool WEIGHTED, bool BWD>
+// X3: the product phase on the bf16 MFMA with split operands (hi = bf16(x), lo = bf16(x - hi); hi*lo + lo*hi + hi*hi, fp32
+// accumulate: GCNX_PREC_BF16X3, ~2^-17 per operand) instead of exact fp32 products -- three 16x16x32 MFMAs per 32 k where
+// the fp32 path issues eight 16x16x4.
+template <int K, bool WEIGHTED, bool BWD, bool X3 = false>
 __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   constexpr int LPR = K / 4;                 // lanes per gathered row
   constexpr int GW = 64 / LPR;               // row groups per wave
@@ -193,17 +197,32 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   // ---- this wave's slice of W, in the MFMA B layout; in flight while the tile is written -------------------------
   const int c16 = lane & 15, kq = lane >> 4;
   const bool wave_on = 16 * wave < p.nc;
+  // register e of the slice holds k = 4 e + (l >> 4) (fp32 MFMA: 16x16x4 B layout) or k = 32 (e / 8) + 8 (l >> 4) + e % 8
+  // (bf16 MFMA: 16x16x32 B layout, eight consecutive k per lane)
+  auto k_of = [&](int e) { return X3 ? 32 * (e / 8) + 8 * kq + (e % 8) : 4 * e + kq; };
   float wreg[K / 4];
   if (wave_on && !(dbg & 4)) {
 #pragma unroll
-    for (int kk = 0; kk < K / 4; ++kk)
-      wreg[kk] = (BWD && !p.w_t) ? p.w[(int64_t)(16 * wave + c16) * p.ldw + 4 * kk + kq]     // W2 [nc, K]: strided
-                                 : p.w[(int64_t)(4 * kk + kq) * p.ldw + 16 * wave + c16];    // [K, nc]: 64-byte row pieces
+    for (int e = 0; e < K / 4; ++e)
+      wreg[e] = (BWD && !p.w_t) ? p.w[(int64_t)(16 * wave + c16) * p.ldw + k_of(e)]     // W2 [nc, K]: strided
+                                : p.w[(int64_t)k_of(e) * p.ldw + 16 * wave + c16];      // [K, nc]: 64-byte row pieces
     if (!BWD && p.wt_out && (int)blockIdx.x < K / 4) {   // W^T, dealt over the first K / 4 workgroups (uniform tests: wreg
 #pragma unroll                                          // stays in registers)
-      for (int kk = 0; kk < K / 4; ++kk)
-        if (kk % ntiles == (int)blockIdx.x) p.wt_out[(int64_t)(16 * wave + c16) * K + 4 * kk + kq] = wreg[kk];
+      for (int e = 0; e < K / 4; ++e)
+        if (e % ntiles == (int)blockIdx.x) p.wt_out[(int64_t)(16 * wave + c16) * K + k_of(e)] = wreg[e];
     }
+  }
+  fbf16x8 wh[X3 ? K / 32 : 1], wl[X3 ? K / 32 : 1];
+  if (X3) {
+#pragma unroll
+    for (int st = 0; st < K / 32; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = wave_on ? wreg[st * 8 + j] : 0.f;
+        const __bf16 h = (__bf16)v;
+        wh[st][j] = h;
+        wl[st][j] = (__bf16)(v - (float)h);
+      }
   }
   if (gid < kFRows) {
 #pragma unroll
@@ -240,13 +259,36 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   }
   const float bcol = (!BWD && p.bias) ? p.bias[col] : 0.f;
   f32x4v c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-  if (!(dbg & 2))
+  if (X3) {
+    if (!(dbg & 2))
 #pragma unroll
-  for (int kk = 0; kk < K / 4; ++kk) {
-    const float a0 = tile[c16][4 * kk + kq];
-    const float a1 = tile[16 + c16][4 * kk + kq];
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[kk], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[kk], c1, 0, 0, 0);
+    for (int st = 0; st < K / 32; ++st) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const float* ap = &tile[16 * hf + c16][32 * st + 8 * kq];
+        const float4 x0 = *reinterpret_cast<const float4*>(ap), x1 = *reinterpret_cast<const float4*>(ap + 4);
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        fbf16x8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 h = (__bf16)xv[j];
+          ah[j] = h;
+          al[j] = (__bf16)(xv[j] - (float)h);
+        }
+        f32x4v& cc = hf ? c1 : c0;
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st], cc, 0, 0, 0);     // small terms first
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st], cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st], cc, 0, 0, 0);
+      }
+    }
+  } else if (!(dbg & 2)) {
+#pragma unroll
+    for (int kk = 0; kk < K / 4; ++kk) {
+      const float a0 = tile[c16][4 * kk + kq];
+      const float a1 = tile[16 + c16][4 * kk + kq];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[kk], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[kk], c1, 0, 0, 0);
+    }
   }
   float cs = 0.f;
 #pragma unroll
@@ -266,7 +308,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
 }
 
 template <bool BWD>
-int launch_fused(gcnx_ctx* ctx, const FusedArgs& a_in, int k) {
+int launch_fused(gcnx_ctx* ctx, const FusedArgs& a_in, int k, bool x3) {
   FusedArgs a = a_in;
 #ifdef GCNX_TUNING
   if (const char* e = getenv("GCNX_FUSED_DBG")) a.dbg = atoi(e);
@@ -278,7 +320,10 @@ int launch_fused(gcnx_ctx* ctx, const FusedArgs& a_in, int k) {
 #endif
 #define GCNX_FUSED_LAUNCH(K_)                                                                                         \
   do {                                                                                                                \
-    if (a.vals) hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, true, BWD>), dim3(tiles), dim3(512), dyn, ctx->stream, a); \
+    if (x3) {                                                                                                         \
+      if (a.vals) hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, true, BWD, true>), dim3(tiles), dim3(512), dyn, ctx->stream, a); \
+      else hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, false, BWD, true>), dim3(tiles), dim3(512), dyn, ctx->stream, a);      \
+    } else if (a.vals) hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, true, BWD>), dim3(tiles), dim3(512), dyn, ctx->stream, a); \
     else hipLaunchKernelGGL((gcn_conv_fused_kernel<K_, false, BWD>), dim3(tiles), dim3(512), dyn, ctx->stream, a);      \
   } while (0)
   if (k == 128) GCNX_FUSED_LAUNCH(128);
@@ -304,9 +349,11 @@ int gcnx_gcn_conv_fused_ok(int64_t n, int32_t fi, int32_t fo, int64_t ldx) { ret
 
 int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* x,
                       int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo, const float* bias, int act, float* s,
-                      int64_t lds, float* out, int64_t ldo, float* wt_out) {
+                      int64_t lds, float* out, int64_t ldo, float* wt_out, int prec) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gcn_conv_fwd: negative size");
+  if (prec != GCNX_PREC_F32 && prec != GCNX_PREC_BF16X3)
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_fwd: precision %d (GCNX_PREC_F32 or GCNX_PREC_BF16X3 here)", prec);
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_gcn_conv_fwd: activation %d not supported here", act);
   if (n == 0 || fo == 0) return GCNX_OK;
   if (!fused_shape_ok(n, fi, fo, ldx))
@@ -320,7 +367,7 @@ int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colid
   FusedArgs a{};
   a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.x = x; a.ldx = ldx; a.n = n; a.w = w; a.ldw = fo; a.nc = fo;
   a.bias = bias; a.act = act; a.s = s; a.lds = lds; a.out = out; a.ldo = ldo; a.wt_out = wt_out;
-  return launch_fused<false>(ctx, a, fi);
+  return launch_fused<false>(ctx, a, fi, prec == GCNX_PREC_BF16X3);
 }
 
 int64_t gcnx_gcn_conv_bwd_scratch_floats(int64_t n, int32_t f1) { return n <= 0 || f1 <= 0 ? 0 : (int64_t)gcnx_cdiv(n, kFRows) * f1; }
@@ -329,8 +376,10 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
                            const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
                            const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
                            int w2_transposed, const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
-                           float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending) {
+                           float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec) {
   GCNX_CHECK_CTX(ctx);
+  if (prec != GCNX_PREC_F32 && prec != GCNX_PREC_BF16X3)
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_bwd_pool: precision %d (GCNX_PREC_F32 or GCNX_PREC_BF16X3 here)", prec);
   if (pending) *pending = gcnx_pending_reduce{nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr};
   GCNX_REQUIRE(ctx, n >= 0 && f1 >= 0 && f2 >= 0 && b >= 0, "gcnx_gcn_conv_bwd_pool: negative size");
   GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
@@ -365,7 +414,7 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
   a.rowptr = rowptr_t; a.colidx = colidx_t; a.vals = vals_t; a.x = y2; a.ldx = ldy2; a.n = n; a.w = w2; a.ldw = w2_transposed ? f1 : f2; a.w_t = w2_transposed ? 1 : 0; a.nc = f1;
   a.out = dz1; a.ldo = lddz1; a.node_graph = node_graph; a.gp = graph_ptr; a.dp = dpooled; a.lddp = lddp;
   a.avg = mode == GCNX_POOL_AVG ? 1 : 0; a.mask = y1; a.ldmask = ldy1; a.dz2 = dz2; a.lddz2 = lddz2; a.colpart = colpart;
-  int rc = launch_fused<true>(ctx, a, f2);
+  int rc = launch_fused<true>(ctx, a, f2, prec == GCNX_PREC_BF16X3);
   if (rc) return rc;
   if (db1) {
     if (defer) *pending = gcnx_pending_reduce{colpart, tiles, f1, db1, nullptr, 0, 0, nullptr};

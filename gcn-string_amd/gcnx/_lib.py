@@ -93,10 +93,10 @@ SIGNATURES = {
     "gcnx_dense_bwd_deferred": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                 _i64, _vp],
     "gcnx_gcn_conv_fused_ok": [_i64, _i32, _i32, _i64],
-    "gcnx_gcn_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _int, _vp, _i64, _vp, _i64, _vp],
+    "gcnx_gcn_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _int, _vp, _i64, _vp, _i64, _vp, _int],
     "gcnx_gcn_conv_bwd_scratch_floats": [_i64, _i32],
     "gcnx_gcn_conv_bwd_pool": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _int, _i32, _i32, _vp, _i32, _int, _vp, _i64,
-                               _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
+                               _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _int],
     "gcnx_gemm_dw2": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _int, _vp, _vp,
                       _i64, _f32, _vp],
     "gcnx_comm_unique_id": [C.c_char_p],

@@ -451,18 +451,18 @@ def gcn_conv_fused_ok(ctx, n, fi, fo, ldx=None):
     return bool(ctx.lib.gcnx_gcn_conv_fused_ok(int(n), int(fi), int(fo), int(ldx if ldx is not None else fi)))
 
 
-def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None, wt=None):
+def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None, wt=None, prec="f32"):
     """out = act((A x) w + bias) in one launch; s (optional) receives A x, wt (optional, [fo, fi]) w^T
     (gcnx_gcn_conv_fwd)."""
     n, fi = x.shape
     fo = w.shape[1]
     assert a.n == n and w.shape[0] == fi and w.contiguous and out.shape == (n, fo) and (s is None or s.shape == (n, fi))
     ctx._ck(ctx.lib.gcnx_gcn_conv_fwd(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(x), x.ld, n, fi, _p(w), fo, _p(bias),
-                                      L.ACTS[act], _p(s), s.ld if s is not None else 0, _p(out), out.ld, _p(wt)))
+                                      L.ACTS[act], _p(s), s.ld if s is not None else 0, _p(out), out.ld, _p(wt), L.PRECS[prec]))
     return out
 
 
-def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mode="sum", scratch=None, w2t=None):
+def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mode="sum", scratch=None, w2t=None, prec="f32"):
     """dz2 = pool'(dpooled) * [y2 > 0], dz1 = ((A^T dz2) w2^T) * [y1 > 0], db1 = column sums of dz1 -- one launch
     (gcnx_gcn_conv_bwd_pool).  With ``scratch`` the db1 reduction is left pending: returns the PendingReduce for
     gemm_dw2 (all zeros when nothing is pending).  w2t: w2^T as written by gcn_conv_fwd(wt=...), read instead of w2."""
@@ -475,7 +475,7 @@ def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mod
                                            seg.dev.ptr, seg.n_graphs, _p(dpooled), dpooled.ld, L.POOLS[mode], n, f2,
                                            _p(w2t if w2t is not None else w2), f1, 1 if w2t is not None else 0, _p(y1), y1.ld, _p(dz2), dz2.ld if dz2 is not None else 0, _p(dz1), dz1.ld, _p(db1),
                                            _p(scratch), scratch.size if scratch is not None else 0,
-                                           C.byref(pend) if scratch is not None else None))
+                                           C.byref(pend) if scratch is not None else None, L.PRECS[prec]))
     return pend
 
 

@@ -126,7 +126,8 @@ class GCNConv(Layer):
         if self._one_launch(x, a):
             # small-feature regime: (A x) W in one launch (csrc/fused.hip); S = A x is kept for dW = S^T dZ
             s = self._buf("s", (n, x.shape[1]))
-            D.gcn_conv_fwd(self.ctx, a, x, self.params["kernel"], self.params.get("bias"), y, act=self.activation, s=s)
+            D.gcn_conv_fwd(self.ctx, a, x, self.params["kernel"], self.params.get("bias"), y, act=self.activation, s=s,
+                           prec=self.prec)
             self._saved = (x, a, y, s)
             return y
         h = self._buf("h", (n, self.channels))
@@ -136,7 +137,7 @@ class GCNConv(Layer):
         return y
 
     def _one_launch(self, x, a):
-        return (self.prec == "f32" and getattr(a, "plan", None) is None and x.contiguous and os.environ.get("GCNX_FUSED", "1") != "0"
+        return (self.prec in ("f32", "bf16x3") and getattr(a, "plan", None) is None and x.contiguous and os.environ.get("GCNX_FUSED", "1") != "0"
                 and D.gcn_conv_fused_ok(self.ctx, x.shape[0], x.shape[1], self.channels, x.ld))
 
     def backward(self, dy, need_dx=True, dy_is_dz=False):

@@ -205,9 +205,10 @@ class GCN2(_GraphRunner):
             # small-feature regime: each GCNConv is one launch, evaluated as (A X) W (gcnx_gcn_conv_fwd); A X is kept
             # for the weight gradient when a backward pass follows
             keep = with_loss == "grads"
-            D.gcn_conv_fwd(ctx, batch.a, batch.x, p["w1"], p["b1"], bufs["y1"], act="relu", s=bufs["s1"] if keep else None)
+            D.gcn_conv_fwd(ctx, batch.a, batch.x, p["w1"], p["b1"], bufs["y1"], act="relu", s=bufs["s1"] if keep else None,
+                           prec=prec)
             D.gcn_conv_fwd(ctx, batch.a, bufs["y1"], p["w2"], p["b2"], bufs["y2"], act="relu", s=bufs["s2"] if keep else None,
-                           wt=bufs["w2t"] if keep else None)
+                           wt=bufs["w2t"] if keep else None, prec=prec)
         else:
             D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
             D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
@@ -247,12 +248,12 @@ class GCN2(_GraphRunner):
             # the head), then both weight gradients -- dW1 = S1^T dZ1, dW2 = S2^T dZ2 -- and the update in the last two
             pend = D.gcn_conv_bwd_pool(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], p["w2"], bufs["y1"], bufs["dz"],
                                        bufs["dz2"], db1=g["b1"], mode=self.pool, scratch=self._defer_scratch(batch),
-                                       w2t=bufs["w2t"])
+                                       w2t=bufs["w2t"], prec=prec)
             if lr is None:
-                D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec=prec,
+                D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec="f32",
                            grads=self.flat_g.flat(0, self.n_params), pending=pend)
                 return False
-            D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec=prec, params=self.flat_p,
+            D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec="f32", params=self.flat_p,
                        grads=self.flat_g.flat(0, self.n_params), lr=lr, pending=pend)
             return True
         if fold:
@@ -304,8 +305,10 @@ class GCN2(_GraphRunner):
 
     def _fused(self, batch):
         """The small-feature regime (config 2): every GCNConv and the backward from the pool down to dZ1 are single
-        launches (csrc/fused.hip).  Needs the folded backward's conditions, fp32 products and F, H in {32, 64, 128}."""
-        return (self.built and self._fold(batch) and self.prec == "f32" and os.environ.get("GCNX_FUSED", "1") != "0"
+        launches (csrc/fused.hip).  Needs the folded backward's conditions and F, H in {32, 64, 128}; prec "f32" (exact
+        fp32 products) or "bf16x3" (split-bf16 products in the conv launches; the two weight gradients stay on the fp32
+        MFMA -- sums over N rows, at least as accurate)."""
+        return (self.built and self._fold(batch) and self.prec in ("f32", "bf16x3") and os.environ.get("GCNX_FUSED", "1") != "0"
                 and os.environ.get("GCNX_DUO", "1") != "0" and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.f_in, self.hidden)
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))

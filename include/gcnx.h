@@ -364,10 +364,12 @@ GCNX_API int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const 
 GCNX_API int gcnx_gcn_conv_fused_ok(int64_t n, int32_t fi, int32_t fo, int64_t ldx);
 /* out[n, fo] = act((A x) w + bias), A in CSR (vals NULL: all ones); s (may be NULL) receives S = A x [n, fi], the
  * operand of the weight gradient dW = S^T dZ (gcnx_gemm_dw2).  wt_out (may be NULL) receives w^T [fo, fi], the layout
- * gcnx_gcn_conv_bwd_pool reads its weight operand fastest in.  act: GCNX_ACT_NONE / GCNX_ACT_RELU. */
+ * gcnx_gcn_conv_bwd_pool reads its weight operand fastest in.  act: GCNX_ACT_NONE / GCNX_ACT_RELU.  prec: GCNX_PREC_F32
+ * (exact fp32 products on the fp32 MFMA) or GCNX_PREC_BF16X3 (split-bf16 on the bf16 MFMA); the gather is fp32 either way. */
 GCNX_API int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                       const float* x, int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo,
-                      const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out);
+                      const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out,
+                      int prec);
 /* Backward from the global pool down to the pre-activation gradient of the layer below, one launch:
  *   dZ2[j] = pool'(dpooled)[graph(j)] * [y2[j] > 0]                      (GlobalSumPool / GlobalAvgPool', ReLU')
  *   dz1    = ((A^T dZ2) w2^T) * [y1 > 0]                                 (aggregation', MatMul', ReLU' of layer 1)
@@ -383,7 +385,7 @@ GCNX_API int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, cons
                       const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
                       const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
                       int w2_transposed, const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
-                      float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending);
+                      float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec);
 /* Two weight gradients in one launch, dwa = xa^T dha [fia, foa] and dwb = xb^T dhb [fib, fob] over the same n rows
  * (MatMul grads wrt the kernels, gcn.py:337), both inside the flat gradient buffer `grads`; with params != NULL the
  * reduction launch also applies p -= lr * g to all n_params parameters and finishes `pending` (column sums left by

@@ -939,9 +939,10 @@ def test_sgd_and_graph_capture_replay(ctx):
 
 # ---- GCNConv as one launch (csrc/fused.hip) -------------------------------------------------------------------------
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("fi,fo", [(128, 128), (64, 128), (32, 16), (128, 48), (64, 64)])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_gcn_conv_fused_forward(ctx, fi, fo, weighted):
+def test_gcn_conv_fused_forward(ctx, fi, fo, weighted, prec):
     """gcnx_gcn_conv_fwd = relu((A X) W + b) and S = A X against the float64 oracle chain dense -> aggregation
     (GCNConv.call order A (X W)); ragged last tile (N % 32 != 0), rows with more than 4 entries per trip."""
     from gcnx import device as D, synth
@@ -954,13 +955,14 @@ def test_gcn_conv_fused_forward(ctx, fi, fo, weighted):
     bias = rng.standard_normal(fo).astype(np.float32)
     assert D.gcn_conv_fused_ok(ctx, hb.n, fi, fo)
     out = ctx.empty((hb.n, fo)); s = ctx.empty((hb.n, fi)); wt = ctx.zeros((fo, fi))
-    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), ctx.to_device(bias), out, act="relu", s=s, wt=wt)
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), ctx.to_device(bias), out, act="relu", s=s, wt=wt, prec=prec)
     assert np.array_equal(wt.numpy(), w.T)                                # the transposed weight by-product
     ref = _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64), bias, True)
-    assert rel_err(out.numpy(), ref) < TIGHT
-    assert rel_err(s.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT
-    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), None, out, act=None)      # inference surface: no S
-    assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64))) < TIGHT
+    tol = TIGHT if prec == "f32" else 5e-5                                # split-bf16 products: 2^-17 per operand
+    assert rel_err(out.numpy(), ref) < tol
+    assert rel_err(s.numpy(), _ref_spmm(hb, vals, hb.x)) < TIGHT            # the gather is fp32 either way
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.to_device(w), None, out, act=None, prec=prec)   # inference surface: no S
+    assert rel_err(out.numpy(), _ref_spmm(hb, vals, hb.x.astype(np.float64) @ w.astype(np.float64))) < tol
 
 
 def test_gcn_conv_fused_long_rows_and_refusals(ctx):
@@ -980,9 +982,10 @@ def test_gcn_conv_fused_long_rows_and_refusals(ctx):
         D.gcn_conv_fwd(ctx, a, ctx.to_device(hb.x), ctx.zeros((64, 256)), None, ctx.empty((hb.n, 256)))
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("f1,f2", [(128, 128), (64, 128), (128, 32)])
 @pytest.mark.parametrize("mode", ["sum", "avg"])
-def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode):
+def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode, prec):
     """gcnx_gcn_conv_bwd_pool + gcnx_gemm_dw2 against the oracle's unfused chain: pool' -> ReLU' -> A^T -> W2^T -> ReLU',
     column sums, the two weight gradients and the SGD step; non-symmetric values so that the transpose matters; the db1
     reduction both immediate and pending."""
@@ -1005,12 +1008,13 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode):
     seg = Segments(ctx, hb.graph_ptr)
     dz2 = ctx.empty((n, f2)); dz1 = ctx.empty((n, f1)); db1 = ctx.empty(f1)
     args = (ctx, a.transpose(), ctx.to_device(y2), seg, ctx.to_device(dp), ctx.to_device(w2), ctx.to_device(y1), dz2, dz1)
-    pend = D.gcn_conv_bwd_pool(*args, db1=db1, mode=mode)
+    tol = TIGHT if prec == "f32" else 5e-5
+    pend = D.gcn_conv_bwd_pool(*args, db1=db1, mode=mode, prec=prec)
     assert not pend.colpart                                              # no scratch: db1 is final
-    assert rel_err(dz2.numpy(), rdz2) < TIGHT and rel_err(dz1.numpy(), rdz1) < TIGHT
-    assert rel_err(db1.numpy(), rdz1.sum(0)) < TIGHT
+    assert rel_err(dz2.numpy(), rdz2) < TIGHT and rel_err(dz1.numpy(), rdz1) < tol
+    assert rel_err(db1.numpy(), rdz1.sum(0)) < tol
     first = (dz2.numpy().copy(), dz1.numpy().copy(), db1.numpy().copy())
-    D.gcn_conv_bwd_pool(*args, db1=db1, mode=mode, w2t=ctx.to_device(np.ascontiguousarray(w2.T)))   # weight operand pre-transposed
+    D.gcn_conv_bwd_pool(*args, db1=db1, mode=mode, w2t=ctx.to_device(np.ascontiguousarray(w2.T)), prec=prec)   # weight operand pre-transposed
     assert all(np.array_equal(x, y) for x, y in zip(first, (dz2.numpy(), dz1.numpy(), db1.numpy())))
     # pending form + both weight gradients + SGD in the flat buffers
     n_par = 32 * f1 + f1 * f2 + f1
@@ -1018,14 +1022,14 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode):
     p0 = params.numpy().copy()
     gw1, gw2, gb1 = grads.flat(0, 32 * f1, (32, f1)), grads.flat(32 * f1, f1 * f2, (f1, f2)), grads.flat(32 * f1 + f1 * f2, f1)
     scratch = ctx.empty(D.gcn_conv_bwd_scratch_floats(ctx, n, f1))
-    pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch)
+    pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch, prec=prec)
     assert pend.colpart
     D.gemm_dw2(ctx, ctx.to_device(s1), dz1, gw1, ctx.to_device(s2), dz2, gw2, params=params, grads=grads, lr=0.05, pending=pend)
     rg = np.concatenate([(s1.astype(np.float64).T @ rdz1).ravel(), (s2.astype(np.float64).T @ rdz2).ravel(), rdz1.sum(0)])
-    assert rel_err(grads.numpy(), rg) < TIGHT
-    assert rel_err(params.numpy(), p0 - 0.05 * rg) < TIGHT
+    assert rel_err(grads.numpy(), rg) < tol
+    assert rel_err(params.numpy(), p0 - 0.05 * rg) < tol
     # gradients only (the multi-GPU path: all-reduce first, update later)
     grads.fill_zero()
-    pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch)
+    pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch, prec=prec)
     D.gemm_dw2(ctx, ctx.to_device(s1), dz1, gw1, ctx.to_device(s2), dz2, gw2, grads=grads, pending=pend)
-    assert rel_err(grads.numpy(), rg) < TIGHT
+    assert rel_err(grads.numpy(), rg) < tol
