@@ -1,7 +1,4 @@
 #!/bin/bash
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "fused or golden or train or bf16" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
-tail -2 gpurun_out/t.log
-for p in f32 bf16x3; do
-python bench.py --prec $p --steps 300 --warmup 30 --cpu-seconds 0 --no-config3 > gpurun_out/b2.json 2>gpurun_out/b2.err && python -c "
-import json; d=json.load(open('gpurun_out/b2.json')); print('$p', d['ms_per_step'], d['m1_median']['ms_per_step'], d['final_loss'], d.get('roofline_step_kernel',{}).get('avg_launch_us'))"
-done
+GCNX_DW_DIRECT=1 timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "fused_backward" 2>&1 | tail -2
+python scripts/fused_bench.py | grep dw2
+for sl in 16 32 64; do for d in 0 3; do echo "slices $sl dbg $d"; GCNX_DW_SLICES=$sl GCNX_DW_DBG=$d GCNX_DW_DIRECT=1 python scripts/fused_bench.py | grep dw2; done; done
