@@ -311,6 +311,50 @@ def test_rccl_path_single_rank(ctx):
     assert np.array_equal(d.numpy(), x) and float(c1.allreduce_host([3.5], "max")[0]) == 3.5
 
 
+def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx):
+    """The code path a rank of an N-GPU run takes -- gradients (fold-only reductions), ncclAllReduce and SGD recorded into
+    ONE HIP graph -- with a real RCCL communicator.  One GPU is all there is here, so the communicator has one rank and
+    the wrapper only CLAIMS a world of two: the collective is then the identity and the step must equal the plain
+    single-process step bit for bit (same kernels, same order), through capture and replay."""
+    import ctypes as C
+    from gcnx import _lib as L, synth
+    from gcnx.comm import Communicator
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GCN2
+
+    class OneRankPosingAsTwo(Communicator):
+        def __init__(self, ctx):
+            self.ctx, self.rank, self.world_size = ctx, 0, 2
+            uid = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+            L.check(ctx.lib.gcnx_comm_unique_id(uid))
+            h = C.c_void_p()
+            ctx._ck(ctx.lib.gcnx_comm_init_rank(ctx.h, uid.raw, 1, 0, C.byref(h)))
+            self.h, self._scratch, self._path = h, ctx.zeros(4), None
+
+    hb = synth.ecoli_batch(6, 128, seed=21)
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+
+    def run(comm):
+        a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+        batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+        m = GCN2(ctx, 2, seed=5, comm=comm)
+        out = [m.train_step(batch, None, lr=0.05, global_batch=hb.n_graphs) for _ in range(4)]   # eager, capture, replay x2
+        return m, out
+
+    comm = OneRankPosingAsTwo(ctx)
+    try:
+        m2, o2 = run(comm)
+        assert m2._comm_in_graph() and not getattr(m2, "_comm_capture_failed", False)
+        assert m2._fused(DeviceBatch(ctx, ctx.to_device(hb.x), DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr),
+                                     Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y)))
+        m1, o1 = run(None)
+        assert o1 == o2
+        for w1, w2 in zip(m1.get_weights(), m2.get_weights()):
+            assert np.array_equal(w1, w2)
+    finally:
+        comm.close()
+
+
 def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
     """The sharded step on the DEVICE path at world_size 2: two ranks (threads, each with its own Context on device
     0, a host-mediated communicator of the Communicator interface, tests/thread_comm.py) take graph shards of one
