@@ -564,25 +564,31 @@ template <int THREADS, int FT> struct DuoShape {
 // A^T (pool'(dPooled) * [Y > 0]) -- the landed tile is turned into its 0 / 1 mask in place (one pass over the tile:
 // every element is gathered ~degree times, so masking it once is that much cheaper than masking every use), and the
 // graph's dPooled row (x 1 / n_g for the average pool) multiplies the finished sums where the bias is added otherwise.
+// MODE 2 / 3, the bit image of a ReLU output (r2): the forward launch of the pooled layer also writes [out > 0] as one
+// 32-bit word per (row, 32-column slab), slab-major (`bits[slab * n + row]`: a unit's words are contiguous), and the folded
+// backward expands those words into the 0 / 1 tile instead of DMA-ing the fp32 slab and masking it -- 4 bytes per row
+// and slab where the fp32 source is 128 (config 3: 1 GB of reads per step become 32 MB).
 struct DuoFold {
   const int32_t* gids;     // graph index of every entry of `graphs`
   const float* dp;         // dPooled [b, f]
   int64_t lddp;
   int avg;
+  uint32_t* bits;          // MODE 2: written; MODE 3: read
 };
+enum { kDuoPlain = 0, kDuoFold = 1, kDuoBitsOut = 2, kDuoFoldBits = 3 };
 
-template <int THREADS, int FT, int LPR, bool WEIGHTED, bool FOLD = false>
+template <int THREADS, int FT, int LPR, bool WEIGHTED, int MODE = kDuoPlain>
 __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
     const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
     const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */,
     int sg /* column slabs per unit */, int act, int nunits, int n, int dbg_rt, DuoFold fo) {
-#ifdef GCNX_TUNING
-  const int dbg = dbg_rt;                       // phase-ablation bits of a tuning build (results are wrong by design)
-#else
-  constexpr int dbg = 0;                        // release build: the ablation tests fold away
-  (void)dbg_rt;
-#endif
+  // Phase-ablation bits (results are wrong by design when set).  The HOST passes 0 unless this is a tuning build
+  // (launch_duo), so a release library cannot be talked into wrong results; the tests stay in the kernel as uniform
+  // branches on purpose: with them folded away at compile time hipcc's allocation of this 128-VGPR kernel spilled 6.
+  const int dbg = dbg_rt;
+  constexpr bool FOLD = MODE == kDuoFold || MODE == kDuoFoldBits;
+  static_assert(MODE == kDuoPlain || MODE == kDuoFold || FT == 32, "the bit image has one 32-bit word per row and slab");
   constexpr int CPL = FT / (4 * LPR);           // float4 chunks per lane (2 only with LPR = 4, FT = 32)
   constexpr int RPW = 64 / LPR;                 // rows per wave
   constexpr int SPAN = (THREADS / 64) * RPW;
@@ -639,7 +645,14 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
       __builtin_amdgcn_s_barrier();
       unsigned ld32 = (unsigned)ldh;
       asm volatile("" : "+s"(ld32));            // opaque per step: the piece offsets are recomputed, not hoisted and spilled
-      if (!(dbg & 1)) tile_dma32<FT / 4, THREADS, CAP * (FT / 4)>(lds, h + (int64_t)g.x * ldh + c0, ld32, g.y);
+      if constexpr (MODE == kDuoFoldBits) {     // the 0 / 1 tile straight from the bit image: 8 threads per row, one float4 each
+        const uint32_t* bw = fo.bits + (size_t)(c0 / FT) * (size_t)n + g.x;
+        float4* t4 = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < g.y * (FT / 4); i += THREADS) {
+          const unsigned nib = bw[i >> 3] >> ((i & 7) * 4);
+          t4[i] = make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
+        }
+      } else if (!(dbg & 1)) tile_dma32<FT / 4, THREADS, CAP * (FT / 4)>(lds, h + (int64_t)g.x * ldh + c0, ld32, g.y);
       if (s == 0) for (int i = tid; i <= g.y; i += THREADS) rp[i] = rowptr[g.x + i];
       if (FOLD) {
         if (tid < FT) lbias[tid] = fo.dp[(int64_t)fo.gids[u / upg] * fo.lddp + c0 + tid] * (fo.avg ? 1.0f / (float)g.y : 1.0f);
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
         if (tid < FT) lbias[tid] = bias ? bias[c0 + tid] : 0.f;
       }
       __syncthreads();                          // the tile (and on s == 0 the index burst) has landed
-      if (FOLD) {                               // Y -> [Y > 0], in place
+      if constexpr (MODE == kDuoFold) {         // Y -> [Y > 0], in place
         float4* t4 = reinterpret_cast<float4*>(lds);
         for (int i = tid; i < g.y * (FT / 4); i += THREADS) t4[i] = f4_step(t4[i]);
         __syncthreads();
@@ -678,6 +691,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
             base += 16;
           }
         }
+        [[maybe_unused]] unsigned bword = 0;
         if (r < g.y && !(dbg & 4)) {
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
@@ -688,7 +702,15 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
             *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
+            if constexpr (MODE == kDuoBitsOut)
+              bword |= ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u))
+                       << (4 * (sub + LPR * (j ^ csw)));
           }
+        }
+        if constexpr (MODE == kDuoBitsOut) {      // the quad's four lanes hold the row's 32 columns: one word per row
+          bword |= __shfl_xor(bword, 1);
+          bword |= __shfl_xor(bword, 2);
+          if (sub == 0 && r < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
         }
       }
     }
@@ -1015,18 +1037,16 @@ void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, 
 template <int THREADS, int FT, int LPR>
 int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-               const int2* graphs, int ngraphs, const DuoFold* fold = nullptr) {
+               const int2* graphs, int ngraphs, const DuoFold* fold = nullptr, int mode = kDuoPlain) {
   constexpr int lds_bytes = DuoShape<THREADS, FT>::LDSF * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+#define GCNX_DUO_ATTR(W, M)                                                                                                  \
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, W, M>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
+    GCNX_DUO_ATTR(true, kDuoPlain); GCNX_DUO_ATTR(false, kDuoPlain); GCNX_DUO_ATTR(true, kDuoFold); GCNX_DUO_ATTR(false, kDuoFold);
+    GCNX_DUO_ATTR(true, kDuoBitsOut); GCNX_DUO_ATTR(false, kDuoBitsOut); GCNX_DUO_ATTR(true, kDuoFoldBits); GCNX_DUO_ATTR(false, kDuoFoldBits);
+#undef GCNX_DUO_ATTR
     attr_set = true;
   }
   int dbg = 0;
@@ -1046,20 +1066,27 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, cons
   const long long nunits = (long long)ngraphs * upg;
   if (nunits >= 2000000000LL) return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: too many work units");
   const int grid = (int)(nunits < full ? nunits : full);
-  const DuoFold nofold{nullptr, nullptr, 0, 0};
-  if (fold) {
-    if (vals)
-      hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
-                         colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, *fold);
-    else
-      hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, false, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
-                         colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, *fold);
-  } else if (vals)
-    hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
-                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, nofold);
-  else
-    hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, false>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
-                       colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, nofold);
+  const DuoFold nofold{nullptr, nullptr, 0, 0, nullptr};
+  const DuoFold fo = fold ? *fold : nofold;
+#define GCNX_DUO_LAUNCH(W, M)                                                                                                \
+  hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, W, M>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, colidx, \
+                     vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo)
+  if (vals) {
+    switch (mode) {
+      case kDuoFold: GCNX_DUO_LAUNCH(true, kDuoFold); break;
+      case kDuoBitsOut: GCNX_DUO_LAUNCH(true, kDuoBitsOut); break;
+      case kDuoFoldBits: GCNX_DUO_LAUNCH(true, kDuoFoldBits); break;
+      default: GCNX_DUO_LAUNCH(true, kDuoPlain); break;
+    }
+  } else {
+    switch (mode) {
+      case kDuoFold: GCNX_DUO_LAUNCH(false, kDuoFold); break;
+      case kDuoBitsOut: GCNX_DUO_LAUNCH(false, kDuoBitsOut); break;
+      case kDuoFoldBits: GCNX_DUO_LAUNCH(false, kDuoFoldBits); break;
+      default: GCNX_DUO_LAUNCH(false, kDuoPlain); break;
+    }
+  }
+#undef GCNX_DUO_LAUNCH
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -1193,9 +1220,27 @@ int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
   return GCNX_OK;
 }
 
+static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                         int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                         const gcnx_spmm_plan* plan, uint32_t* relu_bits);
+
 int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                   int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
                   const gcnx_spmm_plan* plan) {
+  return spmm_csr_impl(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan, nullptr);
+}
+
+int gcnx_spmm_csr_relu_bits(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                            int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f,
+                            const gcnx_spmm_plan* plan, void* relu_bits) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, relu_bits && (reinterpret_cast<uintptr_t>(relu_bits) & 3) == 0, "gcnx_spmm_csr_relu_bits: relu_bits must be a 4-byte aligned buffer");
+  return spmm_csr_impl(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, GCNX_ACT_RELU, plan, (uint32_t*)relu_bits);
+}
+
+static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                         int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
+                         const gcnx_spmm_plan* plan, uint32_t* relu_bits) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr: negative size");
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_spmm_csr: activation %d not supported here", act);
@@ -1217,6 +1262,9 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
   bool tiles = plan && f % kSlab == 0 && (long long)(plan->n1 + 2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
   if (force == 1) tiles = false;
   if (force >= 2 && plan && f % kSlab == 0) tiles = true;
+  if (relu_bits && (!tiles || force == 3))
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_spmm_csr_relu_bits: the bit image is written by the tile kernels only "
+                     "(needs a plan with enough tile units and f %% 32 == 0): use gcnx_spmm_csr");
   if (!tiles) {
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0);
     GCNX_LAUNCH_OK(ctx);
@@ -1289,13 +1337,15 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
     return GCNX_OK;
   }
   // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
+  const DuoFold bo{nullptr, nullptr, 0, 0, relu_bits};     // (graphs taller than a tile get no bits: their rows are folded from out)
+  const int dmode = relu_bits ? kDuoBitsOut : kDuoPlain;
   if (plan->n1 > 0) {
-    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1);
+    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, &bo, dmode);
     if (rc) return rc;
   }
   if (plan->n2 > 0) {
     int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                     plan->n2);
+                                     plan->n2, &bo, dmode);
     if (rc) return rc;
   }
   if (plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
@@ -1309,7 +1359,7 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
 int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                            const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
                            int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode,
-                           const gcnx_spmm_plan* plan) {
+                           const gcnx_spmm_plan* plan, const void* y_bits) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0 && b >= 0, "gcnx_spmm_csr_pool_bwd: negative size");
   GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
@@ -1332,15 +1382,18 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
     GCNX_LAUNCH_OK(ctx);
     return GCNX_OK;
   }
+  // y_bits (the forward's gcnx_spmm_csr_relu_bits image of y): the tiers expand it instead of reading y
+  const int dmode = y_bits ? kDuoFoldBits : kDuoFold;
   if (plan->n1 > 0) {
-    const DuoFold df{plan->gids, dpooled, lddp, fo.avg};
-    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev, plan->n1, &df);
+    const DuoFold df{plan->gids, dpooled, lddp, fo.avg, (uint32_t*)y_bits};
+    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev, plan->n1, &df,
+                                    dmode);
     if (rc) return rc;
   }
   if (plan->n2 > 0) {
-    const DuoFold df{plan->gids + plan->n1, dpooled, lddp, fo.avg};
+    const DuoFold df{plan->gids + plan->n1, dpooled, lddp, fo.avg, (uint32_t*)y_bits};
     int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1,
-                                     plan->n2, &df);
+                                     plan->n2, &df, dmode);
     if (rc) return rc;
   }
   if (plan->nchunks > 0) {

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "libgcnx.so")   # G
 
 # enums of include/gcnx.h
 OK = 0
+ERR_UNSUPPORTED = 5   # GCNX_ERR_UNSUPPORTED: a valid request this build has no kernel for (callers fall back)
 ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
 POOL_SUM, POOL_AVG, POOL_MAX = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
@@ -77,7 +78,8 @@ SIGNATURES = {
     "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],
     "gcnx_dense_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp],
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
-    "gcnx_spmm_csr_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp],
+    "gcnx_spmm_csr_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],
+    "gcnx_spmm_csr_relu_bits": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "gcnx_pool_bwd_colsum": [_vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _int, _vp],
     "gcnx_bn_stats": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "gcnx_bn_finalize": [_vp, _vp, _f32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],

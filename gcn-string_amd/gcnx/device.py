@@ -436,13 +436,27 @@ def pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, loss_acc=None
     return probs
 
 
-def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum"):
+def spmm_relu_bits(ctx, a, h, bias, out, bits):
+    """out = relu(A h + bias) on the tile kernels, which also write the bit image of [out > 0] (int32 [(f / 32) * n]) that
+    spmm_pool_bwd(y_bits=...) folds from.  Returns False -- nothing launched -- if the tile kernels do not serve this
+    batch (gcnx_spmm_csr_relu_bits: GCNX_ERR_UNSUPPORTED); the caller then takes spmm()."""
+    n, f = h.shape
+    assert a.n == n and out.shape == (n, f) and bits.size >= (f // 32) * n
+    rc = ctx.lib.gcnx_spmm_csr_relu_bits(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(h), h.ld, _p(bias), _p(out), out.ld,
+                                         n, f, a.plan, _p(bits))
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
+def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum", y_bits=None):
     """out = A^T (pool'(dpooled) * [y > 0]) in one gather (gcnx_spmm_csr_pool_bwd); ``at`` is the transposed operator."""
     n, f = y.shape
     assert at.n == n and out.shape == (n, f) and dpooled.shape == (seg.n_graphs, f)
     ctx._ck(ctx.lib.gcnx_spmm_csr_pool_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y), y.ld, seg.dev.ptr,
                                            seg.n_graphs, _p(dpooled), dpooled.ld, _p(out), out.ld, n, f, L.POOLS[mode],
-                                           at.plan if at.n_blocks == seg.n_graphs else None))
+                                           at.plan if at.n_blocks == seg.n_graphs else None, _p(y_bits)))
     return out
 
 

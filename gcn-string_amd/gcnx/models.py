@@ -213,7 +213,15 @@ class GCN2(_GraphRunner):
             D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
             D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
             D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
-            D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
+            # pooled layer on the tile kernels with a backward pass to follow: its launch also writes [Y2 > 0] as a bit
+            # image, which the folded backward aggregation expands instead of reading Y2 again (1 GB -> 32 MB at config 3)
+            bufs["y2bits_ok"] = False
+            if with_loss == "grads" and self._fold(batch) and batch.a.plan is not None and self.hidden % 32 == 0:
+                if bufs.get("y2bits") is None or bufs["y2bits"].size < (self.hidden // 32) * batch.n:
+                    bufs["y2bits"] = ctx.empty((self.hidden // 32) * batch.n, np.int32)
+                bufs["y2bits_ok"] = D.spmm_relu_bits(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"])
+            if not bufs["y2bits_ok"]:
+                D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
         # Global pool, then Dense(softmax) + CCE + accuracy + the head gradients in one launch; with few graphs the
         # head also combines the pool's row-slice partial sums (gcnx_pool_dense_softmax_cce)
         head = dict(mode=self.pool, argmax=bufs["arg"])
@@ -257,7 +265,8 @@ class GCN2(_GraphRunner):
                        grads=self.flat_g.flat(0, self.n_params), lr=lr, pending=pend)
             return True
         if fold:
-            D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool)   # dH2 = A^T dZ2
+            D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool,
+                            y_bits=bufs["y2bits"] if bufs.get("y2bits_ok") else None)                # dH2 = A^T dZ2
         else:
             D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
             D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                       # dH2 = A^T dZ2

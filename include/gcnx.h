@@ -275,7 +275,16 @@ GCNX_API int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, cons
 GCNX_API int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                            const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b,
                            const float* dpooled, int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f,
-                           int mode, const gcnx_spmm_plan* plan);
+                           int mode, const gcnx_spmm_plan* plan, const void* y_bits);
+/* gcnx_spmm_csr with act = ReLU on the tile kernels, which also write [out > 0] as a bit image: one 32-bit word per (row,
+ * 32-column slab), slab-major -- relu_bits[slab * n + row], (f / 32) * n words -- for the rows of every graph the plan
+ * serves with a tile (graphs taller than a tile get no bits; gcnx_spmm_csr_pool_bwd folds their rows from `out`).
+ * gcnx_spmm_csr_pool_bwd(..., y_bits = relu_bits) then expands the words into its 0 / 1 tile instead of reading y:
+ * 4 bytes per row and slab instead of 128.  GCNX_ERR_UNSUPPORTED when gcnx_spmm_csr would not take the tile kernels
+ * (no plan, too few tile units, f % 32 != 0): call gcnx_spmm_csr then and pass y_bits = NULL. */
+GCNX_API int gcnx_spmm_csr_relu_bits(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                           const float* h, int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f,
+                           const gcnx_spmm_plan* plan, void* relu_bits);
 /* db[f] = column sums of the same never-materialised dZ (BiasAddGrad of that layer):
  * sum_g scale_g * dPooled[g] * #{j in g : y[j] > 0}; deterministic (fixed summation order). */
 GCNX_API int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, const float* dpooled,

@@ -701,12 +701,34 @@ def test_spmm_pool_bwd_fold_on_the_tile_kernels(ctx, mode):
     assert at.plan is not None
     seg = Segments(ctx, hb.graph_ptr)
     out = ctx.empty((n, f)); dy, ddp = ctx.to_device(y), ctx.to_device(dp)
+    ctx.set_tuning("spmm_kernel", "tile")      # (200 graphs x 2 slabs are fewer units than the library asks for before it picks the tiles)
     D.spmm_pool_bwd(ctx, at, dy, seg, ddp, out, mode)
     assert rel_err(out.numpy(), ref) < TIGHT
     tiled = out.numpy().copy()
+    # ... and from the bit image the forward launch of the pooled layer writes (gcnx_spmm_csr_relu_bits): y2 = relu(A h + b)
+    hsrc = rng.standard_normal((n, f), dtype=np.float32); bias = rng.standard_normal(f).astype(np.float32)
+    y2 = ctx.empty((n, f)); bits = ctx.zeros((f // 32) * n, np.int32)
+    assert D.spmm_relu_bits(ctx, a, ctx.to_device(hsrc), ctx.to_device(bias), y2, bits)
+    y2h = y2.numpy()
+    ref_y2 = np.maximum(o.spmm_csr(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals.astype(np.float64),
+                                   hsrc.astype(np.float64)) + bias, 0)
+    assert rel_err(y2h, ref_y2) < TIGHT
+    img = bits.numpy().view(np.uint32).reshape(f // 32, n)                  # slab-major: one word per (slab, row)
+    tile_rows = np.concatenate([np.arange(hb.graph_ptr[g], hb.graph_ptr[g + 1]) for g in range(b) if sizes[g] <= 1236])
+    got = ((img[:, tile_rows, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)          # [slab, row, bit]
+    want = (y2h[tile_rows] > 0).reshape(len(tile_rows), f // 32, 32).transpose(1, 0, 2)
+    assert np.array_equal(got, want)
+    dz2 = o.global_pool_bwd(dp.astype(np.float64), hb.graph_ptr, n, mode, None) * (y2h > 0)
+    ref2 = o.spmm_csr_T(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals.astype(np.float64), dz2)
+    D.spmm_pool_bwd(ctx, at, y2, seg, ddp, out, mode, y_bits=bits)
+    assert rel_err(out.numpy(), ref2) < TIGHT
+    from_bits = out.numpy().copy()
+    D.spmm_pool_bwd(ctx, at, y2, seg, ddp, out, mode)                       # the fp32-source fold gives the same bits of dH
+    assert np.array_equal(out.numpy(), from_bits)
     ctx.set_tuning("spmm_kernel", "rows")                                   # the same call on the row gather
     try:
         D.spmm_pool_bwd(ctx, at, dy, seg, ddp, out, mode)
+        assert not D.spmm_relu_bits(ctx, a, ctx.to_device(hsrc), ctx.to_device(bias), y2, bits)   # no tiles, no bit image
     finally:
         ctx.set_tuning("spmm_kernel", "auto")
     assert rel_err(out.numpy(), ref) < TIGHT and rel_err(out.numpy(), tiled) < TIGHT
