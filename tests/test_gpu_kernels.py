@@ -1055,3 +1055,54 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode, prec):
     pend = D.gcn_conv_bwd_pool(*args, db1=gb1, mode=mode, scratch=scratch, prec=prec)
     D.gemm_dw2(ctx, ctx.to_device(s1), dz1, gw1, ctx.to_device(s2), dz2, gw2, grads=grads, pending=pend)
     assert rel_err(grads.numpy(), rg) < tol
+
+
+def test_gcn_conv_fused_edge_cases(ctx):
+    """The one-launch GCNConv on degenerate inputs: fewer rows than a tile, rows without entries, single-node graphs, a
+    graph boundary inside every tile, average pooling over graphs of one node -- forward, backward and the column sums."""
+    from gcnx import device as D
+    from gcnx.device import DeviceCSR, Segments
+    o = O()
+    rng = np.random.default_rng(3)
+    sizes = np.array([1, 3, 1, 7, 2, 1, 40, 1], np.int64)             # 56 rows: two tiles, the second ragged
+    gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n, b, f = int(gp[-1]), len(sizes), 32
+    rows, cols = [], []
+    for g in range(b):                                                # self-loops except on rows 4 and 20 (empty rows), a few in-graph pairs
+        for i in range(gp[g], gp[g + 1]):
+            if i in (4, 20):
+                continue
+            rows.append(i); cols.append(i)
+            if sizes[g] > 2 and i + 1 < gp[g + 1]:
+                rows += [i, i + 1]; cols += [i + 1, i]
+    order = np.lexsort((cols, rows))
+    rows, cols = np.asarray(rows)[order], np.asarray(cols)[order]
+    keep = ~np.isin(rows, (4, 20))                                     # rows 4 and 20 end up with no entries at all
+    rows, cols = rows[keep], cols[keep]
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    colidx = cols.astype(np.int32)
+    vals = (rng.random(len(cols)) + 0.5).astype(np.float32)
+    assert rowptr[5] == rowptr[4] and rowptr[21] == rowptr[20]
+    a = DeviceCSR.from_host_csr(ctx, rowptr, colidx, vals, gp, symmetric=False)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = (rng.standard_normal((f, f)) / 6).astype(np.float32); bias = rng.standard_normal(f).astype(np.float32)
+    out = ctx.empty((n, f)); s = ctx.empty((n, f))
+    D.gcn_conv_fwd(ctx, a, ctx.to_device(x), ctx.to_device(w), ctx.to_device(bias), out, act="relu", s=s)
+    ax = o.spmm_csr(rowptr.astype(np.int64), colidx.astype(np.int64), vals.astype(np.float64), x.astype(np.float64))
+    assert rel_err(s.numpy(), ax) < TIGHT and not s.numpy()[[4, 20]].any()
+    assert rel_err(out.numpy(), np.maximum(ax @ w.astype(np.float64) + bias, 0)) < TIGHT
+    for mode in ("sum", "avg"):
+        y2 = np.maximum(rng.standard_normal((n, f), dtype=np.float32), 0); y1 = np.maximum(rng.standard_normal((n, f), dtype=np.float32), 0)
+        dp = rng.standard_normal((b, f), dtype=np.float32)
+        rdz2 = o.global_pool_bwd(dp.astype(np.float64), gp, n, mode, None) * (y2 > 0)
+        rdz1 = (o.spmm_csr_T(rowptr.astype(np.int64), colidx.astype(np.int64), vals.astype(np.float64), rdz2) @ w.astype(np.float64).T) * (y1 > 0)
+        dz2 = ctx.empty((n, f)); dz1 = ctx.empty((n, f)); db1 = ctx.empty(f)
+        D.gcn_conv_bwd_pool(ctx, a.transpose(), ctx.to_device(y2), Segments(ctx, gp), ctx.to_device(dp), ctx.to_device(w),
+                            ctx.to_device(y1), dz2, dz1, db1=db1, mode=mode)
+        assert rel_err(dz2.numpy(), rdz2) < TIGHT and rel_err(dz1.numpy(), rdz1) < TIGHT and rel_err(db1.numpy(), rdz1.sum(0)) < TIGHT
+    # n smaller than one tile
+    assert list(gp[:4]) == [0, 1, 4, 5]
+    a5 = DeviceCSR.from_host_csr(ctx, rowptr[:6], colidx[:rowptr[5]], vals[:rowptr[5]], gp[:4].copy(), symmetric=False)
+    out5 = ctx.empty((5, f))
+    D.gcn_conv_fwd(ctx, a5, ctx.to_device(x[:5]), ctx.to_device(w), None, out5, act=None)
+    assert rel_err(out5.numpy(), ax[:5] @ w.astype(np.float64)) < TIGHT
