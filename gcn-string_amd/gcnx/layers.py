@@ -18,6 +18,8 @@ import numpy as np
 
 from . import device as D
 
+_FUSED_KNOB = os.environ.get("GCNX_FUSED", "1") != "0"     # tuning knob, read once at import (diagnostics)
+
 
 def glorot_uniform(rng, fan_in, fan_out):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
@@ -137,7 +139,7 @@ class GCNConv(Layer):
         return y
 
     def _one_launch(self, x, a):
-        return (self.prec in ("f32", "bf16x3") and getattr(a, "plan", None) is None and x.contiguous and os.environ.get("GCNX_FUSED", "1") != "0"
+        return (self.prec in ("f32", "bf16x3") and getattr(a, "plan", None) is None and x.contiguous and _FUSED_KNOB
                 and D.gcn_conv_fused_ok(self.ctx, x.shape[0], x.shape[1], self.channels, x.ld))
 
     def backward(self, dy, need_dx=True, dy_is_dz=False):

@@ -127,6 +127,9 @@ class GCN2(_GraphRunner):
         self.cce_train, self.cce_eval = cce_train, cce_eval
         self.comm = comm                     # gcnx.comm.Communicator or None
         self.use_graph = use_graph
+        # tuning knobs (diagnostics), read ONCE here -- the sequence a model runs never changes under it
+        self._knob = {"fold": os.environ.get("GCNX_FOLD", "1") != "0", "duo": os.environ.get("GCNX_DUO", "1") != "0",
+                      "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1"))}
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
@@ -244,7 +247,7 @@ class GCN2(_GraphRunner):
         # section, concurrently with the main chain dX -> db1 -> A^T -> dW1.  One fork and one join per step: each
         # costs ~10 us of cross-queue signalling, which is why there are not three sections.  The buffers the side
         # section reads (dz, h) stay unmodified until the join: the main chain continues in dz2 / h2.
-        side = int(os.environ.get("GCNX_SIDE", "1"))   # tuning knob: 0 = serial, 1 = one section, 7 = three sections
+        side = self._knob["side"]                      # tuning knob GCNX_SIDE: 0 = serial, 1 = one section, 7 = three sections
         if side != 1:
             return self._backward_knob(batch, bufs, 0 if side == 0 else 7)
         # SUM / AVG pooling: dZ2 = pool'(dPooled) * [Y2 > 0] is never materialised -- the aggregation gathers the mask
@@ -270,7 +273,7 @@ class GCN2(_GraphRunner):
         else:
             D.segment_pool_bwd(ctx, batch.seg, bufs["dpooled"], bufs["dz"], self.pool, bufs["arg"], y=bufs["y2"])  # dZ2 (ReLU mask fused)
             D.spmm(ctx, at, bufs["dz"], None, bufs["h"])                       # dH2 = A^T dZ2
-        if fold and batch.a.plan is None and os.environ.get("GCNX_DUO", "1") != "0":
+        if fold and batch.a.plan is None and self._knob["duo"]:
             # db2 came out of the head, and dW2 shares dX's launch (gcnx_dense_bwd): one stream, no fork / join --
             # the second stream's signalling cost 25 us of a 194 us step
             if lr is None:
@@ -310,15 +313,15 @@ class GCN2(_GraphRunner):
         """SUM / AVG pooling: pool' and the ReLU mask fold into the backward aggregation (dZ2 is never materialised) and
         db2 = sum_g dPooled[g] * #[Y2_g > 0] comes out of the head (few graphs) or of gcnx_pool_bwd_colsum."""
         return (self.pool in ("sum", "avg") and self.hidden % 4 == 0 and (batch.a.plan is None or self.hidden % 32 == 0)
-                and os.environ.get("GCNX_FOLD", "1") != "0" and int(os.environ.get("GCNX_SIDE", "1")) == 1)
+                and self._knob["fold"] and self._knob["side"] == 1)
 
     def _fused(self, batch):
         """The small-feature regime (config 2): every GCNConv and the backward from the pool down to dZ1 are single
         launches (csrc/fused.hip).  Needs the folded backward's conditions and F, H in {32, 64, 128}; prec "f32" (exact
         fp32 products) or "bf16x3" (split-bf16 products in the conv launches; the two weight gradients stay on the fp32
         MFMA -- sums over N rows, at least as accurate)."""
-        return (self.built and self._fold(batch) and self.prec in ("f32", "bf16x3") and os.environ.get("GCNX_FUSED", "1") != "0"
-                and os.environ.get("GCNX_DUO", "1") != "0" and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
+        return (self.built and self._fold(batch) and self.prec in ("f32", "bf16x3") and self._knob["fused"]
+                and self._knob["duo"] and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.f_in, self.hidden)
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))
 
