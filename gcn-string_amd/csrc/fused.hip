@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   // instruction per (lane, entry) shows.  2 U slack entries: the loop reads up to U - 1 past a row's end unclamped.
   __shared__ __attribute__((aligned(8))) int2 s_ent[kFCap + 2 * U];
   __shared__ int32_t s_rp[kFRows + 1];
+  __shared__ unsigned char s_mb[BWD ? kFRows * 32 : 1];   // backward: [Y1 > 0] of the tile, 4 columns per byte
 #ifdef GCNX_TUNING
   const int dbg = p.dbg;
 #else
@@ -125,7 +126,29 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
       grow[j] = (r < nr && gid < kFRows) ? p.node_graph[r0 + r] : -1;
     }
   }
+  // backward: the ReLU mask rows of the tile (saved Y1), read here as whole 512-byte rows -- two loads per thread under
+  // the staging latency -- and kept as bits in LDS; the epilogue's accumulator layout would read them as 64-byte pieces,
+  // eight load instructions per wave in a loop whose cost is counted in instructions (2.2 us of the launch)
+  float4 mrow[2];
+  const int mlanes = p.nc >> 2;
+  if (BWD) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = tid + 512 * q, row = i / mlanes, c4 = i - row * mlanes;
+      mrow[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nr && !(dbg & 16)) mrow[q] = *reinterpret_cast<const float4*>(p.mask + (int64_t)(r0 + row) * p.ldmask + 4 * c4);
+    }
+  }
   __syncthreads();
+  if (BWD) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = tid + 512 * q, row = i / mlanes, c4 = i - row * mlanes;
+      if (row < kFRows)
+        s_mb[row * 32 + c4] = (unsigned char)((mrow[q].x > 0.f ? 1u : 0u) | (mrow[q].y > 0.f ? 2u : 0u) | (mrow[q].z > 0.f ? 4u : 0u) |
+                                              (mrow[q].w > 0.f ? 8u : 0u));
+    }
+  }
   float4 acc[RPG];
   int ea[RPG], eb[RPG], ebf[RPG];
   int len = 0;
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
 #pragma unroll
     for (int j = 0; j < RPG; ++j)
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[j] = f4fma(wv[j][u], BWD ? f4step(hv[j][u]) : hv[j][u], acc[j]);
+      for (int u = 0; u < U; ++u) acc[j] = f4fma(wv[j][u], (BWD && !(dbg & 64)) ? f4step(hv[j][u]) : hv[j][u], acc[j]);
   }
   if (e1 - e0 > kFCap) {       // uniform per workgroup, rare: entries beyond the staged ones, one at a time from global memory
 #pragma unroll
@@ -183,7 +206,8 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
     for (int j = 0; j < RPG; ++j) {
       const int r = gid + j * NG;
       own[j] = dscale[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (grow[j] >= 0) {
+      if (grow[j] >= 0 && (dbg & 32)) dscale[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (grow[j] >= 0 && !(dbg & 32)) {
         float4 d = *reinterpret_cast<const float4*>(p.dp + (int64_t)grow[j] * p.lddp + sub * 4);
         if (p.avg) {
           const float sc = 1.0f / (float)(p.gp[grow[j] + 1] - p.gp[grow[j]]);
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
       float4 a = acc[j];
       if (BWD) {
         a.x *= dscale[j].x; a.y *= dscale[j].y; a.z *= dscale[j].z; a.w *= dscale[j].w;
-        if (p.dz2 && r < nr) {
+        if (p.dz2 && r < nr && !(dbg & 8)) {
           const float4 m = f4step(own[j]);
           *reinterpret_cast<float4*>(p.dz2 + (int64_t)(r0 + r) * p.lddz2 + sub * 4) =
               make_float4(m.x * dscale[j].x, m.y * dscale[j].y, m.z * dscale[j].z, m.w * dscale[j].w);
@@ -250,11 +274,11 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   if (!wave_on) return;
   const int col = 16 * wave + c16;
   float mk[8];
-  if (BWD) {                                          // the ReLU mask (saved Y1), in flight under the MFMAs
+  if (BWD) {                                          // the ReLU mask bits of this lane's column (rows past the end: 0)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int row = 16 * (r >> 2) + 4 * kq + (r & 3);
-      mk[r] = row < nr ? p.mask[(int64_t)(r0 + row) * p.ldmask + col] : 0.f;
+      mk[r] = (dbg & 16) ? 1.f : (float)((s_mb[row * 32 + (col >> 2)] >> (col & 3)) & 1u);
     }
   }
   const float bcol = (!BWD && p.bias) ? p.bias[col] : 0.f;
