@@ -95,6 +95,9 @@ __device__ __forceinline__ void gcnx_colpart_reduce_body(const float* __restrict
 // this reduction's own second-stage scratch behind them).
 size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f);
 int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out);
+// head.hip: the classifier head from the pool's partial sums as a launch of its own (what gcnx_gemm_dw2 falls back to when
+// the head does not fit inside its launch)
+int gcnx_head_from_parts(gcnx_ctx* ctx, const gcnx_head_args* leaf);
 // reduce.hip: the split global pool (sum / avg).  gcnx_pool_split = slices per graph worth launching (1: none);
 // gcnx_pool_partials writes the partial row sums [nsplit][b][f] (row stride f) to `part`.
 // half_wgs_per_cu: first-stage workgroups to aim for, in halves per CU: 4 (= 2 per CU) for the stand-alone pool; 1

@@ -48,6 +48,11 @@ struct FusedArgs {
   const float* mask; int64_t ldmask;     // Y1 (ReLU output of the layer below)
   float* dz2; int64_t lddz2;             // dZ2 rows of this tile (may be NULL)
   float* colpart;                        // [tiles, nc] column sums of what was written to out (may be NULL)
+  // backward with the classifier head folded in (hd_part != NULL): dPooled is not read -- every row group evaluates
+  // Dense(softmax) + CCE' of its own graph from the pool's partial sums (a few hundred flops), so that the head's kernel
+  // is no longer between the pool and this launch (its remaining outputs are leaves: gcnx_gemm_dw2 computes them)
+  const float* hd_part; int hd_nsplit; int hd_b;       // pool partials [nsplit][b][K]
+  const float* hd_w; const float* hd_bias; const float* hd_y; int hd_c; float hd_denom; int hd_fl;
   int dbg;                               // tuning builds: phase-ablation bits (1 no gather, 2 no MFMA, 4 no weight load)
 };
 
@@ -72,6 +77,44 @@ __device__ __forceinline__ float4 f4step(float4 a) {
   return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
 
+// pool'(dPooled) of graph g for this lane's 4 columns, from the pool's partial sums: Dense(softmax) + CCE' evaluated by
+// one lane group (LPR lanes x 4 columns = the K pooled features; logits by lane partials and an xor tree inside the
+// group), the arithmetic of head_kernel.  Two class slots -- the reference's binary labels; a single class leaves the
+// second slot at weight 0 and logit -inf (more classes: the host refuses and the step keeps the head's own launch).
+template <int K, int LPR>
+__device__ __forceinline__ float4 fused_head_dpooled(const FusedArgs& p, int g, int sub) {
+  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < p.hd_nsplit; ++z) {
+    const float4 q = *reinterpret_cast<const float4*>(p.hd_part + ((int64_t)z * p.hd_b + g) * K + sub * 4);
+    pv.x += q.x; pv.y += q.y; pv.z += q.z; pv.w += q.w;
+  }
+  float sc = 1.0f;
+  if (p.avg) { sc = 1.0f / (float)max(p.gp[g + 1] - p.gp[g], 1); pv.x *= sc; pv.y *= sc; pv.z *= sc; pv.w *= sc; }
+  // (two class slots -- the reference's binary labels; a single class leaves the second slot at weight 0 and
+  // logit -inf.  More classes: the host refuses and the step keeps the head's own launch.)
+  const bool two = p.hd_c > 1;
+  const float4 w0 = make_float4(p.hd_w[(int64_t)(sub * 4 + 0) * p.hd_c], p.hd_w[(int64_t)(sub * 4 + 1) * p.hd_c],
+                                p.hd_w[(int64_t)(sub * 4 + 2) * p.hd_c], p.hd_w[(int64_t)(sub * 4 + 3) * p.hd_c]);
+  float4 w1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (two) w1 = make_float4(p.hd_w[(int64_t)(sub * 4 + 0) * p.hd_c + 1], p.hd_w[(int64_t)(sub * 4 + 1) * p.hd_c + 1],
+                            p.hd_w[(int64_t)(sub * 4 + 2) * p.hd_c + 1], p.hd_w[(int64_t)(sub * 4 + 3) * p.hd_c + 1]);
+  float z0 = fmaf(pv.w, w0.w, fmaf(pv.z, w0.z, fmaf(pv.y, w0.y, pv.x * w0.x)));
+  float z1 = fmaf(pv.w, w1.w, fmaf(pv.z, w1.z, fmaf(pv.y, w1.y, pv.x * w1.x)));
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) { z0 += __shfl_xor(z0, off); z1 += __shfl_xor(z1, off); }
+  z0 += p.hd_bias ? p.hd_bias[0] : 0.f;
+  z1 = two ? z1 + (p.hd_bias ? p.hd_bias[1] : 0.f) : -INFINITY;
+  const float y0 = p.hd_y[(int64_t)g * p.hd_c], y1 = two ? p.hd_y[(int64_t)g * p.hd_c + 1] : 0.f;
+  const float m = fmaxf(z0, z1), e0 = expf(z0 - m), e1 = expf(z1 - m), sum = e0 + e1;
+  const float p0 = e0 / sum, p1 = e1 / sum;
+  const bool k0 = p.hd_fl || (p0 > 1e-7f && p0 < 1.0f - 1e-7f), k1 = two && (p.hd_fl || (p1 > 1e-7f && p1 < 1.0f - 1e-7f));
+  const float ymsum = (k0 ? y0 : 0.f) + (k1 ? y1 : 0.f);
+  const float dl0 = (p0 * ymsum - (k0 ? y0 : 0.f)) / p.hd_denom, dl1 = two ? (p1 * ymsum - (k1 ? y1 : 0.f)) / p.hd_denom : 0.f;
+  const float4 d = make_float4(fmaf(dl1, w1.x, dl0 * w0.x), fmaf(dl1, w1.y, dl0 * w0.y), fmaf(dl1, w1.z, dl0 * w0.z),
+                               fmaf(dl1, w1.w, dl0 * w0.w));
+  return make_float4(d.x * sc, d.y * sc, d.z * sc, d.w * sc);
+}
+
 // X3: the product phase on the bf16 MFMA with split operands (hi = bf16(x), lo = bf16(x - hi); hi*lo + lo*hi + hi*hi, fp32
 // accumulate: GCNX_PREC_BF16X3, ~2^-17 per operand) instead of exact fp32 products -- three 16x16x32 MFMAs per 32 k where
 // the fp32 path issues eight 16x16x4.
@@ -91,6 +134,8 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   __shared__ __attribute__((aligned(8))) int2 s_ent[kFCap + 2 * U];
   __shared__ int32_t s_rp[kFRows + 1];
   __shared__ unsigned char s_mb[BWD ? kFRows * 32 : 1];   // backward: [Y1 > 0] of the tile, 4 columns per byte
+  __shared__ float4 s_hd[BWD ? 2 : 1][LPR];               // backward, head folded in: pool'(dPooled) of the tile's first two graphs
+  __shared__ int s_hdg;
 #ifdef GCNX_TUNING
   const int dbg = p.dbg;
 #else
@@ -129,6 +174,15 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   // backward: the ReLU mask rows of the tile (saved Y1), read here as whole 512-byte rows -- two loads per thread under
   // the staging latency -- and kept as bits in LDS; the epilogue's accumulator layout would read them as 64-byte pieces,
   // eight load instructions per wave in a loop whose cost is counted in instructions (2.2 us of the launch)
+  if (BWD && p.hd_part && wave == 0) {     // (uniform per wave) the classifier head of the tile's first two graphs
+    const int g_first = p.node_graph[r0];
+    const int gsel = lane / LPR;
+    if (gsel < 2) {
+      const float4 d = fused_head_dpooled<K, LPR>(p, min(g_first + gsel, p.hd_b - 1), lane % LPR);
+      s_hd[gsel][lane % LPR] = d;
+    }
+    if (lane == 0) s_hdg = g_first;
+  }
   float4 mrow[2];
   const int mlanes = p.nc >> 2;
   if (BWD) {
@@ -207,14 +261,25 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
       const int r = gid + j * NG;
       own[j] = dscale[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (grow[j] >= 0 && (dbg & 32)) dscale[j] = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (grow[j] >= 0 && !(dbg & 32)) {
+      if (grow[j] >= 0 && !(dbg & 32) && !p.hd_part) {
         float4 d = *reinterpret_cast<const float4*>(p.dp + (int64_t)grow[j] * p.lddp + sub * 4);
         if (p.avg) {
           const float sc = 1.0f / (float)(p.gp[grow[j] + 1] - p.gp[grow[j]]);
           d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
         }
         dscale[j] = d;
-        if (p.dz2) own[j] = *reinterpret_cast<const float4*>(p.x + (int64_t)(r0 + r) * p.ldx + sub * 4);
+      }
+      if (grow[j] >= 0 && p.dz2) own[j] = *reinterpret_cast<const float4*>(p.x + (int64_t)(r0 + r) * p.ldx + sub * 4);
+    }
+    if (p.hd_part && !(dbg & 32)) {
+      // the head's dPooled rows of the tile's first two graphs were put in LDS by wave 0 under the staging latency; a row of
+      // a later graph (tiles that span three or more graphs: graphs of fewer than 32 rows) evaluates its own
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) {
+        if (grow[j] < 0) continue;
+        const int gi = grow[j] - s_hdg;
+        if (gi < 2) dscale[j] = s_hd[gi][sub];
+        else dscale[j] = fused_head_dpooled<K, LPR>(p, grow[j], sub);
       }
     }
   }
@@ -400,7 +465,8 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
                            const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
                            const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
                            int w2_transposed, const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
-                           float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec) {
+                           float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec,
+                           const gcnx_head_args* head) {
   GCNX_CHECK_CTX(ctx);
   if (prec != GCNX_PREC_F32 && prec != GCNX_PREC_BF16X3)
     return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_bwd_pool: precision %d (GCNX_PREC_F32 or GCNX_PREC_BF16X3 here)", prec);
@@ -415,11 +481,20 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
   if (!fused_shape_ok(n, f2, f1, ldy2))
     return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_bwd_pool: needs f2 in {32, 64, 128}, f1 a multiple of 16 up to 128 "
                      "and n * ldy2 * 4 < 2^32 (got n=%d f1=%d f2=%d)", n, f1, f2);
-  GCNX_REQUIRE(ctx, b > 0 && rowptr_t && colidx_t && y2 && node_graph && graph_ptr && dpooled && w2 && y1 && dz1,
+  GCNX_REQUIRE(ctx, b > 0 && rowptr_t && colidx_t && y2 && node_graph && graph_ptr && (dpooled || head) && w2 && y1 && dz1,
                "gcnx_gcn_conv_bwd_pool: NULL pointer");
-  GCNX_REQUIRE(ctx, lddp >= f2 && lddp % 4 == 0 && ldy1 >= f1 && ldy1 % 4 == 0 && lddz1 >= f1 && lddz1 % 4 == 0 && fal16(y2) &&
-                        fal16(dpooled) && fal16(y1) && fal16(dz1) && (!dz2 || (fal16(dz2) && lddz2 >= f2 && lddz2 % 4 == 0)),
+  GCNX_REQUIRE(ctx, (head || (lddp >= f2 && lddp % 4 == 0 && fal16(dpooled))) && ldy1 >= f1 && ldy1 % 4 == 0 && lddz1 >= f1 &&
+                        lddz1 % 4 == 0 && fal16(y2) && fal16(y1) && fal16(dz1) &&
+                        (!dz2 || (fal16(dz2) && lddz2 >= f2 && lddz2 % 4 == 0)),
                "gcnx_gcn_conv_bwd_pool: operands must be 16-byte aligned with leading dimensions in multiples of 4 floats");
+  if (head) {
+    GCNX_REQUIRE(ctx, head->part && head->w && head->y && head->nsplit >= 1 && head->b == b && head->h == f2 && head->c >= 1 &&
+                          head->denom > 0.f && fal16(head->part) && head->pool_mode == mode &&
+                          (head->cce_mode == GCNX_CCE_PROBS || head->cce_mode == GCNX_CCE_LOGITS),
+                 "gcnx_gcn_conv_bwd_pool: inconsistent head arguments");
+    if (head->c > 2)
+      return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_bwd_pool: the in-kernel head serves one or two classes (got %d)", head->c);
+  }
   GCNX_REQUIRE(ctx, y2 != dz1 && y2 != dz2 && y1 != dz1, "gcnx_gcn_conv_bwd_pool: outputs must not alias the saved activations");
   const int64_t tiles = gcnx_cdiv(n, kFRows);
   float* colpart = nullptr;
@@ -438,6 +513,10 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
   a.rowptr = rowptr_t; a.colidx = colidx_t; a.vals = vals_t; a.x = y2; a.ldx = ldy2; a.n = n; a.w = w2; a.ldw = w2_transposed ? f1 : f2; a.w_t = w2_transposed ? 1 : 0; a.nc = f1;
   a.out = dz1; a.ldo = lddz1; a.node_graph = node_graph; a.gp = graph_ptr; a.dp = dpooled; a.lddp = lddp;
   a.avg = mode == GCNX_POOL_AVG ? 1 : 0; a.mask = y1; a.ldmask = ldy1; a.dz2 = dz2; a.lddz2 = lddz2; a.colpart = colpart;
+  if (head) {
+    a.hd_part = head->part; a.hd_nsplit = head->nsplit; a.hd_b = head->b; a.hd_w = head->w; a.hd_bias = head->bias; a.hd_y = head->y;
+    a.hd_c = head->c; a.hd_denom = head->denom; a.hd_fl = head->cce_mode == GCNX_CCE_LOGITS ? 1 : 0;
+  }
   int rc = launch_fused<true>(ctx, a, f2, prec == GCNX_PREC_BF16X3);
   if (rc) return rc;
   if (db1) {

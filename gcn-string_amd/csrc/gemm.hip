@@ -11,6 +11,7 @@
 // LDS.  LDS images are k-major ([k][m] and [k][n]) so that the MFMA operand read -- lane l takes
 // element [k = 2*kk + (l>>5)][l & 31] -- is 32 consecutive dwords per half-wave: conflict-free.
 #include "common.h"
+#include "head_body.h"
 
 namespace {
 
@@ -320,6 +321,46 @@ __global__ __launch_bounds__(256) void gemm_f32_dw2_kernel(GemmJob ja, GemmJob j
     const int bx = bid % jb.gx, t = bid / jb.gx;
     gemm_f32_tile<false, false>(jb.a, jb.lda, jb.b, jb.ldb, jb.c, jb.ldc, jb.M, jb.Nc, jb.K, jb.kchunk, jb.ep, jb.vec_a,
                                 jb.vec_b, bx, t % jb.gy, t / jb.gy, jb.gz, As, Bs);
+  }
+}
+
+// gcnx_gemm_dw2 with the classifier head's leaves (gcnx_head_args): the FIRST n_head workgroups of the launch run the head
+// kernel's body (csrc/head_body.h: Dense(softmax) + CCE + accuracy + dW3, db3, db_relu from the pool's partial sums) --
+// 10 us of one workgroup that used to be a launch of its own between the pool and the backward aggregation; here it
+// overlaps the 500-odd split-K tiles.  One LDS block serves both roles (the tile images / the head's staged operands).
+struct HeadLeaf {
+  const float* w; const float* bias; const float* y; int32_t b, h, c; float denom;
+  float* probs; float* loss_acc; float* dw; float* db; float* dpooled; int64_t lddp; int64_t ldp;
+  float* slabs; int* ticket; gcnx_head::PoolParts pp; int from_logits;
+};
+constexpr int kDw2HeadLds = 9216;          // floats: >= 2 x 2 x BK x LD (8704) and the head's staged operands at h = 128, c = 2 (9024)
+
+// (The head body's combine runs with ZU = 1: at its stand-alone unroll the body holds 208 VGPRs and the WHOLE launch drops
+// to two waves per SIMD -- the tiles then take 24.2 us instead of 22.3.  106 VGPRs as built; check after any change.)
+__global__ __launch_bounds__(256) void gemm_f32_dw2_head_kernel(GemmJob ja, GemmJob jb, int n_a, HeadLeaf hl, int n_head) {
+  struct Lds { float As[2][BK][LD]; float Bs[2][BK][LD]; float pad[kDw2HeadLds - 2 * 2 * BK * LD]; };
+  __shared__ __attribute__((aligned(16))) Lds sm;
+  static_assert(2 * 2 * BK * LD <= kDw2HeadLds, "tile images");
+  float* smem = &sm.As[0][0][0];
+  int bid = blockIdx.x;                      // uniform per workgroup
+  if (bid < n_head) {
+    // (two classes only -- the host checks: the generic instance keeps 32 class slots of static LDS per graph, which would
+    // cost this launch a workgroup per CU)
+    __builtin_amdgcn_s_setprio(3);     // one workgroup, a chain of dependent phases: its waves go first among the CU's tile waves
+    gcnx_head::head_body<true, true, 2, 1>(nullptr, hl.ldp, hl.w, hl.bias, hl.y, hl.b, hl.h, hl.c, hl.denom, hl.probs, hl.loss_acc, hl.dw,
+                                        hl.db, hl.dpooled, hl.lddp, hl.slabs, hl.ticket, hl.pp, hl.from_logits, smem, bid, n_head);
+    return;
+  }
+  bid -= n_head;
+  if (bid < n_a) {
+    const int bx = bid % ja.gx, t = bid / ja.gx;
+    gemm_f32_tile<false, false>(ja.a, ja.lda, ja.b, ja.ldb, ja.c, ja.ldc, ja.M, ja.Nc, ja.K, ja.kchunk, ja.ep, ja.vec_a,
+                                ja.vec_b, bx, t % ja.gy, t / ja.gy, ja.gz, sm.As, sm.Bs);
+  } else {
+    bid -= n_a;
+    const int bx = bid % jb.gx, t = bid / jb.gx;
+    gemm_f32_tile<false, false>(jb.a, jb.lda, jb.b, jb.ldb, jb.c, jb.ldc, jb.M, jb.Nc, jb.K, jb.kchunk, jb.ep, jb.vec_a,
+                                jb.vec_b, bx, t % jb.gy, t / jb.gy, jb.gz, sm.As, sm.Bs);
   }
 }
 
@@ -1233,8 +1274,17 @@ int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh
 int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha, int64_t lddha, float* dwa, int32_t fia,
                   int32_t foa, const float* xb, int64_t ldxb, const float* dhb, int64_t lddhb, float* dwb, int32_t fib,
                   int32_t fob, int64_t n, int prec, float* params, float* grads, int64_t n_params, float lr,
-                  const gcnx_pending_reduce* pending) {
+                  const gcnx_pending_reduce* pending, const gcnx_head_args* leaf) {
   GCNX_CHECK_CTX(ctx);
+  if (leaf) {
+    GCNX_REQUIRE(ctx, leaf->part && leaf->graph_ptr && leaf->w && leaf->y && leaf->probs && leaf->loss_acc && leaf->dw && leaf->dpooled &&
+                          leaf->pooled && leaf->b > 0 && leaf->h > 0 && leaf->h % 4 == 0 && leaf->c >= 1 && leaf->c <= gcnx_head::kHeadMaxC &&
+                          leaf->nsplit >= 1 && leaf->denom > 0.f && (leaf->pool_mode == GCNX_POOL_SUM || leaf->pool_mode == GCNX_POOL_AVG) &&
+                          (leaf->cce_mode == GCNX_CCE_PROBS || leaf->cce_mode == GCNX_CCE_LOGITS) && (!leaf->db_relu || leaf->cnt),
+                 "gcnx_gemm_dw2: inconsistent head arguments");
+    GCNX_REQUIRE(ctx, !params || (leaf->dw >= grads && leaf->dw + (int64_t)leaf->h * leaf->c <= grads + n_params),
+                 "gcnx_gemm_dw2: the head's gradients must lie inside the flat gradient buffer");
+  }
   if (pending && !pending->colpart && !pending->slabs) pending = nullptr;
   GCNX_REQUIRE(ctx, n >= 0 && fia >= 0 && foa >= 0 && fib >= 0 && fob >= 0 && n_params >= 0, "gcnx_gemm_dw2: negative size");
   GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dw2: unknown precision %d", prec);
@@ -1265,6 +1315,7 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
   if (!shapes_ok || nsplit <= 1) {   // bf16 precisions, empty or short inputs: the separate calls
     int rc = flush_pending(ctx, pending);
     if (rc) return rc;
+    if (leaf) { rc = gcnx_head_from_parts(ctx, leaf); if (rc) return rc; }
     rc = gcnx_gemm_dw(ctx, xa, ldxa, dha, lddha, dwa, n, fia, foa, prec);
     if (rc) return rc;
     rc = gcnx_gemm_dw(ctx, xb, ldxb, dhb, lddhb, dwb, n, fib, fob, prec);
@@ -1284,7 +1335,20 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
   GemmJob jb{xb, ldxb, dhb, lddhb, sb, (int64_t)fob, (int64_t)fib, fob, n, kchunk, ep,
              al16(xb) && ldxb % 4 == 0, al16(dhb) && lddhb % 4 == 0, gcnx_cdiv(fob, BN), gcnx_cdiv(fib, BM), nsplit};
   const int n_a = ja.gx * ja.gy * ja.gz, n_b = jb.gx * jb.gy * jb.gz;
-  hipLaunchKernelGGL(gemm_f32_dw2_kernel, dim3(n_a + n_b), dim3(256), 0, ctx->stream, ja, jb, n_a);
+  const bool want_db = leaf && leaf->db_relu;
+  const bool merged = leaf && leaf->c == 2 && gcnx_head::head_lds_floats(leaf->h, leaf->c, want_db) <= (size_t)kDw2HeadLds &&
+                      leaf->b <= gcnx_head::kHeadRows;
+  if (leaf && !merged) { rc = gcnx_head_from_parts(ctx, leaf); if (rc) return rc; }   // (many graphs / wide operands: its own launch)
+  if (merged) {
+    HeadLeaf hl{leaf->w, leaf->bias, leaf->y, leaf->b, leaf->h, leaf->c, leaf->denom, leaf->probs, leaf->loss_acc, leaf->dw, leaf->db,
+                leaf->dpooled, (int64_t)leaf->h, (int64_t)leaf->h, nullptr, ctx->flag + 3,
+                gcnx_head::PoolParts{leaf->part, leaf->graph_ptr, leaf->pooled, leaf->nsplit, leaf->pool_mode == GCNX_POOL_AVG ? 1 : 0,
+                                     want_db ? leaf->cnt : nullptr, want_db ? leaf->db_relu : nullptr},
+                leaf->cce_mode == GCNX_CCE_LOGITS ? 1 : 0};
+    hipLaunchKernelGGL(gemm_f32_dw2_head_kernel, dim3(1 + n_a + n_b), dim3(256), 0, ctx->stream, ja, jb, n_a, hl, 1);
+  } else {
+    hipLaunchKernelGGL(gemm_f32_dw2_kernel, dim3(n_a + n_b), dim3(256), 0, ctx->stream, ja, jb, n_a);
+  }
   GCNX_LAUNCH_OK(ctx);
   // one reduction launch either way: with params == NULL reduce_sgd_kernel only folds (offsets relative to `base`)
   float* base = params ? grads : std::min(dwa, dwb);

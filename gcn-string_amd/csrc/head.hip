@@ -147,3 +147,40 @@ static int head_impl(gcnx_ctx* ctx, const float* pooled, int64_t ldp, const floa
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
+
+// The classifier head from the pool's partial sums (gcnx_head_args), as a launch of its own.
+int gcnx_head_from_parts(gcnx_ctx* ctx, const gcnx_head_args* a) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, a != nullptr, "gcnx_head_from_parts: NULL arguments");
+  const bool want_db = a->db_relu != nullptr;
+  const size_t need = head_lds_floats(a->h, a->c, want_db);
+  GCNX_REQUIRE(ctx, need <= (size_t)kHeadLdsFloats, "gcnx_head_from_parts: operands too large for the head kernel (h=%d c=%d)", a->h, a->c);
+  const int nblk = gcnx_cdiv(a->b, kHeadRows);
+  const size_t slab_floats = nblk > 1 ? (((size_t)nblk * ((size_t)a->h * a->c + a->c + 2 + (want_db ? a->h : 0)) + 3) & ~(size_t)3) : 0;
+  if (slab_floats) {
+    int rc = gcnx_ws_reserve(ctx, slab_floats * sizeof(float));
+    if (rc) return rc;
+  }
+  const PoolParts pp{a->part, a->graph_ptr, a->pooled, a->nsplit, a->pool_mode == GCNX_POOL_AVG ? 1 : 0, want_db ? a->cnt : nullptr,
+                     want_db ? a->db_relu : nullptr};
+  const int fl = a->cce_mode == GCNX_CCE_LOGITS ? 1 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&head_kernel<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kHeadLdsFloats * 4));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&head_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kHeadLdsFloats * 4));
+    attr_set = true;
+  }
+  if (a->c == 2)
+    hipLaunchKernelGGL((head_kernel<true, true, 2>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, (const float*)nullptr,
+                       (int64_t)a->h, a->w, a->bias, a->y, a->b, a->h, a->c, a->denom, a->probs, a->loss_acc, a->dw, a->db, a->dpooled,
+                       (int64_t)a->h, slab_floats ? (float*)ctx->ws : nullptr, ctx->flag + 3, pp, fl);
+  else
+    hipLaunchKernelGGL((head_kernel<true, true, 0>), dim3(nblk), dim3(256), need * sizeof(float), ctx->stream, (const float*)nullptr,
+                       (int64_t)a->h, a->w, a->bias, a->y, a->b, a->h, a->c, a->denom, a->probs, a->loss_acc, a->dw, a->db, a->dpooled,
+                       (int64_t)a->h, slab_floats ? (float*)ctx->ws : nullptr, ctx->flag + 3, pp, fl);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+

@@ -28,7 +28,9 @@ struct PoolParts {
 // The body of head_kernel as a device function: `s_dyn` is the LDS area for the staged operands, (bx, nblk) this
 // workgroup's index and the number of head workgroups -- so that the same code can run as the first workgroups of
 // another 256-thread launch (gemm.hip: the weight-gradient launch of a small-batch step hides the head's leaves).
-template <bool STAGED, bool PARTS = false, int CT = 0>
+// ZU: unroll of the partial-sum combine (ZU x 32 VGPRs of loads in flight: 4 as a kernel of its own, 2 inside the
+// weight-gradient launch, whose tile workgroups need the 128-VGPR occupancy).
+template <bool STAGED, bool PARTS = false, int CT = 0, int ZU = 4>
 __device__ __forceinline__ void head_body(const float* __restrict__ pooled, int64_t ldp, const float* __restrict__ w,
                                           const float* __restrict__ bias, const float* __restrict__ y, int32_t b, int32_t h,
                                           int32_t c_rt, float denom, float* __restrict__ probs, float* __restrict__ loss_acc,
@@ -38,8 +40,10 @@ __device__ __forceinline__ void head_body(const float* __restrict__ pooled, int6
   static_assert(STAGED || !PARTS, "partials are combined into the LDS copy");
   const int c = CT > 0 ? CT : c_rt;
   constexpr bool staged = STAGED;
-  __shared__ float s_z[kHeadRows][kHeadMaxC + 1];   // logits, then dlogits
-  __shared__ float s_y[kHeadRows * kHeadMaxC];      // labels of this workgroup's graphs, [rows][c] packed
+  constexpr int MC = CT > 0 ? CT : kHeadMaxC;       // class slots held in LDS (a compile-time class count keeps this small:
+                                                    // the body also runs inside a launch whose occupancy the total decides)
+  __shared__ float s_z[kHeadRows][MC + 1];          // logits, then dlogits
+  __shared__ float s_y[kHeadRows * MC];             // labels of this workgroup's graphs, [rows][c] packed
   __shared__ float s_red[2][256];
   __shared__ int s_last;
   // s_dyn (argument): staged pooled rows [rows][h+1] | w [h*c] | counts | db partials
@@ -84,7 +88,7 @@ __device__ __forceinline__ void head_body(const float* __restrict__ pooled, int6
           acc[u] = cacc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           nn[u] = pp.avg ? pp.gp[g0 + ii[u] + 1] - pp.gp[g0 + ii[u]] : 1;
         }
-#pragma unroll 4
+#pragma unroll ZU
         for (int z = 0; z < pp.nsplit; ++z) {                       // slice order, as pool_combine_kernel
 #pragma unroll
           for (int u = 0; u < 4; ++u) {

@@ -476,20 +476,45 @@ def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None, wt=None, prec="f32
     return out
 
 
-def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mode="sum", scratch=None, w2t=None, prec="f32"):
+def pool_parts_split(ctx, b, h, mode="sum"):
+    """Row slices per graph pool_parts uses for this batch shape (gcnx_pool_parts_split)."""
+    return int(ctx.lib.gcnx_pool_parts_split(ctx.h, int(b), int(h), L.POOLS[mode]))
+
+
+def pool_parts(ctx, seg, x, part, cnt, nsplit, mode="sum"):
+    """part[z][g][:] / cnt[z][g][:] = row sums / positive counts of slice z of graph g (gcnx_pool_parts): the pool of a
+    step whose classifier head runs inside the backward launches (head_args)."""
+    n, h = x.shape
+    assert part.size >= nsplit * seg.n_graphs * h and (cnt is None or cnt.size >= nsplit * seg.n_graphs * h)
+    ctx._ck(ctx.lib.gcnx_pool_parts(ctx.h, seg.dev.ptr, _p(x), x.ld, seg.n_graphs, h, L.POOLS[mode], int(nsplit), _p(part), _p(cnt)))
+
+
+def head_args(seg, part, cnt, nsplit, w, bias, y, denom, probs, loss_acc, dw, db, db_relu, pooled, dpooled, mode="sum", cce="logits"):
+    """gcnx_head_args for gcn_conv_bwd_pool(head=...) and gemm_dw2(leaf=...).  The DeviceArrays must outlive the calls."""
+    b, h = seg.n_graphs, w.shape[0]
+    c = w.shape[1]
+    assert w.contiguous and pooled.contiguous and dpooled.contiguous and pooled.shape == (b, h) and dpooled.shape == (b, h)
+    return L.HeadArgs(_p(part), _p(cnt), int(nsplit), seg.dev.ptr, b, h, L.POOLS[mode], _p(w), _p(bias), _p(y), c, float(denom),
+                      L.CCES[cce], _p(probs), _p(loss_acc), _p(dw), _p(db), _p(db_relu), _p(pooled), _p(dpooled))
+
+
+def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mode="sum", scratch=None, w2t=None, prec="f32",
+                      head=None):
     """dz2 = pool'(dpooled) * [y2 > 0], dz1 = ((A^T dz2) w2^T) * [y1 > 0], db1 = column sums of dz1 -- one launch
     (gcnx_gcn_conv_bwd_pool).  With ``scratch`` the db1 reduction is left pending: returns the PendingReduce for
     gemm_dw2 (all zeros when nothing is pending).  w2t: w2^T as written by gcn_conv_fwd(wt=...), read instead of w2."""
     n, f2 = y2.shape
     f1 = w2.shape[0]
     assert at.n == n and w2.shape == (f1, f2) and w2.contiguous and y1.shape == (n, f1) and dz1.shape == (n, f1)
-    assert dpooled.shape == (seg.n_graphs, f2) and (dz2 is None or dz2.shape == (n, f2))
+    assert (head is not None or dpooled.shape == (seg.n_graphs, f2)) and (dz2 is None or dz2.shape == (n, f2))
     pend = L.PendingReduce()
     ctx._ck(ctx.lib.gcnx_gcn_conv_bwd_pool(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y2), y2.ld, seg.ids.ptr,
-                                           seg.dev.ptr, seg.n_graphs, _p(dpooled), dpooled.ld, L.POOLS[mode], n, f2,
+                                           seg.dev.ptr, seg.n_graphs, _p(dpooled), dpooled.ld if dpooled is not None else 0,
+                                           L.POOLS[mode], n, f2,
                                            _p(w2t if w2t is not None else w2), f1, 1 if w2t is not None else 0, _p(y1), y1.ld, _p(dz2), dz2.ld if dz2 is not None else 0, _p(dz1), dz1.ld, _p(db1),
                                            _p(scratch), scratch.size if scratch is not None else 0,
-                                           C.byref(pend) if scratch is not None else None, L.PRECS[prec]))
+                                           C.byref(pend) if scratch is not None else None, L.PRECS[prec],
+                                           C.byref(head) if head is not None else None))
     return pend
 
 
@@ -497,7 +522,7 @@ def gcn_conv_bwd_scratch_floats(ctx, n, f1):
     return int(ctx.lib.gcnx_gcn_conv_bwd_scratch_floats(int(n), int(f1)))
 
 
-def gemm_dw2(ctx, xa, dha, dwa, xb, dhb, dwb, prec="f32", params=None, grads=None, lr=0.0, pending=None):
+def gemm_dw2(ctx, xa, dha, dwa, xb, dhb, dwb, prec="f32", params=None, grads=None, lr=0.0, pending=None, leaf=None):
     """dwa = xa^T dha and dwb = xb^T dhb in one launch; with params / grads (the flat buffers both gradients are
     views of) the reduction also applies the SGD step and finishes ``pending`` (gcnx_gemm_dw2)."""
     n, fia = xa.shape
@@ -507,7 +532,7 @@ def gemm_dw2(ctx, xa, dha, dwa, xb, dhb, dwb, prec="f32", params=None, grads=Non
     ctx._ck(ctx.lib.gcnx_gemm_dw2(ctx.h, _p(xa), xa.ld, _p(dha), dha.ld, _p(dwa), fia, foa, _p(xb), xb.ld, _p(dhb), dhb.ld,
                                   _p(dwb), fib, fob, n, L.PRECS[prec], _p(params), _p(grads),
                                   params.size if params is not None else (grads.size if grads is not None else 0), float(lr),
-                                  C.byref(pending) if pending is not None else None))
+                                  C.byref(pending) if pending is not None else None, C.byref(leaf) if leaf is not None else None))
 
 
 def pool_bwd_colsum(ctx, seg, dpooled, y, db, mode="sum"):

@@ -129,7 +129,8 @@ class GCN2(_GraphRunner):
         self.use_graph = use_graph
         # tuning knobs (diagnostics), read ONCE here -- the sequence a model runs never changes under it
         self._knob = {"fold": os.environ.get("GCNX_FOLD", "1") != "0", "duo": os.environ.get("GCNX_DUO", "1") != "0",
-                      "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1"))}
+                      "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1")),
+                      "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0"}
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
@@ -196,6 +197,9 @@ class GCN2(_GraphRunner):
         if self._fused(batch):                                  # one-launch layers: S1 = A X, S2 = A Y1 (operands of dW)
             self._bufs["s1"], self._bufs["s2"] = v("s1", n, self.f_in), v("s2", n, h)
             self._bufs["w2t"] = v("w2t", h, h)                  # W2^T, a by-product of layer 2's forward launch
+            ns = D.pool_parts_split(self.ctx, b, h, self.pool) if self.pool in ("sum", "avg") else 1
+            self._bufs["pp_n"] = ns                             # the pool's partial sums / positive counts (head inside the backward)
+            self._bufs["pp_part"], self._bufs["pp_cnt"] = v("pp_part", ns * b, h), v("pp_cnt", ns * b, h)
         for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
             self._bufs[k] = v(k, b, w)
         self._bufs["arg"] = v("arg", b, h, np.int32) if self.pool == "max" else None
@@ -228,7 +232,16 @@ class GCN2(_GraphRunner):
         # Global pool, then Dense(softmax) + CCE + accuracy + the head gradients in one launch; with few graphs the
         # head also combines the pool's row-slice partial sums (gcnx_pool_dense_softmax_cce)
         head = dict(mode=self.pool, argmax=bufs["arg"])
-        if with_loss == "grads":
+        bufs["_head_late"] = None
+        if with_loss == "grads" and self._head_late(batch):
+            # one-launch layers with a backward pass to follow: only the pool's partial sums here.  The backward
+            # aggregation evaluates dPooled per graph itself and the rest of the head (probabilities, loss, accuracy, dW3,
+            # db3, db2 -- leaves) rides in the weight-gradient launch: the head's 10 us are off the critical path.
+            D.pool_parts(ctx, batch.seg, bufs["y2"], bufs["pp_part"], bufs["pp_cnt"], bufs["pp_n"], self.pool)
+            bufs["_head_late"] = D.head_args(batch.seg, bufs["pp_part"], bufs["pp_cnt"], bufs["pp_n"], p["w3"], p["b3"], batch.y, denom,
+                                             bufs["probs"], self.loss_acc, self.g["w3"], self.g["b3"], self.g["b2"], bufs["pooled"],
+                                             bufs["dpooled"], mode=self.pool, cce=self.cce_train)
+        elif with_loss == "grads":
             # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"],
@@ -257,15 +270,16 @@ class GCN2(_GraphRunner):
         if self._fused(batch):
             # pool' + ReLU' + A^T + W2^T + ReLU' in one launch (dZ2 and dZ1 out, db1 partials pending; db2 came out of
             # the head), then both weight gradients -- dW1 = S1^T dZ1, dW2 = S2^T dZ2 -- and the update in the last two
-            pend = D.gcn_conv_bwd_pool(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], p["w2"], bufs["y1"], bufs["dz"],
-                                       bufs["dz2"], db1=g["b1"], mode=self.pool, scratch=self._defer_scratch(batch),
-                                       w2t=bufs["w2t"], prec=prec)
+            ha = bufs.get("_head_late")
+            pend = D.gcn_conv_bwd_pool(ctx, at, bufs["y2"], batch.seg, None if ha is not None else bufs["dpooled"], p["w2"], bufs["y1"],
+                                       bufs["dz"], bufs["dz2"], db1=g["b1"], mode=self.pool, scratch=self._defer_scratch(batch),
+                                       w2t=bufs["w2t"], prec=prec, head=ha)
             if lr is None:
                 D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec="f32",
-                           grads=self.flat_g.flat(0, self.n_params), pending=pend)
+                           grads=self.flat_g.flat(0, self.n_params), pending=pend, leaf=ha)
                 return False
             D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec="f32", params=self.flat_p,
-                       grads=self.flat_g.flat(0, self.n_params), lr=lr, pending=pend)
+                       grads=self.flat_g.flat(0, self.n_params), lr=lr, pending=pend, leaf=ha)
             return True
         if fold:
             D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool,
@@ -324,6 +338,12 @@ class GCN2(_GraphRunner):
                 and self._knob["duo"] and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.f_in, self.hidden)
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))
+
+    def _head_late(self, batch):
+        """One-launch layers (see _fused; SUM / AVG pooling) and at most 2 classes (the reference's binary labels): the
+        classifier head is evaluated inside the backward launches (gcnx_head_args) instead of between the pool and the
+        backward aggregation."""
+        return self._knob["head_late"] and self._fused(batch) and self.n_labels <= 2 and batch.y is not None
 
     def _backward_knob(self, batch, bufs, side):
         """The same backward with individual side sections switched off (GCNX_SIDE bits; measurement only)."""

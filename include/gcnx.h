@@ -379,6 +379,29 @@ GCNX_API int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32
                       const float* x, int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo,
                       const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out,
                       int prec);
+/* The classifier head of a small-batch step whose pool is still in partial sums (plain data, no ownership).  In a
+ * latency-bound step the head's launch -- Dense(softmax) + CCE + their gradients on a [B, H] operand: 10 us of one
+ * workgroup -- sits between the pool and the backward aggregation only because that needs dPooled.  With this struct
+ * gcnx_gcn_conv_bwd_pool evaluates dPooled per graph itself (a few hundred flops per row group) and gcnx_gemm_dw2 runs
+ * everything else the head produces (probabilities, loss, accuracy, dW, db, db_relu: leaves nobody in the step waits
+ * for) as the FIRST workgroups of the weight-gradient launch, where it costs nothing.
+ *   part / cnt: gcnx_pool_parts output [nsplit][b][h]; w [h, c], bias [c], y [b, c] one-hot; c <= 2 for the in-kernel form
+ *   (gcnx_gcn_conv_bwd_pool returns GCNX_ERR_UNSUPPORTED beyond that; gcnx_gemm_dw2 takes any c the head kernel does).
+ *   outputs (written by gcnx_gemm_dw2): probs [b, c], loss_acc [2] (mean loss, hit count), dw [h, c], db [c],
+ *   db_relu [h] (may be NULL), pooled [b, h], dpooled [b, h]. */
+typedef struct gcnx_head_args {
+  const float* part; const float* cnt; int32_t nsplit;
+  const int32_t* graph_ptr; int32_t b; int32_t h; int pool_mode;
+  const float* w; const float* bias; const float* y; int32_t c; float denom; int cce_mode;
+  float* probs; float* loss_acc; float* dw; float* db; float* db_relu; float* pooled; float* dpooled;
+} gcnx_head_args;
+/* Row slices per graph gcnx_pool_parts uses (>= 1; a function of b, h and the device), and the partial pool itself:
+ * part[z][g][:] = sum of the rows of slice z of graph g, cnt likewise the number of positive entries (SUM / AVG only;
+ * the 1 / n_g of the average pool is applied by the consumers).  part / cnt: nsplit * b * h floats each. */
+GCNX_API int gcnx_pool_parts_split(gcnx_ctx* ctx, int32_t b, int32_t h, int mode);
+GCNX_API int gcnx_pool_parts(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t h,
+                    int mode, int32_t nsplit, float* part, float* cnt);
+
 /* Backward from the global pool down to the pre-activation gradient of the layer below, one launch:
  *   dZ2[j] = pool'(dpooled)[graph(j)] * [y2[j] > 0]                      (GlobalSumPool / GlobalAvgPool', ReLU')
  *   dz1    = ((A^T dZ2) w2^T) * [y1 > 0]                                 (aggregation', MatMul', ReLU' of layer 1)
@@ -388,21 +411,25 @@ GCNX_API int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32
  * y2 [n, f2], y1 [n, f1]: the saved ReLU outputs.  dz2 (may be NULL) receives dZ2 [n, f2] (the operand
  * of dW2 = S2^T dZ2).  db1 (may be NULL): with `pending` and a scratch of >= gcnx_gcn_conv_bwd_scratch_floats(n, f1)
  * floats the per-tile partial sums stay in scratch and *pending describes the reduction (gcnx_gemm_dw2 finishes it);
- * otherwise db1 is complete on return.  mode: GCNX_POOL_SUM / GCNX_POOL_AVG. */
+ * otherwise db1 is complete on return.  mode: GCNX_POOL_SUM / GCNX_POOL_AVG.  head (may be NULL): see gcnx_head_args --
+ * dpooled is then not read (may be NULL). */
 GCNX_API int64_t gcnx_gcn_conv_bwd_scratch_floats(int64_t n, int32_t f1);
 GCNX_API int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* vals_t,
                       const float* y2, int64_t ldy2, const int32_t* node_graph, const int32_t* graph_ptr, int32_t b,
                       const float* dpooled, int64_t lddp, int mode, int32_t n, int32_t f2, const float* w2, int32_t f1,
                       int w2_transposed, const float* y1, int64_t ldy1, float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* db1,
-                      float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec);
+                      float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec,
+                      const gcnx_head_args* head);
 /* Two weight gradients in one launch, dwa = xa^T dha [fia, foa] and dwb = xb^T dhb [fib, fob] over the same n rows
  * (MatMul grads wrt the kernels, gcn.py:337), both inside the flat gradient buffer `grads`; with params != NULL the
  * reduction launch also applies p -= lr * g to all n_params parameters and finishes `pending` (column sums left by
- * gcnx_gcn_conv_bwd_pool), as gcnx_gemm_dw_sgd does.  params == NULL: gradients only. */
+ * gcnx_gcn_conv_bwd_pool), as gcnx_gemm_dw_sgd does.  params == NULL: gradients only.  leaf (may be NULL): the classifier
+ * head's outputs (gcnx_head_args) are computed by the first workgroups of the same launch; its gradients must lie in
+ * `grads` too when params != NULL (they are updated with the rest). */
 GCNX_API int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha, int64_t lddha, float* dwa,
                       int32_t fia, int32_t foa, const float* xb, int64_t ldxb, const float* dhb, int64_t lddhb,
                       float* dwb, int32_t fib, int32_t fob, int64_t n, int prec, float* params, float* grads,
-                      int64_t n_params, float lr, const gcnx_pending_reduce* pending);
+                      int64_t n_params, float lr, const gcnx_pending_reduce* pending, const gcnx_head_args* leaf);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new capability) ---- */
 GCNX_API int gcnx_comm_unique_id(char id[GCNX_UNIQUE_ID_BYTES]);

@@ -1057,6 +1057,121 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode, prec):
     assert rel_err(grads.numpy(), rg) < tol
 
 
+@pytest.mark.parametrize("cce", ["logits", "probs"])
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+@pytest.mark.parametrize("shape,h,c", [("ecoli", 128, 2), ("ecoli", 32, 1), ("ragged", 64, 2), ("many", 32, 2)])
+def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
+    """gcnx_head_args: pool partials (gcnx_pool_parts) -> gcnx_gcn_conv_bwd_pool(head) evaluates dPooled per graph itself ->
+    gcnx_gemm_dw2(leaf) produces the head's outputs, against the sequence pool + head launch -> backward -> dw2 with the
+    same operands.  "ragged": single-node graphs, so 32-row tiles span more than the two graphs wave 0 precomputes (the
+    per-row path); "many": more graphs than one head workgroup holds (the leaf falls back to a launch of its own);
+    "ecoli" at h = 128, c = 2 is the shape the merged launch serves.  Two runs agree bit for bit."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    rng = np.random.default_rng(h + c)
+    if shape == "ecoli":
+        hb = synth.ecoli_batch(4, h, seed=h)
+        rowptr, colidx, gp = hb.rowptr, hb.colidx, hb.graph_ptr
+    else:
+        sizes = (np.array([1, 1, 1, 2, 1, 50, 1, 1, 1, 1, 3, 1, 70, 1, 1], np.int64) if shape == "ragged"
+                 else rng.integers(1, 40, 90))
+        gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        rows, cols = [], []
+        for g in range(len(sizes)):                                     # self-loops and a chain inside every graph
+            for i in range(gp[g], gp[g + 1]):
+                rows.append(i); cols.append(i)
+                if i + 1 < gp[g + 1]:
+                    rows += [i, i + 1]; cols += [i + 1, i]
+        order = np.lexsort((cols, rows))
+        rows, cols = np.asarray(rows)[order], np.asarray(cols)[order]
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=int(gp[-1])))]).astype(np.int32)
+        colidx = cols.astype(np.int32)
+    n, b, f1 = int(gp[-1]), len(gp) - 1, 64
+    vals = (rng.random(len(colidx)) + 0.25).astype(np.float32)
+    a = DeviceCSR.from_host_csr(ctx, rowptr, colidx, vals, gp, symmetric=False)
+    seg = Segments(ctx, gp)
+    y2 = ctx.to_device(np.maximum(rng.standard_normal((n, h), dtype=np.float32), 0))
+    y1 = ctx.to_device(np.maximum(rng.standard_normal((n, f1), dtype=np.float32), 0))
+    w2 = ctx.to_device((rng.standard_normal((f1, h)) / np.sqrt(f1)).astype(np.float32))
+    s1 = ctx.to_device(rng.standard_normal((n, 32), dtype=np.float32)); s2 = ctx.to_device(rng.standard_normal((n, f1), dtype=np.float32))
+    scale = np.sqrt(h) * (n / b if mode == "sum" else 1.0)              # logits of order 1: no saturated softmax, gradients flow
+    w3 = ctx.to_device((rng.standard_normal((h, c)) / scale).astype(np.float32))
+    b3 = ctx.to_device(rng.standard_normal(c).astype(np.float32))
+    y = ctx.to_device(np.eye(c, dtype=np.float32)[rng.integers(0, c, b)])
+    denom = float(b + 1)
+    # flat gradient buffer: dW1 | dW2 | db1 | dW3 | db3 | db2   (everything the two launches write)
+    offs = [int(v) for v in np.cumsum([0, 32 * f1, f1 * h, f1, h * c, c, h])]
+    names = ("pooled", "probs", "la", "dp", "dz2", "dz1", "grads", "params")
+    out = {}
+    for how in ("early", "late", "late again", "late grads only"):
+        params = ctx.to_device(np.linspace(-1, 1, offs[-1] + 3, dtype=np.float32)); grads = ctx.zeros(offs[-1] + 3)
+        gw1, gw2, gb1 = grads.flat(offs[0], 32 * f1, (32, f1)), grads.flat(offs[1], f1 * h, (f1, h)), grads.flat(offs[2], f1)
+        gw3, gb3, gb2 = grads.flat(offs[3], h * c, (h, c)), grads.flat(offs[4], c), grads.flat(offs[5], h)
+        pooled, probs, la, dp = ctx.zeros((b, h)), ctx.zeros((b, c)), ctx.zeros(2), ctx.zeros((b, h))
+        dz2, dz1 = ctx.empty((n, h)), ctx.empty((n, f1))
+        scratch = ctx.empty(D.gcn_conv_bwd_scratch_floats(ctx, n, f1))
+        sgd = dict(grads=grads) if how == "late grads only" else dict(params=params, grads=grads, lr=0.05)
+        if how == "early":
+            D.pool_dense_softmax_cce(ctx, seg, y2, pooled, w3, b3, y, probs, la, denom, dw=gw3, db=gb3, dpooled=dp, mode=mode,
+                                     db_relu=gb2, cce=cce)
+            pend = D.gcn_conv_bwd_pool(ctx, a.transpose(), y2, seg, dp, w2, y1, dz2, dz1, db1=gb1, mode=mode, scratch=scratch)
+            D.gemm_dw2(ctx, s1, dz1, gw1, s2, dz2, gw2, pending=pend, **sgd)
+        else:
+            ns = D.pool_parts_split(ctx, b, h, mode)
+            part, cnt = ctx.empty((ns * b, h)), ctx.empty((ns * b, h))
+            D.pool_parts(ctx, seg, y2, part, cnt, ns, mode)
+            ha = D.head_args(seg, part, cnt, ns, w3, b3, y, denom, probs, la, gw3, gb3, gb2, pooled, dp, mode=mode, cce=cce)
+            pend = D.gcn_conv_bwd_pool(ctx, a.transpose(), y2, seg, None, w2, y1, dz2, dz1, db1=gb1, mode=mode, scratch=scratch, head=ha)
+            D.gemm_dw2(ctx, s1, dz1, gw1, s2, dz2, gw2, pending=pend, leaf=ha, **sgd)
+        out[how] = dict(zip(names, [t.numpy().copy() for t in (pooled, probs, la, dp, dz2, dz1, grads, params)]))
+    for k in names:
+        assert rel_err(out["late"][k], out["early"][k]) < TIGHT, k
+        assert np.array_equal(out["late"][k], out["late again"][k]), k
+        if k != "params":
+            assert np.array_equal(out["late"][k], out["late grads only"][k]), k
+    assert out["late"]["la"][1] == out["early"]["la"][1]                # hit count
+    assert np.any(out["late"]["grads"][offs[5]:offs[6]] != 0) or c == 1  # db2 was produced (c == 1: all gradients vanish)
+
+
+def test_head_inside_the_backward_refusals_and_fallbacks(ctx):
+    """More than two classes: the backward launch refuses the in-kernel head (GCNX_ERR_UNSUPPORTED); gcnx_gemm_dw2(leaf)
+    alone serves any class count through the head kernel's launch, and also when the weight gradients take their
+    separate calls (too few rows for the split-K launch)."""
+    from gcnx import device as D, synth
+    from gcnx._lib import GcnxError
+    from gcnx.device import DeviceCSR, Segments
+    rng = np.random.default_rng(5)
+    for n_graphs, c in ((3, 3), (1, 2)):
+        hb = synth.ecoli_batch(n_graphs, 32, seed=c) if n_graphs > 1 else synth.power_law_batch(n_graphs=1, graph_size=96, f=32, seed=2, max_deg=24)
+        n, b, h, f1 = hb.n, len(hb.graph_ptr) - 1, 32, 32
+        a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr, symmetric=True)
+        seg = Segments(ctx, hb.graph_ptr)
+        y2 = ctx.to_device(np.maximum(rng.standard_normal((n, h), dtype=np.float32), 0))
+        y1 = ctx.to_device(np.maximum(rng.standard_normal((n, f1), dtype=np.float32), 0))
+        w2 = ctx.to_device((rng.standard_normal((f1, h)) / 6).astype(np.float32))
+        w3 = ctx.to_device((rng.standard_normal((h, c)) / 6).astype(np.float32)); b3 = ctx.zeros(c)
+        y = ctx.to_device(np.eye(c, dtype=np.float32)[rng.integers(0, c, b)])
+        ns = D.pool_parts_split(ctx, b, h, "sum")
+        part, cnt = ctx.empty((ns * b, h)), ctx.empty((ns * b, h))
+        D.pool_parts(ctx, seg, y2, part, cnt, ns, "sum")
+        ref = [ctx.zeros((b, h)), ctx.zeros((b, c)), ctx.zeros(2), ctx.zeros((h, c)), ctx.zeros(c), ctx.zeros((b, h)), ctx.zeros(h)]
+        D.pool_dense_softmax_cce(ctx, seg, y2, ref[0], w3, b3, y, ref[1], ref[2], float(b), dw=ref[3], db=ref[4], dpooled=ref[5],
+                                 mode="sum", db_relu=ref[6])
+        got = [ctx.zeros(t.shape) for t in ref]
+        ha = D.head_args(seg, part, cnt, ns, w3, b3, y, float(b), got[1], got[2], got[3], got[4], got[6], got[0], got[5])
+        dz2, dz1 = ctx.empty((n, h)), ctx.empty((n, f1))
+        if c > 2:
+            with pytest.raises(GcnxError, match="two classes"):
+                D.gcn_conv_bwd_pool(ctx, a.transpose(), y2, seg, None, w2, y1, dz2, dz1, head=ha)
+        D.gcn_conv_bwd_pool(ctx, a.transpose(), y2, seg, ref[5], w2, y1, dz2, dz1)
+        s1 = ctx.to_device(rng.standard_normal((n, 32), dtype=np.float32))
+        gw1, gw2 = ctx.empty((32, f1)), ctx.empty((32, h))
+        D.gemm_dw2(ctx, s1, dz1, gw1, s1, dz2, gw2, leaf=ha)
+        for r, g in zip(ref, got):
+            assert rel_err(g.numpy(), r.numpy()) < TIGHT
+        assert rel_err(gw2.numpy(), s1.numpy().astype(np.float64).T @ dz2.numpy()) < TIGHT
+
+
 def test_gcn_conv_fused_edge_cases(ctx):
     """The one-launch GCNConv on degenerate inputs: fewer rows than a tile, rows without entries, single-node graphs, a
     graph boundary inside every tile, average pooling over graphs of one node -- forward, backward and the column sums."""
