@@ -48,10 +48,16 @@ struct FusedArgs {
   const float* mask; int64_t ldmask;     // Y1 (ReLU output of the layer below)
   float* dz2; int64_t lddz2;             // dZ2 rows of this tile (may be NULL)
   float* colpart;                        // [tiles, nc] column sums of what was written to out (may be NULL)
-  // backward with the classifier head folded in (hd_part != NULL): dPooled is not read -- every row group evaluates
-  // Dense(softmax) + CCE' of its own graph from the pool's partial sums (a few hundred flops), so that the head's kernel
-  // is no longer between the pool and this launch (its remaining outputs are leaves: gcnx_gemm_dw2 computes them)
-  const float* hd_part; int hd_nsplit; int hd_b;       // pool partials [nsplit][b][K]
+  // forward with the global pool's partial sums in the epilogue (tp_part != NULL; node_graph set): row t + g of tp_part /
+  // tp_cnt receives the column sums / positive counts of the rows of graph g in tile t -- (tile, graph) pairs form a
+  // staircase, so t + g is a distinct row for every pair and a graph's partials are the rows t + g of its tiles
+  float* tp_part; float* tp_cnt;
+  // backward with the classifier head folded in (hd_part != NULL): dPooled is not read -- every workgroup evaluates
+  // Dense(softmax) + CCE' of its tile's graphs from those partial sums (a few hundred flops each), so that neither the
+  // pool nor the head is a launch between the forward and this one (the head's other outputs are leaves: gcnx_gemm_dw2
+  // computes them from hd_psum / hd_csum, the per-graph totals the workgroup holding a graph's first row writes here)
+  const float* hd_part; const float* hd_cnt; int hd_rows; int hd_b;   // tile partials [(tiles + b)][K]; rows of the arrays
+  float* hd_psum; float* hd_csum;                                      // [b][K] each
   const float* hd_w; const float* hd_bias; const float* hd_y; int hd_c; float hd_denom; int hd_fl;
   int dbg;                               // tuning builds: phase-ablation bits (1 no gather, 2 no MFMA, 4 no weight load)
 };
@@ -77,42 +83,31 @@ __device__ __forceinline__ float4 f4step(float4 a) {
   return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
 
-// pool'(dPooled) of graph g for this lane's 4 columns, from the pool's partial sums: Dense(softmax) + CCE' evaluated by
-// one lane group (LPR lanes x 4 columns = the K pooled features; logits by lane partials and an xor tree inside the
-// group), the arithmetic of head_kernel.  Two class slots -- the reference's binary labels; a single class leaves the
+// The classifier head inside the backward launch: pooled sums of a graph (this lane's 4 of the K columns; LPR lanes hold
+// a row) -> logits (lane partials + an xor tree inside the lane group) -> softmax -> CCE' -> dlogits, the arithmetic of
+// head_kernel, times the pool's 1 / n_g.  Two class slots -- the reference's binary labels; a single class leaves the
 // second slot at weight 0 and logit -inf (more classes: the host refuses and the step keeps the head's own launch).
-template <int K, int LPR>
-__device__ __forceinline__ float4 fused_head_dpooled(const FusedArgs& p, int g, int sub) {
-  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = 0; z < p.hd_nsplit; ++z) {
-    const float4 q = *reinterpret_cast<const float4*>(p.hd_part + ((int64_t)z * p.hd_b + g) * K + sub * 4);
-    pv.x += q.x; pv.y += q.y; pv.z += q.z; pv.w += q.w;
-  }
+// pool'(dPooled) of the graph is then dl.x * W3[:, 0] + dl.y * W3[:, 1], which every row group forms for its own columns.
+__device__ __forceinline__ void f4acc(float4& a, const float4 q) { a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+
+template <int LPR>
+__device__ __forceinline__ float2 fused_head_dlogits(const FusedArgs& p, float4 pv, int rows, float4 w0, float4 w1, float b0,
+                                                     float b1, float y0, float y1) {
   float sc = 1.0f;
-  if (p.avg) { sc = 1.0f / (float)max(p.gp[g + 1] - p.gp[g], 1); pv.x *= sc; pv.y *= sc; pv.z *= sc; pv.w *= sc; }
-  // (two class slots -- the reference's binary labels; a single class leaves the second slot at weight 0 and
-  // logit -inf.  More classes: the host refuses and the step keeps the head's own launch.)
+  if (p.avg) { sc = 1.0f / (float)max(rows, 1); pv.x *= sc; pv.y *= sc; pv.z *= sc; pv.w *= sc; }
   const bool two = p.hd_c > 1;
-  const float4 w0 = make_float4(p.hd_w[(int64_t)(sub * 4 + 0) * p.hd_c], p.hd_w[(int64_t)(sub * 4 + 1) * p.hd_c],
-                                p.hd_w[(int64_t)(sub * 4 + 2) * p.hd_c], p.hd_w[(int64_t)(sub * 4 + 3) * p.hd_c]);
-  float4 w1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (two) w1 = make_float4(p.hd_w[(int64_t)(sub * 4 + 0) * p.hd_c + 1], p.hd_w[(int64_t)(sub * 4 + 1) * p.hd_c + 1],
-                            p.hd_w[(int64_t)(sub * 4 + 2) * p.hd_c + 1], p.hd_w[(int64_t)(sub * 4 + 3) * p.hd_c + 1]);
   float z0 = fmaf(pv.w, w0.w, fmaf(pv.z, w0.z, fmaf(pv.y, w0.y, pv.x * w0.x)));
   float z1 = fmaf(pv.w, w1.w, fmaf(pv.z, w1.z, fmaf(pv.y, w1.y, pv.x * w1.x)));
 #pragma unroll
   for (int off = 1; off < LPR; off <<= 1) { z0 += __shfl_xor(z0, off); z1 += __shfl_xor(z1, off); }
-  z0 += p.hd_bias ? p.hd_bias[0] : 0.f;
-  z1 = two ? z1 + (p.hd_bias ? p.hd_bias[1] : 0.f) : -INFINITY;
-  const float y0 = p.hd_y[(int64_t)g * p.hd_c], y1 = two ? p.hd_y[(int64_t)g * p.hd_c + 1] : 0.f;
+  z0 += b0;
+  z1 = two ? z1 + b1 : -INFINITY;
   const float m = fmaxf(z0, z1), e0 = expf(z0 - m), e1 = expf(z1 - m), sum = e0 + e1;
   const float p0 = e0 / sum, p1 = e1 / sum;
   const bool k0 = p.hd_fl || (p0 > 1e-7f && p0 < 1.0f - 1e-7f), k1 = two && (p.hd_fl || (p1 > 1e-7f && p1 < 1.0f - 1e-7f));
   const float ymsum = (k0 ? y0 : 0.f) + (k1 ? y1 : 0.f);
   const float dl0 = (p0 * ymsum - (k0 ? y0 : 0.f)) / p.hd_denom, dl1 = two ? (p1 * ymsum - (k1 ? y1 : 0.f)) / p.hd_denom : 0.f;
-  const float4 d = make_float4(fmaf(dl1, w1.x, dl0 * w0.x), fmaf(dl1, w1.y, dl0 * w0.y), fmaf(dl1, w1.z, dl0 * w0.z),
-                               fmaf(dl1, w1.w, dl0 * w0.w));
-  return make_float4(d.x * sc, d.y * sc, d.z * sc, d.w * sc);
+  return make_float2(dl0 * sc, dl1 * sc);
 }
 
 // X3: the product phase on the bf16 MFMA with split operands (hi = bf16(x), lo = bf16(x - hi); hi*lo + lo*hi + hi*hi, fp32
@@ -134,8 +129,10 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   __shared__ __attribute__((aligned(8))) int2 s_ent[kFCap + 2 * U];
   __shared__ int32_t s_rp[kFRows + 1];
   __shared__ unsigned char s_mb[BWD ? kFRows * 32 : 1];   // backward: [Y1 > 0] of the tile, 4 columns per byte
-  __shared__ float4 s_hd[BWD ? 2 : 1][LPR];               // backward, head folded in: pool'(dPooled) of the tile's first two graphs
-  __shared__ int s_hdg;
+  __shared__ float2 s_dl[BWD ? kFRows : 1];               // backward, head folded in: dlogits x pool scale of the tile's graphs
+  __shared__ __attribute__((aligned(16))) float s_w3[BWD ? 2 : 1][K];   // ... and the two columns of W3
+  __shared__ int32_t s_g[BWD ? 1 : kFRows];               // forward with the pool's partial sums: graph of each row
+  static_assert(!BWD || sizeof(float) * kFRows * (K + 4) >= sizeof(float4) * 2 * 8 * 2 * LPR, "the head's wave partials alias the tile");
 #ifdef GCNX_TUNING
   const int dbg = p.dbg;
 #else
@@ -147,6 +144,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   const int t = gcnx_xcd_remap(blockIdx.x, ntiles);
   const int r0 = t * kFRows, nr = min(p.n - r0, kFRows);
   if (tid <= nr) s_rp[tid] = p.rowptr[r0 + tid];
+  if (!BWD && p.tp_part && tid < kFRows) s_g[tid] = tid < nr ? p.node_graph[r0 + tid] : -1;
   const int e0 = p.rowptr[r0], e1 = p.rowptr[r0 + nr];
   const int staged = min(e1 - e0, kFCap);
   const unsigned ld4 = (unsigned)p.ldx * 4u;
@@ -174,15 +172,6 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   // backward: the ReLU mask rows of the tile (saved Y1), read here as whole 512-byte rows -- two loads per thread under
   // the staging latency -- and kept as bits in LDS; the epilogue's accumulator layout would read them as 64-byte pieces,
   // eight load instructions per wave in a loop whose cost is counted in instructions (2.2 us of the launch)
-  if (BWD && p.hd_part && wave == 0) {     // (uniform per wave) the classifier head of the tile's first two graphs
-    const int g_first = p.node_graph[r0];
-    const int gsel = lane / LPR;
-    if (gsel < 2) {
-      const float4 d = fused_head_dpooled<K, LPR>(p, min(g_first + gsel, p.hd_b - 1), lane % LPR);
-      s_hd[gsel][lane % LPR] = d;
-    }
-    if (lane == 0) s_hdg = g_first;
-  }
   float4 mrow[2];
   const int mlanes = p.nc >> 2;
   if (BWD) {
@@ -193,7 +182,74 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
       if (row < nr && !(dbg & 16)) mrow[q] = *reinterpret_cast<const float4*>(p.mask + (int64_t)(r0 + row) * p.ldmask + 4 * c4);
     }
   }
-  __syncthreads();
+  // The classifier head of the tile's graphs (uniform branches), two graphs per round -- one round at E. coli sizes, up
+  // to 16 where the graphs are single nodes.  All eight waves add up the two graphs' tile partials, strided (tile
+  // tlo + wave, + 8, ...: two or three 16-byte loads per lane, range-checked buffer loads so that nothing branches around
+  // them), under the staging latency; the round's barrier is the staging barrier; wave 0 then combines the eight in order
+  // -- the same order wherever a graph is evaluated -- and leaves the graphs' dlogits in LDS while the others gather.
+  // The workgroup that holds a graph's first row also writes its totals (the head's leaves read them in gcnx_gemm_dw2).
+  float4 (*s_pv)[2][2][LPR] = reinterpret_cast<float4 (*)[2][2][LPR]>(&tile[0][0]);   // [wave][sum | count][graph][lane]
+  const int hsel = lane / LPR, hsub = lane % LPR;
+  int g_first = 0;
+  if (BWD && p.hd_part) {
+    g_first = __builtin_amdgcn_readfirstlane(p.node_graph[r0]);
+    const int g_last = __builtin_amdgcn_readfirstlane(p.node_graph[r0 + nr - 1]);
+    for (int i = tid; i < 2 * K; i += 512) {
+      const int cls = i / K, k = i - cls * K;
+      s_w3[cls][k] = cls < p.hd_c ? p.hd_w[(int64_t)k * p.hd_c + cls] : 0.f;
+    }
+    const unsigned bytes = (unsigned)p.hd_rows * (unsigned)K * 4u;
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)p.hd_part, (short)0, (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)p.hd_cnt, (short)0, (int)bytes, 0x00020000);
+    for (int gb = g_first; gb <= g_last; gb += 2) {
+      if (gb > g_first) __syncthreads();                 // wave 0 is done with the previous round's partials
+      int hd_g = 0, hd_n = 0;
+      bool hd_desig = false;
+      float y0 = 0.f, y1 = 0.f;
+      if (hsel < 2) {
+        hd_g = min(gb + hsel, g_last);                   // (an odd graph out is evaluated twice: same values)
+        const int hd_a = p.gp[hd_g];
+        hd_n = p.gp[hd_g + 1] - hd_a;
+        hd_desig = hd_a >= r0 && hd_n > 0;               // the graph's first row is in this tile
+        const int tlo = hd_a / kFRows, thi = hd_n > 0 ? (hd_a + hd_n - 1) / kFRows : tlo - 1;
+        float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pc = ps;
+        for (int tb = tlo + wave; __builtin_amdgcn_ballot_w64(tb <= thi) != 0; tb += 32) {
+          float4 q[4], c[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int tt = tb + 8 * u;
+            const unsigned off = tt <= thi ? ((unsigned)(tt + hd_g) * (unsigned)K + (unsigned)hsub * 4u) * 4u : 0xFFFFFFF0u;
+            q[u] = fbuf4(pr, off);
+            c[u] = fbuf4(cr, hd_desig ? off : 0xFFFFFFF0u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { f4acc(ps, q[u]); f4acc(pc, c[u]); }
+        }
+        s_pv[wave][0][hsel][hsub] = ps;
+        s_pv[wave][1][hsel][hsub] = pc;
+        if (wave == 0) {
+          y0 = p.hd_y[(int64_t)hd_g * p.hd_c];
+          y1 = p.hd_c > 1 ? p.hd_y[(int64_t)hd_g * p.hd_c + 1] : 0.f;
+        }
+      }
+      __syncthreads();
+      if (wave == 0 && hsel < 2) {
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), pc = pv;
+#pragma unroll 2
+        for (int w = 0; w < 8; ++w) { f4acc(pv, s_pv[w][0][hsel][hsub]); f4acc(pc, s_pv[w][1][hsel][hsub]); }
+        if (hd_desig) {
+          *reinterpret_cast<float4*>(p.hd_psum + (int64_t)hd_g * K + hsub * 4) = pv;
+          *reinterpret_cast<float4*>(p.hd_csum + (int64_t)hd_g * K + hsub * 4) = pc;
+        }
+        const float2 dl = fused_head_dlogits<LPR>(p, pv, hd_n, *reinterpret_cast<const float4*>(&s_w3[0][hsub * 4]),
+                                                  *reinterpret_cast<const float4*>(&s_w3[1][hsub * 4]),
+                                                  p.hd_bias ? p.hd_bias[0] : 0.f, (p.hd_bias && p.hd_c > 1) ? p.hd_bias[1] : 0.f, y0, y1);
+        if (hsub == 0) s_dl[hd_g - g_first] = dl;
+      }
+    }
+  } else {
+    __syncthreads();
+  }
   if (BWD) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -272,14 +328,16 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
       if (grow[j] >= 0 && p.dz2) own[j] = *reinterpret_cast<const float4*>(p.x + (int64_t)(r0 + r) * p.ldx + sub * 4);
     }
     if (p.hd_part && !(dbg & 32)) {
-      // the head's dPooled rows of the tile's first two graphs were put in LDS by wave 0 under the staging latency; a row of
-      // a later graph (tiles that span three or more graphs: graphs of fewer than 32 rows) evaluates its own
+      // wave 0 left the dlogits of the tile's graphs in LDS while the others were gathering (the barrier also ends the
+      // life of the wave partials in the tile's LDS, which is written next): pool'(dPooled) = dlogits . W3^T per row
+      __syncthreads();
+      const float4 w0 = *reinterpret_cast<const float4*>(&s_w3[0][sub * 4]), w1 = *reinterpret_cast<const float4*>(&s_w3[1][sub * 4]);
 #pragma unroll
       for (int j = 0; j < RPG; ++j) {
         if (grow[j] < 0) continue;
-        const int gi = grow[j] - s_hdg;
-        if (gi < 2) dscale[j] = s_hd[gi][sub];
-        else dscale[j] = fused_head_dpooled<K, LPR>(p, grow[j], sub);
+        const float2 dl = s_dl[grow[j] - g_first];
+        dscale[j] = make_float4(fmaf(dl.y, w1.x, dl.x * w0.x), fmaf(dl.y, w1.y, dl.x * w0.y), fmaf(dl.y, w1.z, dl.x * w0.z),
+                                fmaf(dl.y, w1.w, dl.x * w0.w));
       }
     }
   }
@@ -380,6 +438,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
     }
   }
   float cs = 0.f;
+  float vout[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int row = 16 * (r >> 2) + 4 * kq + (r & 3);
@@ -388,6 +447,30 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
     else { v += bcol; if (p.act == GCNX_ACT_RELU) v = fmaxf(v, 0.f); }
     if (row < nr) p.out[(int64_t)(r0 + row) * p.ldo + col] = v;
     cs += v;                                          // rows in ascending order within the lane
+    vout[r] = v;
+  }
+  if (!BWD && p.tp_part) {
+    // the global pool's partial sums of this tile, per graph present in it (one or two at E. coli sizes): the lane's
+    // rows in ascending order, then the four row groups in a fixed tree -- one 64-byte store per graph and wave
+    int gr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gr[r] = s_g[16 * (r >> 2) + 4 * kq + (r & 3)];      // rows past the end: -1
+    const int g_lo = s_g[0], g_hi = s_g[nr - 1];
+    for (int g = g_lo; g <= g_hi; ++g) {
+      float sm = 0.f, cn = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bool mine = gr[r] == g;
+        sm += mine ? vout[r] : 0.f;
+        cn += (mine && vout[r] > 0.f) ? 1.f : 0.f;
+      }
+      sm += __shfl_xor(sm, 16); cn += __shfl_xor(cn, 16);
+      sm += __shfl_xor(sm, 32); cn += __shfl_xor(cn, 32);
+      if (lane < 16) {
+        p.tp_part[(int64_t)(t + g) * p.nc + col] = sm;
+        p.tp_cnt[(int64_t)(t + g) * p.nc + col] = cn;
+      }
+    }
   }
   if (BWD && p.colpart) {                             // ... then the four row groups (lane >> 4) in a fixed tree
     cs += __shfl_xor(cs, 16);
@@ -424,6 +507,7 @@ int launch_fused(gcnx_ctx* ctx, const FusedArgs& a_in, int k, bool x3) {
 }
 
 inline bool fal16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int64_t tiles_of(int64_t n) { return (n + kFRows - 1) / kFRows; }
 
 bool fused_shape_ok(int64_t n, int32_t k, int32_t nc, int64_t ldx) {
   return n > 0 && (k == 32 || k == 64 || k == 128) && nc >= 16 && nc <= 128 && nc % 16 == 0 && ldx >= k && ldx % 4 == 0 &&
@@ -436,10 +520,13 @@ extern "C" {
 
 int gcnx_gcn_conv_fused_ok(int64_t n, int32_t fi, int32_t fo, int64_t ldx) { return fused_shape_ok(n, fi, fo, ldx) ? 1 : 0; }
 
-int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* x,
-                      int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo, const float* bias, int act, float* s,
-                      int64_t lds, float* out, int64_t ldo, float* wt_out, int prec) {
+int gcnx_gcn_conv_fwd_pool(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* x,
+                           int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo, const float* bias, int act, float* s,
+                           int64_t lds, float* out, int64_t ldo, float* wt_out, int prec, const int32_t* node_graph, int32_t b,
+                           float* tile_part, float* tile_cnt) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, (!tile_part && !tile_cnt) || (tile_part && tile_cnt && node_graph && b > 0 && fal16(tile_part) && fal16(tile_cnt)),
+               "gcnx_gcn_conv_fwd_pool: the pool's partial sums need node_graph, b > 0 and two 16-byte aligned outputs");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gcn_conv_fwd: negative size");
   if (prec != GCNX_PREC_F32 && prec != GCNX_PREC_BF16X3)
     return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_fwd: precision %d (GCNX_PREC_F32 or GCNX_PREC_BF16X3 here)", prec);
@@ -456,7 +543,15 @@ int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colid
   FusedArgs a{};
   a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.x = x; a.ldx = ldx; a.n = n; a.w = w; a.ldw = fo; a.nc = fo;
   a.bias = bias; a.act = act; a.s = s; a.lds = lds; a.out = out; a.ldo = ldo; a.wt_out = wt_out;
+  a.node_graph = node_graph; a.tp_part = tile_part; a.tp_cnt = tile_cnt;
   return launch_fused<false>(ctx, a, fi, prec == GCNX_PREC_BF16X3);
+}
+
+int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* x,
+                      int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo, const float* bias, int act, float* s,
+                      int64_t lds, float* out, int64_t ldo, float* wt_out, int prec) {
+  return gcnx_gcn_conv_fwd_pool(ctx, rowptr, colidx, vals, x, ldx, n, fi, w, fo, bias, act, s, lds, out, ldo, wt_out, prec,
+                                nullptr, 0, nullptr, nullptr);
 }
 
 int64_t gcnx_gcn_conv_bwd_scratch_floats(int64_t n, int32_t f1) { return n <= 0 || f1 <= 0 ? 0 : (int64_t)gcnx_cdiv(n, kFRows) * f1; }
@@ -488,8 +583,10 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
                         (!dz2 || (fal16(dz2) && lddz2 >= f2 && lddz2 % 4 == 0)),
                "gcnx_gcn_conv_bwd_pool: operands must be 16-byte aligned with leading dimensions in multiples of 4 floats");
   if (head) {
-    GCNX_REQUIRE(ctx, head->part && head->w && head->y && head->nsplit >= 1 && head->b == b && head->h == f2 && head->c >= 1 &&
-                          head->denom > 0.f && fal16(head->part) && head->pool_mode == mode &&
+    GCNX_REQUIRE(ctx, head->tile_part && head->tile_cnt && head->pool_sum && head->pool_cnt && head->w && head->y &&
+                          head->tile_rows >= tiles_of(n) + b && head->tile_rows * f2 * 4 < 0xFFFFFFF0ll && head->b == b &&
+                          head->h == f2 && head->c >= 1 && head->denom > 0.f && fal16(head->tile_part) && fal16(head->tile_cnt) &&
+                          fal16(head->pool_sum) && fal16(head->pool_cnt) && head->pool_mode == mode &&
                           (head->cce_mode == GCNX_CCE_PROBS || head->cce_mode == GCNX_CCE_LOGITS),
                  "gcnx_gcn_conv_bwd_pool: inconsistent head arguments");
     if (head->c > 2)
@@ -514,7 +611,8 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
   a.out = dz1; a.ldo = lddz1; a.node_graph = node_graph; a.gp = graph_ptr; a.dp = dpooled; a.lddp = lddp;
   a.avg = mode == GCNX_POOL_AVG ? 1 : 0; a.mask = y1; a.ldmask = ldy1; a.dz2 = dz2; a.lddz2 = lddz2; a.colpart = colpart;
   if (head) {
-    a.hd_part = head->part; a.hd_nsplit = head->nsplit; a.hd_b = head->b; a.hd_w = head->w; a.hd_bias = head->bias; a.hd_y = head->y;
+    a.hd_part = head->tile_part; a.hd_cnt = head->tile_cnt; a.hd_rows = (int)head->tile_rows; a.hd_b = head->b;
+    a.hd_psum = head->pool_sum; a.hd_csum = head->pool_cnt; a.hd_w = head->w; a.hd_bias = head->bias; a.hd_y = head->y;
     a.hd_c = head->c; a.hd_denom = head->denom; a.hd_fl = head->cce_mode == GCNX_CCE_LOGITS ? 1 : 0;
   }
   int rc = launch_fused<true>(ctx, a, f2, prec == GCNX_PREC_BF16X3);

@@ -1277,10 +1277,10 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
                   const gcnx_pending_reduce* pending, const gcnx_head_args* leaf) {
   GCNX_CHECK_CTX(ctx);
   if (leaf) {
-    GCNX_REQUIRE(ctx, leaf->part && leaf->graph_ptr && leaf->w && leaf->y && leaf->probs && leaf->loss_acc && leaf->dw && leaf->dpooled &&
+    GCNX_REQUIRE(ctx, leaf->pool_sum && leaf->graph_ptr && leaf->w && leaf->y && leaf->probs && leaf->loss_acc && leaf->dw && leaf->dpooled &&
                           leaf->pooled && leaf->b > 0 && leaf->h > 0 && leaf->h % 4 == 0 && leaf->c >= 1 && leaf->c <= gcnx_head::kHeadMaxC &&
-                          leaf->nsplit >= 1 && leaf->denom > 0.f && (leaf->pool_mode == GCNX_POOL_SUM || leaf->pool_mode == GCNX_POOL_AVG) &&
-                          (leaf->cce_mode == GCNX_CCE_PROBS || leaf->cce_mode == GCNX_CCE_LOGITS) && (!leaf->db_relu || leaf->cnt),
+                          leaf->denom > 0.f && (leaf->pool_mode == GCNX_POOL_SUM || leaf->pool_mode == GCNX_POOL_AVG) &&
+                          (leaf->cce_mode == GCNX_CCE_PROBS || leaf->cce_mode == GCNX_CCE_LOGITS) && (!leaf->db_relu || leaf->pool_cnt),
                  "gcnx_gemm_dw2: inconsistent head arguments");
     GCNX_REQUIRE(ctx, !params || (leaf->dw >= grads && leaf->dw + (int64_t)leaf->h * leaf->c <= grads + n_params),
                  "gcnx_gemm_dw2: the head's gradients must lie inside the flat gradient buffer");
@@ -1342,8 +1342,8 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
   if (merged) {
     HeadLeaf hl{leaf->w, leaf->bias, leaf->y, leaf->b, leaf->h, leaf->c, leaf->denom, leaf->probs, leaf->loss_acc, leaf->dw, leaf->db,
                 leaf->dpooled, (int64_t)leaf->h, (int64_t)leaf->h, nullptr, ctx->flag + 3,
-                gcnx_head::PoolParts{leaf->part, leaf->graph_ptr, leaf->pooled, leaf->nsplit, leaf->pool_mode == GCNX_POOL_AVG ? 1 : 0,
-                                     want_db ? leaf->cnt : nullptr, want_db ? leaf->db_relu : nullptr},
+                gcnx_head::PoolParts{leaf->pool_sum, leaf->graph_ptr, leaf->pooled, 1, leaf->pool_mode == GCNX_POOL_AVG ? 1 : 0,
+                                     want_db ? leaf->pool_cnt : nullptr, want_db ? leaf->db_relu : nullptr},
                 leaf->cce_mode == GCNX_CCE_LOGITS ? 1 : 0};
     hipLaunchKernelGGL(gemm_f32_dw2_head_kernel, dim3(1 + n_a + n_b), dim3(256), 0, ctx->stream, ja, jb, n_a, hl, 1);
   } else {

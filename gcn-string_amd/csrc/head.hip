@@ -161,7 +161,7 @@ int gcnx_head_from_parts(gcnx_ctx* ctx, const gcnx_head_args* a) {
     int rc = gcnx_ws_reserve(ctx, slab_floats * sizeof(float));
     if (rc) return rc;
   }
-  const PoolParts pp{a->part, a->graph_ptr, a->pooled, a->nsplit, a->pool_mode == GCNX_POOL_AVG ? 1 : 0, want_db ? a->cnt : nullptr,
+  const PoolParts pp{a->pool_sum, a->graph_ptr, a->pooled, 1, a->pool_mode == GCNX_POOL_AVG ? 1 : 0, want_db ? a->pool_cnt : nullptr,
                      want_db ? a->db_relu : nullptr};
   const int fl = a->cce_mode == GCNX_CCE_LOGITS ? 1 : 0;
   static bool attr_set = false;

@@ -560,25 +560,6 @@ int gcnx_act_bias_grad(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float
   return colsum_impl(ctx, dy, lddy, n, f, db, y ? y : dy, y ? ldy : lddy, dz, lddz, act, alpha, dalpha);
 }
 
-int gcnx_pool_parts_split(gcnx_ctx* ctx, int32_t b, int32_t h, int mode) {
-  if (!ctx || b <= 0 || h <= 0 || (mode != GCNX_POOL_SUM && mode != GCNX_POOL_AVG)) return 1;
-  return gcnx_pool_split(ctx, b, h, mode, 1);       // the deal the head's combine is sized for (one slice workgroup per two CUs)
-}
-
-int gcnx_pool_parts(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t h, int mode,
-                    int32_t nsplit, float* part, float* cnt) {
-  GCNX_CHECK_CTX(ctx);
-  GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && nsplit >= 1 && nsplit <= 16, "gcnx_pool_parts: bad shape");
-  GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG, "gcnx_pool_parts: SUM / AVG pooling only");
-  if (b == 0 || h == 0) return GCNX_OK;
-  GCNX_REQUIRE(ctx, graph_ptr && x && part, "gcnx_pool_parts: NULL pointer");
-  GCNX_REQUIRE(ctx, ldx >= h && h % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0 &&
-                        (!cnt || (reinterpret_cast<uintptr_t>(cnt) & 15) == 0),
-               "gcnx_pool_parts: needs h %% 4 == 0 and 16-byte aligned outputs");
-  // SUM partials in both modes: the consumers apply 1 / n_g (gcnx_pool_partials with nsplit > 1 leaves the sums unscaled)
-  return gcnx_pool_partials(ctx, graph_ptr, x, ldx, b, h, nsplit > 1 ? mode : GCNX_POOL_SUM, nsplit, part, cnt, 1);
-}
-
 int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, float* pooled, int32_t b,
                       int32_t f, int mode, int32_t* argmax) {
   GCNX_CHECK_CTX(ctx);

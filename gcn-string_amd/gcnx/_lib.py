@@ -99,8 +99,8 @@ SIGNATURES = {
     "gcnx_gcn_conv_bwd_scratch_floats": [_i64, _i32],
     "gcnx_gcn_conv_bwd_pool": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _int, _i32, _i32, _vp, _i32, _int, _vp, _i64,
                                _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _int, _vp],
-    "gcnx_pool_parts_split": [_vp, _i32, _i32, _int],
-    "gcnx_pool_parts": [_vp, _vp, _vp, _i64, _i32, _i32, _int, _i32, _vp, _vp],
+    "gcnx_gcn_conv_fwd_pool": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _int, _vp, _i64, _vp, _i64, _vp, _int,
+                               _vp, _i32, _vp, _vp],
     "gcnx_gemm_dw2": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _int, _vp, _vp,
                       _i64, _f32, _vp, _vp],
     "gcnx_comm_unique_id": [C.c_char_p],
@@ -118,8 +118,9 @@ class PendingReduce(C.Structure):
                 ("slabs", C.c_void_p), ("total", C.c_int64), ("nsplit", C.c_int32), ("out", C.c_void_p)]
 
 class HeadArgs(C.Structure):
-    """gcnx_head_args (include/gcnx.h): the classifier head of a step whose pool is still in partial sums."""
-    _fields_ = [("part", C.c_void_p), ("cnt", C.c_void_p), ("nsplit", C.c_int32),
+    """gcnx_head_args (include/gcnx.h): the classifier head of a step whose pool is still in per-tile partial sums."""
+    _fields_ = [("tile_part", C.c_void_p), ("tile_cnt", C.c_void_p), ("tile_rows", C.c_int64),
+                ("pool_sum", C.c_void_p), ("pool_cnt", C.c_void_p),
                 ("graph_ptr", C.c_void_p), ("b", C.c_int32), ("h", C.c_int32), ("pool_mode", C.c_int),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("c", C.c_int32), ("denom", C.c_float), ("cce_mode", C.c_int),
                 ("probs", C.c_void_p), ("loss_acc", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("db_relu", C.c_void_p),

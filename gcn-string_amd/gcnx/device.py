@@ -360,6 +360,11 @@ class Segments:
         return self
 
     @property
+    def has_empty(self):
+        """True if some graph of the batch has no nodes (never out of DisjointLoader; possible through the raw surface)."""
+        return bool(self.n_graphs) and bool(np.any(np.diff(self.host) <= 0))
+
+    @property
     def ids(self):
         """The DisjointLoader id vector i[N] (graph of every row) on the device, built on first use."""
         if getattr(self, "_ids", None) is None:
@@ -465,37 +470,41 @@ def gcn_conv_fused_ok(ctx, n, fi, fo, ldx=None):
     return bool(ctx.lib.gcnx_gcn_conv_fused_ok(int(n), int(fi), int(fo), int(ldx if ldx is not None else fi)))
 
 
-def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None, wt=None, prec="f32"):
+def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None, wt=None, prec="f32", pool=None):
     """out = act((A x) w + bias) in one launch; s (optional) receives A x, wt (optional, [fo, fi]) w^T
-    (gcnx_gcn_conv_fwd)."""
+    (gcnx_gcn_conv_fwd).  pool = (seg, tile_part, tile_cnt): the launch also leaves the global pool's per-tile partial
+    sums / positive counts of ``out`` in the two [pool_tile_rows(n, b), fo] arrays (gcnx_gcn_conv_fwd_pool)."""
     n, fi = x.shape
     fo = w.shape[1]
     assert a.n == n and w.shape[0] == fi and w.contiguous and out.shape == (n, fo) and (s is None or s.shape == (n, fi))
-    ctx._ck(ctx.lib.gcnx_gcn_conv_fwd(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(x), x.ld, n, fi, _p(w), fo, _p(bias),
-                                      L.ACTS[act], _p(s), s.ld if s is not None else 0, _p(out), out.ld, _p(wt), L.PRECS[prec]))
+    if pool is None:
+        ctx._ck(ctx.lib.gcnx_gcn_conv_fwd(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(x), x.ld, n, fi, _p(w), fo, _p(bias),
+                                          L.ACTS[act], _p(s), s.ld if s is not None else 0, _p(out), out.ld, _p(wt), L.PRECS[prec]))
+        return out
+    seg, tp, tc = pool
+    assert tp.shape == tc.shape == (pool_tile_rows(n, seg.n_graphs), fo) and tp.contiguous and tc.contiguous
+    ctx._ck(ctx.lib.gcnx_gcn_conv_fwd_pool(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(x), x.ld, n, fi, _p(w), fo, _p(bias),
+                                           L.ACTS[act], _p(s), s.ld if s is not None else 0, _p(out), out.ld, _p(wt), L.PRECS[prec],
+                                           seg.ids.ptr, seg.n_graphs, _p(tp), _p(tc)))
     return out
 
 
-def pool_parts_split(ctx, b, h, mode="sum"):
-    """Row slices per graph pool_parts uses for this batch shape (gcnx_pool_parts_split)."""
-    return int(ctx.lib.gcnx_pool_parts_split(ctx.h, int(b), int(h), L.POOLS[mode]))
+def pool_tile_rows(n, b):
+    """Rows of the per-tile partial-sum arrays gcn_conv_fwd(pool=...) fills: one per (32-row tile, graph) pair at most."""
+    return (int(n) + 31) // 32 + int(b)
 
 
-def pool_parts(ctx, seg, x, part, cnt, nsplit, mode="sum"):
-    """part[z][g][:] / cnt[z][g][:] = row sums / positive counts of slice z of graph g (gcnx_pool_parts): the pool of a
-    step whose classifier head runs inside the backward launches (head_args)."""
-    n, h = x.shape
-    assert part.size >= nsplit * seg.n_graphs * h and (cnt is None or cnt.size >= nsplit * seg.n_graphs * h)
-    ctx._ck(ctx.lib.gcnx_pool_parts(ctx.h, seg.dev.ptr, _p(x), x.ld, seg.n_graphs, h, L.POOLS[mode], int(nsplit), _p(part), _p(cnt)))
-
-
-def head_args(seg, part, cnt, nsplit, w, bias, y, denom, probs, loss_acc, dw, db, db_relu, pooled, dpooled, mode="sum", cce="logits"):
+def head_args(seg, tile_part, tile_cnt, pool_sum, pool_cnt, w, bias, y, denom, probs, loss_acc, dw, db, db_relu, pooled, dpooled,
+              mode="sum", cce="logits"):
     """gcnx_head_args for gcn_conv_bwd_pool(head=...) and gemm_dw2(leaf=...).  The DeviceArrays must outlive the calls."""
     b, h = seg.n_graphs, w.shape[0]
     c = w.shape[1]
     assert w.contiguous and pooled.contiguous and dpooled.contiguous and pooled.shape == (b, h) and dpooled.shape == (b, h)
-    return L.HeadArgs(_p(part), _p(cnt), int(nsplit), seg.dev.ptr, b, h, L.POOLS[mode], _p(w), _p(bias), _p(y), c, float(denom),
-                      L.CCES[cce], _p(probs), _p(loss_acc), _p(dw), _p(db), _p(db_relu), _p(pooled), _p(dpooled))
+    assert tile_part.shape[1] == h and tile_cnt.shape == tile_part.shape and tile_part.contiguous and tile_cnt.contiguous
+    assert pool_sum.shape == (b, h) and pool_cnt.shape == (b, h) and pool_sum.contiguous and pool_cnt.contiguous
+    return L.HeadArgs(_p(tile_part), _p(tile_cnt), tile_part.shape[0], _p(pool_sum), _p(pool_cnt), seg.dev.ptr, b, h, L.POOLS[mode],
+                      _p(w), _p(bias), _p(y), c, float(denom), L.CCES[cce], _p(probs), _p(loss_acc), _p(dw), _p(db), _p(db_relu),
+                      _p(pooled), _p(dpooled))
 
 
 def gcn_conv_bwd_pool(ctx, at, y2, seg, dpooled, w2, y1, dz2, dz1, db1=None, mode="sum", scratch=None, w2t=None, prec="f32",

@@ -197,9 +197,11 @@ class GCN2(_GraphRunner):
         if self._fused(batch):                                  # one-launch layers: S1 = A X, S2 = A Y1 (operands of dW)
             self._bufs["s1"], self._bufs["s2"] = v("s1", n, self.f_in), v("s2", n, h)
             self._bufs["w2t"] = v("w2t", h, h)                  # W2^T, a by-product of layer 2's forward launch
-            ns = D.pool_parts_split(self.ctx, b, h, self.pool) if self.pool in ("sum", "avg") else 1
-            self._bufs["pp_n"] = ns                             # the pool's partial sums / positive counts (head inside the backward)
-            self._bufs["pp_part"], self._bufs["pp_cnt"] = v("pp_part", ns * b, h), v("pp_cnt", ns * b, h)
+            # head inside the backward: the pool's per-tile partial sums / positive counts (layer 2's launch writes them)
+            # and the per-graph totals (the backward launch does)
+            tr = D.pool_tile_rows(n, b)
+            self._bufs["tp_part"], self._bufs["tp_cnt"] = v("tp_part", tr, h), v("tp_cnt", tr, h)
+            self._bufs["pool_sum"], self._bufs["pool_cnt"] = v("pool_sum", b, h), v("pool_cnt", b, h)
         for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
             self._bufs[k] = v(k, b, w)
         self._bufs["arg"] = v("arg", b, h, np.int32) if self.pool == "max" else None
@@ -212,10 +214,12 @@ class GCN2(_GraphRunner):
             # small-feature regime: each GCNConv is one launch, evaluated as (A X) W (gcnx_gcn_conv_fwd); A X is kept
             # for the weight gradient when a backward pass follows
             keep = with_loss == "grads"
+            late = keep and self._head_late(batch)
             D.gcn_conv_fwd(ctx, batch.a, batch.x, p["w1"], p["b1"], bufs["y1"], act="relu", s=bufs["s1"] if keep else None,
                            prec=prec)
             D.gcn_conv_fwd(ctx, batch.a, bufs["y1"], p["w2"], p["b2"], bufs["y2"], act="relu", s=bufs["s2"] if keep else None,
-                           wt=bufs["w2t"] if keep else None, prec=prec)
+                           wt=bufs["w2t"] if keep else None, prec=prec,
+                           pool=(batch.seg, bufs["tp_part"], bufs["tp_cnt"]) if late else None)
         else:
             D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
             D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
@@ -234,13 +238,13 @@ class GCN2(_GraphRunner):
         head = dict(mode=self.pool, argmax=bufs["arg"])
         bufs["_head_late"] = None
         if with_loss == "grads" and self._head_late(batch):
-            # one-launch layers with a backward pass to follow: only the pool's partial sums here.  The backward
-            # aggregation evaluates dPooled per graph itself and the rest of the head (probabilities, loss, accuracy, dW3,
-            # db3, db2 -- leaves) rides in the weight-gradient launch: the head's 10 us are off the critical path.
-            D.pool_parts(ctx, batch.seg, bufs["y2"], bufs["pp_part"], bufs["pp_cnt"], bufs["pp_n"], self.pool)
-            bufs["_head_late"] = D.head_args(batch.seg, bufs["pp_part"], bufs["pp_cnt"], bufs["pp_n"], p["w3"], p["b3"], batch.y, denom,
-                                             bufs["probs"], self.loss_acc, self.g["w3"], self.g["b3"], self.g["b2"], bufs["pooled"],
-                                             bufs["dpooled"], mode=self.pool, cce=self.cce_train)
+            # one-launch layers with a backward pass to follow: neither a pool nor a head launch here.  Layer 2's launch
+            # left the pool's per-tile partial sums; the backward aggregation adds them up and evaluates dPooled per graph
+            # itself, and the rest of the head (probabilities, loss, accuracy, dW3, db3, db2 -- leaves) rides in the
+            # weight-gradient launch: the pool's 7 us and the head's 10 are off the critical path.
+            bufs["_head_late"] = D.head_args(batch.seg, bufs["tp_part"], bufs["tp_cnt"], bufs["pool_sum"], bufs["pool_cnt"], p["w3"],
+                                             p["b3"], batch.y, denom, bufs["probs"], self.loss_acc, self.g["w3"], self.g["b3"],
+                                             self.g["b2"], bufs["pooled"], bufs["dpooled"], mode=self.pool, cce=self.cce_train)
         elif with_loss == "grads":
             # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
@@ -340,10 +344,11 @@ class GCN2(_GraphRunner):
                 and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))
 
     def _head_late(self, batch):
-        """One-launch layers (see _fused; SUM / AVG pooling) and at most 2 classes (the reference's binary labels): the
-        classifier head is evaluated inside the backward launches (gcnx_head_args) instead of between the pool and the
-        backward aggregation."""
-        return self._knob["head_late"] and self._fused(batch) and self.n_labels <= 2 and batch.y is not None
+        """One-launch layers (see _fused; SUM / AVG pooling), at most 2 classes (the reference's binary labels) and no graph
+        without nodes: pool and classifier head are evaluated inside the forward / backward launches (gcnx_gcn_conv_fwd_pool,
+        gcnx_head_args) instead of as launches between them."""
+        return (self._knob["head_late"] and self._fused(batch) and self.n_labels <= 2 and batch.y is not None
+                and not batch.seg.has_empty)
 
     def _backward_knob(self, batch, bufs, side):
         """The same backward with individual side sections switched off (GCNX_SIDE bits; measurement only)."""

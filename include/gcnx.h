@@ -379,28 +379,37 @@ GCNX_API int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32
                       const float* x, int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo,
                       const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out,
                       int prec);
-/* The classifier head of a small-batch step whose pool is still in partial sums (plain data, no ownership).  In a
- * latency-bound step the head's launch -- Dense(softmax) + CCE + their gradients on a [B, H] operand: 10 us of one
- * workgroup -- sits between the pool and the backward aggregation only because that needs dPooled.  With this struct
- * gcnx_gcn_conv_bwd_pool evaluates dPooled per graph itself (a few hundred flops per row group) and gcnx_gemm_dw2 runs
- * everything else the head produces (probabilities, loss, accuracy, dW, db, db_relu: leaves nobody in the step waits
- * for) as the FIRST workgroups of the weight-gradient launch, where it costs nothing.
- *   part / cnt: gcnx_pool_parts output [nsplit][b][h]; w [h, c], bias [c], y [b, c] one-hot; c <= 2 for the in-kernel form
- *   (gcnx_gcn_conv_bwd_pool returns GCNX_ERR_UNSUPPORTED beyond that; gcnx_gemm_dw2 takes any c the head kernel does).
+/* gcnx_gcn_conv_fwd with the global pool's partial sums out of the same launch (GlobalSumPool / GlobalAvgPool over the
+ * layer's output, gcn.py:334): node_graph [n] is the DisjointLoader id vector `i` (non-decreasing), b the number of
+ * graphs.  Row t + g of tile_part / tile_cnt ((ceil(n / 32) + b) rows of fo floats each, 16-byte aligned) receives the
+ * column sums / the number of positive entries of the rows of graph g inside the 32-row tile t; the other rows are not
+ * written.  A graph's pooled sum is the sum of the rows t + g over its tiles t = first_row / 32 .. last_row / 32 --
+ * gcnx_gcn_conv_bwd_pool(head) consumes them in that form. */
+GCNX_API int gcnx_gcn_conv_fwd_pool(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                      const float* x, int64_t ldx, int32_t n, int32_t fi, const float* w, int32_t fo,
+                      const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out,
+                      int prec, const int32_t* node_graph, int32_t b, float* tile_part, float* tile_cnt);
+/* The classifier head of a small-batch step whose pool is still in per-tile partial sums (plain data, no ownership).  In
+ * a latency-bound step the pool and the head -- Dense(softmax) + CCE + their gradients on a [B, H] operand: 7 + 10 us of
+ * little parallel work -- sit between the forward and the backward aggregation only because that needs dPooled.  With
+ * this struct gcnx_gcn_conv_bwd_pool adds up the tile partials of its tile's graphs and evaluates dPooled itself (a few
+ * hundred flops per graph), writing each graph's totals to pool_sum / pool_cnt on the way (the workgroup that holds the
+ * graph's first row does; rows of graphs without nodes are NOT written: zero them beforehand if there can be any), and
+ * gcnx_gemm_dw2 computes everything else the head produces (probabilities, loss, accuracy, dW, db, db_relu: leaves
+ * nobody in the step waits for) from those totals in the FIRST workgroup of the weight-gradient launch.
+ *   tile_part / tile_cnt: gcnx_gcn_conv_fwd_pool output, tile_rows = ceil(n / 32) + b rows of h floats
+ *   pool_sum / pool_cnt [b, h]: written by gcnx_gcn_conv_bwd_pool, read by gcnx_gemm_dw2 (16-byte aligned)
+ *   w [h, c], bias [c], y [b, c] one-hot; c <= 2 for the in-kernel form (gcnx_gcn_conv_bwd_pool returns
+ *   GCNX_ERR_UNSUPPORTED beyond that; gcnx_gemm_dw2 takes any c the head kernel does)
  *   outputs (written by gcnx_gemm_dw2): probs [b, c], loss_acc [2] (mean loss, hit count), dw [h, c], db [c],
  *   db_relu [h] (may be NULL), pooled [b, h], dpooled [b, h]. */
 typedef struct gcnx_head_args {
-  const float* part; const float* cnt; int32_t nsplit;
+  const float* tile_part; const float* tile_cnt; int64_t tile_rows;
+  float* pool_sum; float* pool_cnt;
   const int32_t* graph_ptr; int32_t b; int32_t h; int pool_mode;
   const float* w; const float* bias; const float* y; int32_t c; float denom; int cce_mode;
   float* probs; float* loss_acc; float* dw; float* db; float* db_relu; float* pooled; float* dpooled;
 } gcnx_head_args;
-/* Row slices per graph gcnx_pool_parts uses (>= 1; a function of b, h and the device), and the partial pool itself:
- * part[z][g][:] = sum of the rows of slice z of graph g, cnt likewise the number of positive entries (SUM / AVG only;
- * the 1 / n_g of the average pool is applied by the consumers).  part / cnt: nsplit * b * h floats each. */
-GCNX_API int gcnx_pool_parts_split(gcnx_ctx* ctx, int32_t b, int32_t h, int mode);
-GCNX_API int gcnx_pool_parts(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int32_t b, int32_t h,
-                    int mode, int32_t nsplit, float* part, float* cnt);
 
 /* Backward from the global pool down to the pre-activation gradient of the layer below, one launch:
  *   dZ2[j] = pool'(dpooled)[graph(j)] * [y2[j] > 0]                      (GlobalSumPool / GlobalAvgPool', ReLU')

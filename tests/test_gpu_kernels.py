@@ -1061,11 +1061,12 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode, prec):
 @pytest.mark.parametrize("mode", ["sum", "avg"])
 @pytest.mark.parametrize("shape,h,c", [("ecoli", 128, 2), ("ecoli", 32, 1), ("ragged", 64, 2), ("many", 32, 2)])
 def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
-    """gcnx_head_args: pool partials (gcnx_pool_parts) -> gcnx_gcn_conv_bwd_pool(head) evaluates dPooled per graph itself ->
-    gcnx_gemm_dw2(leaf) produces the head's outputs, against the sequence pool + head launch -> backward -> dw2 with the
-    same operands.  "ragged": single-node graphs, so 32-row tiles span more than the two graphs wave 0 precomputes (the
-    per-row path); "many": more graphs than one head workgroup holds (the leaf falls back to a launch of its own);
-    "ecoli" at h = 128, c = 2 is the shape the merged launch serves.  Two runs agree bit for bit."""
+    """gcnx_head_args: the forward launch leaves the pool's per-tile partial sums (gcnx_gcn_conv_fwd_pool) ->
+    gcnx_gcn_conv_bwd_pool(head) adds them up and evaluates dPooled per graph itself -> gcnx_gemm_dw2(leaf) produces the
+    head's outputs, against the sequence pool + head launch -> backward -> dw2 with the same operands.  "ragged":
+    single-node graphs, so 32-row tiles span up to 13 graphs (several rounds of the in-kernel head); "many": more graphs
+    than one head workgroup holds (the leaf falls back to a launch of its own); "ecoli" at h = 128, c = 2 is the shape
+    the merged launch serves.  Two runs agree bit for bit."""
     from gcnx import device as D, synth
     from gcnx.device import DeviceCSR, Segments
     rng = np.random.default_rng(h + c)
@@ -1090,9 +1091,22 @@ def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
     vals = (rng.random(len(colidx)) + 0.25).astype(np.float32)
     a = DeviceCSR.from_host_csr(ctx, rowptr, colidx, vals, gp, symmetric=False)
     seg = Segments(ctx, gp)
-    y2 = ctx.to_device(np.maximum(rng.standard_normal((n, h), dtype=np.float32), 0))
     y1 = ctx.to_device(np.maximum(rng.standard_normal((n, f1), dtype=np.float32), 0))
     w2 = ctx.to_device((rng.standard_normal((f1, h)) / np.sqrt(f1)).astype(np.float32))
+    # the pooled layer's forward launch leaves the pool's per-tile partial sums and positive counts: row t + g = the rows
+    # of graph g inside tile t
+    y2, tp, tc = ctx.empty((n, h)), ctx.zeros((D.pool_tile_rows(n, b), h)), ctx.zeros((D.pool_tile_rows(n, b), h))
+    D.gcn_conv_fwd(ctx, a, y1, w2, ctx.to_device(rng.standard_normal(h).astype(np.float32)), y2, act="relu", pool=(seg, tp, tc))
+    y2h, tph, tch = y2.numpy(), tp.numpy(), tc.numpy()
+    assert (y2h > 0).mean() > 0.2
+    for g in range(b):
+        tiles = range(gp[g] // 32, (gp[g + 1] - 1) // 32 + 1)
+        rows = y2h[gp[g]:gp[g + 1]]
+        assert rel_err(sum(tph[t + g].astype(np.float64) for t in tiles), rows.sum(0, dtype=np.float64)) < TIGHT
+        assert np.array_equal(sum(tch[t + g] for t in tiles), (rows > 0).sum(0).astype(np.float32))
+        for t in tiles:                                                    # and each partial row by itself
+            lo, hi = max(gp[g], 32 * t), min(gp[g + 1], 32 * t + 32)
+            assert rel_err(tph[t + g], y2h[lo:hi].sum(0, dtype=np.float64)) < TIGHT
     s1 = ctx.to_device(rng.standard_normal((n, 32), dtype=np.float32)); s2 = ctx.to_device(rng.standard_normal((n, f1), dtype=np.float32))
     scale = np.sqrt(h) * (n / b if mode == "sum" else 1.0)              # logits of order 1: no saturated softmax, gradients flow
     w3 = ctx.to_device((rng.standard_normal((h, c)) / scale).astype(np.float32))
@@ -1117,10 +1131,8 @@ def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
             pend = D.gcn_conv_bwd_pool(ctx, a.transpose(), y2, seg, dp, w2, y1, dz2, dz1, db1=gb1, mode=mode, scratch=scratch)
             D.gemm_dw2(ctx, s1, dz1, gw1, s2, dz2, gw2, pending=pend, **sgd)
         else:
-            ns = D.pool_parts_split(ctx, b, h, mode)
-            part, cnt = ctx.empty((ns * b, h)), ctx.empty((ns * b, h))
-            D.pool_parts(ctx, seg, y2, part, cnt, ns, mode)
-            ha = D.head_args(seg, part, cnt, ns, w3, b3, y, denom, probs, la, gw3, gb3, gb2, pooled, dp, mode=mode, cce=cce)
+            ha = D.head_args(seg, tp, tc, ctx.empty((b, h)), ctx.empty((b, h)), w3, b3, y, denom, probs, la, gw3, gb3, gb2, pooled, dp,
+                             mode=mode, cce=cce)
             pend = D.gcn_conv_bwd_pool(ctx, a.transpose(), y2, seg, None, w2, y1, dz2, dz1, db1=gb1, mode=mode, scratch=scratch, head=ha)
             D.gemm_dw2(ctx, s1, dz1, gw1, s2, dz2, gw2, pending=pend, leaf=ha, **sgd)
         out[how] = dict(zip(names, [t.numpy().copy() for t in (pooled, probs, la, dp, dz2, dz1, grads, params)]))
@@ -1135,8 +1147,8 @@ def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
 
 def test_head_inside_the_backward_refusals_and_fallbacks(ctx):
     """More than two classes: the backward launch refuses the in-kernel head (GCNX_ERR_UNSUPPORTED); gcnx_gemm_dw2(leaf)
-    alone serves any class count through the head kernel's launch, and also when the weight gradients take their
-    separate calls (too few rows for the split-K launch)."""
+    alone -- given the per-graph pool totals -- serves any class count through the head kernel's launch, and also when
+    the weight gradients take their separate calls (too few rows for the split-K launch)."""
     from gcnx import device as D, synth
     from gcnx._lib import GcnxError
     from gcnx.device import DeviceCSR, Segments
@@ -1151,14 +1163,15 @@ def test_head_inside_the_backward_refusals_and_fallbacks(ctx):
         w2 = ctx.to_device((rng.standard_normal((f1, h)) / 6).astype(np.float32))
         w3 = ctx.to_device((rng.standard_normal((h, c)) / 6).astype(np.float32)); b3 = ctx.zeros(c)
         y = ctx.to_device(np.eye(c, dtype=np.float32)[rng.integers(0, c, b)])
-        ns = D.pool_parts_split(ctx, b, h, "sum")
-        part, cnt = ctx.empty((ns * b, h)), ctx.empty((ns * b, h))
-        D.pool_parts(ctx, seg, y2, part, cnt, ns, "sum")
+        gpl = hb.graph_ptr
+        psum = ctx.to_device(np.stack([y2.numpy()[gpl[g]:gpl[g + 1]].sum(0) for g in range(b)]).astype(np.float32))
+        pcnt = ctx.to_device(np.stack([(y2.numpy()[gpl[g]:gpl[g + 1]] > 0).sum(0) for g in range(b)]).astype(np.float32))
+        tiles = ctx.zeros((D.pool_tile_rows(n, b), h))
         ref = [ctx.zeros((b, h)), ctx.zeros((b, c)), ctx.zeros(2), ctx.zeros((h, c)), ctx.zeros(c), ctx.zeros((b, h)), ctx.zeros(h)]
         D.pool_dense_softmax_cce(ctx, seg, y2, ref[0], w3, b3, y, ref[1], ref[2], float(b), dw=ref[3], db=ref[4], dpooled=ref[5],
                                  mode="sum", db_relu=ref[6])
         got = [ctx.zeros(t.shape) for t in ref]
-        ha = D.head_args(seg, part, cnt, ns, w3, b3, y, float(b), got[1], got[2], got[3], got[4], got[6], got[0], got[5])
+        ha = D.head_args(seg, tiles, tiles, psum, pcnt, w3, b3, y, float(b), got[1], got[2], got[3], got[4], got[6], got[0], got[5])
         dz2, dz1 = ctx.empty((n, h)), ctx.empty((n, f1))
         if c > 2:
             with pytest.raises(GcnxError, match="two classes"):
