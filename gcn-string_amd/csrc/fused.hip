@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   __shared__ unsigned char s_mb[BWD ? kFRows * 32 : 1];   // backward: [Y1 > 0] of the tile, 4 columns per byte
   __shared__ float2 s_dl[BWD ? kFRows : 1];               // backward, head folded in: dlogits x pool scale of the tile's graphs
   __shared__ __attribute__((aligned(16))) float s_w3[BWD ? 2 : 1][K];   // ... and the two columns of W3
+  __shared__ float s_b3[2];
   __shared__ int32_t s_g[BWD ? 1 : kFRows];               // forward with the pool's partial sums: graph of each row
   static_assert(!BWD || sizeof(float) * kFRows * (K + 4) >= sizeof(float4) * 2 * 8 * 2 * LPR, "the head's wave partials alias the tile");
 #ifdef GCNX_TUNING
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
       const int cls = i / K, k = i - cls * K;
       s_w3[cls][k] = cls < p.hd_c ? p.hd_w[(int64_t)k * p.hd_c + cls] : 0.f;
     }
+    if (tid >= 2 * K && tid < 2 * K + 2) s_b3[tid - 2 * K] = (p.hd_bias && tid - 2 * K < p.hd_c) ? p.hd_bias[tid - 2 * K] : 0.f;
     const unsigned bytes = (unsigned)p.hd_rows * (unsigned)K * 4u;
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)p.hd_part, (short)0, (int)bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)p.hd_cnt, (short)0, (int)bytes, 0x00020000);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
         }
         const float2 dl = fused_head_dlogits<LPR>(p, pv, hd_n, *reinterpret_cast<const float4*>(&s_w3[0][hsub * 4]),
                                                   *reinterpret_cast<const float4*>(&s_w3[1][hsub * 4]),
-                                                  p.hd_bias ? p.hd_bias[0] : 0.f, (p.hd_bias && p.hd_c > 1) ? p.hd_bias[1] : 0.f, y0, y1);
+                                                  s_b3[0], s_b3[1], y0, y1);
         if (hsub == 0) s_dl[hd_g - g_first] = dl;
       }
     }

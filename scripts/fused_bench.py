@@ -30,6 +30,13 @@ def timeit(fn, iters=50):
 print("fwd  (S, W^T out): %.1f us" % timeit(lambda: D.gcn_conv_fwd(ctx, a, x, w, b, out, act="relu", s=s, wt=wt)))
 print("fwd  (inference) : %.1f us" % timeit(lambda: D.gcn_conv_fwd(ctx, a, x, w, b, out, act="relu")))
 print("bwd              : %.1f us" % timeit(lambda: D.gcn_conv_bwd_pool(ctx, at, out, seg, dp, w, s, dz2, dz1, db1=g.flat(2 * f * f, f), scratch=scratch, w2t=wt)))
+tp, tc = ctx.zeros((D.pool_tile_rows(hb.n, 32), f)), ctx.zeros((D.pool_tile_rows(hb.n, 32), f))
+w3 = ctx.to_device((rng.standard_normal((f, 2)) / 1e3).astype(np.float32)); b3 = ctx.zeros(2)
+yl = ctx.to_device(np.eye(2, dtype=np.float32)[rng.integers(0, 2, 32)])
+print("fwd  (S, W^T, pool partials): %.1f us" % timeit(lambda: D.gcn_conv_fwd(ctx, a, x, w, b, out, act="relu", s=s, wt=wt, pool=(seg, tp, tc))))
+ha = D.head_args(seg, tp, tc, ctx.empty((32, f)), ctx.empty((32, f)), w3, b3, yl, 32.0, ctx.empty((32, 2)), ctx.zeros(2), ctx.empty((f, 2)),
+                 ctx.empty(2), ctx.empty(f), ctx.empty((32, f)), ctx.empty((32, f)))
+print("bwd  (head inside): %.1f us" % timeit(lambda: D.gcn_conv_bwd_pool(ctx, at, out, seg, None, w, s, dz2, dz1, db1=g.flat(2 * f * f, f), scratch=scratch, w2t=wt, head=ha)))
 print("dw2              : %.1f us" % timeit(lambda: D.gemm_dw2(ctx, s, dz1, g.flat(0, f * f, (f, f)), s, dz2, g.flat(f * f, f * f, (f, f)), grads=g)))
 h = ctx.empty((hb.n, f))
 print("gemm + spmm      : %.1f us" % timeit(lambda: (D.gemm(ctx, x, w, None, h), D.spmm(ctx, a, h, b, out, act="relu"))))
