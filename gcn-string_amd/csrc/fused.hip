@@ -145,7 +145,8 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   const int t = gcnx_xcd_remap(blockIdx.x, ntiles);
   const int r0 = t * kFRows, nr = min(p.n - r0, kFRows);
   if (tid <= nr) s_rp[tid] = p.rowptr[r0 + tid];
-  if (!BWD && p.tp_part && tid < kFRows) s_g[tid] = tid < nr ? p.node_graph[r0 + tid] : -1;
+  if (!BWD && p.tp_part && tid < kFRows)               // (clamped: a malformed id vector cannot write outside the two arrays)
+    s_g[tid] = tid < nr ? min(max(p.node_graph[r0 + tid], 0), p.hd_b - 1) : -1;
   const int e0 = p.rowptr[r0], e1 = p.rowptr[r0 + nr];
   const int staged = min(e1 - e0, kFCap);
   const unsigned ld4 = (unsigned)p.ldx * 4u;
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
   const int hsel = lane / LPR, hsub = lane % LPR;
   int g_first = 0;
   if (BWD && p.hd_part) {
-    g_first = __builtin_amdgcn_readfirstlane(p.node_graph[r0]);
-    const int g_last = __builtin_amdgcn_readfirstlane(p.node_graph[r0 + nr - 1]);
+    g_first = min(max(__builtin_amdgcn_readfirstlane(p.node_graph[r0]), 0), p.hd_b - 1);       // (clamped, as in the forward)
+    const int g_last = min(max(__builtin_amdgcn_readfirstlane(p.node_graph[r0 + nr - 1]), g_first), min(g_first + kFRows, p.hd_b) - 1);
     for (int i = tid; i < 2 * K; i += 512) {
       const int cls = i / K, k = i - cls * K;
       s_w3[cls][k] = cls < p.hd_c ? p.hd_w[(int64_t)k * p.hd_c + cls] : 0.f;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512, 6) void gcn_conv_fused_kernel(FusedArgs p) {
 #pragma unroll
       for (int j = 0; j < RPG; ++j) {
         if (grow[j] < 0) continue;
-        const float2 dl = s_dl[grow[j] - g_first];
+        const float2 dl = s_dl[(grow[j] - g_first) & (kFRows - 1)];
         dscale[j] = make_float4(fmaf(dl.y, w1.x, dl.x * w0.x), fmaf(dl.y, w1.y, dl.x * w0.y), fmaf(dl.y, w1.z, dl.x * w0.z),
                                 fmaf(dl.y, w1.w, dl.x * w0.w));
       }
@@ -545,7 +546,7 @@ int gcnx_gcn_conv_fwd_pool(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
   FusedArgs a{};
   a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.x = x; a.ldx = ldx; a.n = n; a.w = w; a.ldw = fo; a.nc = fo;
   a.bias = bias; a.act = act; a.s = s; a.lds = lds; a.out = out; a.ldo = ldo; a.wt_out = wt_out;
-  a.node_graph = node_graph; a.tp_part = tile_part; a.tp_cnt = tile_cnt;
+  a.node_graph = node_graph; a.tp_part = tile_part; a.tp_cnt = tile_cnt; a.hd_b = b;
   return launch_fused<false>(ctx, a, fi, prec == GCNX_PREC_BF16X3);
 }
 

@@ -380,8 +380,8 @@ GCNX_API int gcnx_gcn_conv_fwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32
                       const float* bias, int act, float* s, int64_t lds, float* out, int64_t ldo, float* wt_out,
                       int prec);
 /* gcnx_gcn_conv_fwd with the global pool's partial sums out of the same launch (GlobalSumPool / GlobalAvgPool over the
- * layer's output, gcn.py:334): node_graph [n] is the DisjointLoader id vector `i` (non-decreasing), b the number of
- * graphs.  Row t + g of tile_part / tile_cnt ((ceil(n / 32) + b) rows of fo floats each, 16-byte aligned) receives the
+ * layer's output, gcn.py:334): node_graph [n] is the DisjointLoader id vector `i` (non-decreasing, values in [0, b)), b the
+ * number of graphs.  Row t + g of tile_part / tile_cnt ((ceil(n / 32) + b) rows of fo floats each, 16-byte aligned) receives the
  * column sums / the number of positive entries of the rows of graph g inside the 32-row tile t; the other rows are not
  * written.  A graph's pooled sum is the sum of the rows t + g over its tiles t = first_row / 32 .. last_row / 32 --
  * gcnx_gcn_conv_bwd_pool(head) consumes them in that form. */

@@ -7,6 +7,8 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R; mkdir -p $O
 python3 bench.py --steps 200 --warmup 20 > $O/bench_ecoli.json 2> $O/bench_ecoli.err || { tail -5 $O/bench_ecoli.err; exit 1; }
+python3 bench.py --prec bf16x3 --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 > $O/bench_ecoli_bf16x3.json 2> $O/bench_ecoli_bf16x3.err
+python3 scripts/loader_bench.py > $O/loader_bench.txt 2>&1
 python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > $O/bench_block1m.json 2> $O/bench_block1m.err || { tail -5 $O/bench_block1m.err; exit 1; }
 python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec f32 > $O/bench_block1m_f32.json 2> $O/bench_block1m_f32.err
 python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec bf16x3 > $O/bench_block1m_bf16x3.json 2> $O/bench_block1m_bf16x3.err
