@@ -40,6 +40,14 @@ struct gcnx_ctx {
   int ev_next = 0;
   int num_cus = 256;
   std::string arch;
+  // gcnx_h2d_async: a ring of pinned staging slots (allocated on first use), one event per slot -- a slot is reused only
+  // after the copy out of it has completed
+  static constexpr int kPinSlots = 32;
+  static constexpr size_t kPinSlotBytes = 16384;
+  char* pin_base = nullptr;
+  hipEvent_t pin_ev[kPinSlots] = {};
+  bool pin_busy[kPinSlots] = {};
+  int pin_next = 0;
 };
 
 struct gcnx_event { hipEvent_t ev; };

@@ -4,6 +4,7 @@
 #include <utility>
 
 #include "common.h"
+#include <cstring>
 
 thread_local std::string gcnx_tls_error;
 
@@ -112,6 +113,10 @@ int gcnx_ctx_destroy(gcnx_ctx* ctx) {
   if (ctx->ws_other) (void)hipFree(ctx->ws_other);
   for (void* p : ctx->retired_ws) (void)hipFree(p);
   if (ctx->flag) (void)hipFree(ctx->flag);
+  if (ctx->pin_base) {
+    (void)hipHostFree(ctx->pin_base);
+    for (int i = 0; i < gcnx_ctx::kPinSlots; ++i) if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+  }
   for (int i = 0; i < gcnx_ctx::kSideEvents; ++i) {
     if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -185,6 +190,29 @@ int gcnx_h2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   GCNX_REQUIRE(ctx, dst && src, "gcnx_h2d: NULL pointer");
   GCNX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GCNX_OK;
+}
+
+// Small host -> device copies that must not stall the host behind the GPU (the per-batch descriptor of the device-side
+// collate: with the synchronous copy every streamed step waited for the previous one to finish before its launches
+// could even be queued).  The bytes are taken from `src` before the call returns.
+int gcnx_h2d_async(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  GCNX_CHECK_CTX(ctx);
+  if (bytes == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, dst && src, "gcnx_h2d_async: NULL pointer");
+  if (bytes > gcnx_ctx::kPinSlotBytes || ctx->capturing) return gcnx_h2d(ctx, dst, src, bytes);
+  if (!ctx->pin_base) {
+    GCNX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_base, gcnx_ctx::kPinSlots * gcnx_ctx::kPinSlotBytes, hipHostMallocDefault));
+    for (int i = 0; i < gcnx_ctx::kPinSlots; ++i) GCNX_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+  }
+  const int slot = ctx->pin_next;
+  ctx->pin_next = (slot + 1) % gcnx_ctx::kPinSlots;
+  if (ctx->pin_busy[slot]) GCNX_HIP(ctx, hipEventSynchronize(ctx->pin_ev[slot]));   // 32 copies ago: almost never waits
+  char* stage = ctx->pin_base + (size_t)slot * gcnx_ctx::kPinSlotBytes;
+  memcpy(stage, src, bytes);
+  GCNX_HIP(ctx, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GCNX_HIP(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+  ctx->pin_busy[slot] = true;
   return GCNX_OK;
 }
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gcnx_free": [_vp, _vp],
     "gcnx_memset": [_vp, _vp, _int, _sz],
     "gcnx_h2d": [_vp, _vp, _vp, _sz],
+    "gcnx_h2d_async": [_vp, _vp, _vp, _sz],
     "gcnx_d2h": [_vp, _vp, _vp, _sz],
     "gcnx_d2d": [_vp, _vp, _vp, _sz],
     "gcnx_sync": [_vp],

@@ -160,7 +160,10 @@ class DeviceArray:
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
 
     @property
     def nbytes(self):
@@ -185,10 +188,12 @@ class DeviceArray:
         assert self.contiguous
         self.ctx._ck(self.ctx.lib.gcnx_memset(self.ctx.h, self.ptr, 0, self.nbytes))
 
-    def copy_from_host(self, host):
+    def copy_from_host(self, host, wait=True):
+        """wait=False: small copies are staged and queued in stream order without stalling the host (gcnx_h2d_async)."""
         host = np.ascontiguousarray(host, dtype=self.dtype)
         assert host.size == self.size and self.contiguous
-        self.ctx._ck(self.ctx.lib.gcnx_h2d(self.ctx.h, self.ptr, host.ctypes.data, host.nbytes))
+        fn = self.ctx.lib.gcnx_h2d if wait else self.ctx.lib.gcnx_h2d_async
+        self.ctx._ck(fn(self.ctx.h, self.ptr, host.ctypes.data, host.nbytes))
 
     def numpy(self):
         if self.contiguous:
@@ -362,7 +367,9 @@ class Segments:
     @property
     def has_empty(self):
         """True if some graph of the batch has no nodes (never out of DisjointLoader; possible through the raw surface)."""
-        return bool(self.n_graphs) and bool(np.any(np.diff(self.host) <= 0))
+        if getattr(self, "_has_empty", None) is None:
+            self._has_empty = bool(self.n_graphs) and bool(np.any(np.diff(self.host) <= 0))
+        return self._has_empty
 
     @property
     def ids(self):

@@ -80,7 +80,7 @@ def collate_on_device(ds, indices, bufs=None):
     n, nnz = int(bn[-1]), int(be[-1])
     desc = np.concatenate([sel, [0], bn, be]).astype(np.int32)
     dview = bufs.desc.flat(0, desc.size)
-    dview.copy_from_host(desc)
+    dview.copy_from_host(desc, wait=False)               # queued: the host runs ahead of the GPU across batches
     f, c = ds.n_features, ds.n_labels
     csr = ds.csr
     ctx._ck(ctx.lib.gcnx_collate(ctx.h, dview.ptr, b, ds.node_ptr.ptr, csr.rowptr.ptr, csr.colidx.ptr,

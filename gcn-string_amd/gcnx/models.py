@@ -105,6 +105,36 @@ class _GraphRunner:
         else:
             st.launch()
 
+    # ---- metrics without a host round trip per step ---------------------------------------------------------------
+    _MRING = 1024
+
+    def stash_metrics(self, n_graphs):
+        """After train_step(..., fetch=False): keep this step's (loss, hit count) on the device -- an 8-byte copy in
+        stream order -- instead of reading it back; collect_metrics() returns the stashed steps.  A loop that reads
+        loss and accuracy after every step waits for the GPU every step, and the GPU then waits for the host to queue
+        the next one: the reference's loop only uses them at the end of the epoch (gcn.py:375-377)."""
+        if getattr(self, "_mring", None) is None:
+            self._mring, self._mcount, self._mdone = self.ctx.zeros(2 * self._MRING), [], []
+        if len(self._mcount) == self._MRING:
+            self._mdone.extend(self._read_ring())
+        k = len(self._mcount)
+        self.ctx._ck(self.ctx.lib.gcnx_d2d(self.ctx.h, self._mring.ptr + 8 * k, self.loss_acc.ptr, 8))
+        self._mcount.append(float(n_graphs))
+
+    def _read_ring(self):
+        la = self._mring.numpy().reshape(-1, 2)[:len(self._mcount)]
+        out = [(float(l), float(h) / n) for (l, h), n in zip(la, self._mcount)]
+        self._mcount = []
+        return out
+
+    def collect_metrics(self):
+        """[(loss, accuracy)] of the steps stashed since the last call (one device -> host copy)."""
+        if getattr(self, "_mring", None) is None:
+            return []
+        out = self._mdone + self._read_ring()
+        self._mdone = []
+        return out
+
     def _drop_graphs(self):
         for g in getattr(self, "_graphs", {}).values():
             if not isinstance(g, str):
@@ -338,10 +368,14 @@ class GCN2(_GraphRunner):
         launches (csrc/fused.hip).  Needs the folded backward's conditions and F, H in {32, 64, 128}; prec "f32" (exact
         fp32 products) or "bf16x3" (split-bf16 products in the conv launches; the two weight gradients stay on the fp32
         MFMA -- sums over N rows, at least as accurate)."""
-        return (self.built and self._fold(batch) and self.prec in ("f32", "bf16x3") and self._knob["fused"]
-                and self._knob["duo"] and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
-                and D.gcn_conv_fused_ok(self.ctx, batch.n, self.f_in, self.hidden)
-                and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))
+        route = batch.__dict__.setdefault("_route", {})      # asked several times per step: once per (batch, model)
+        key = ("fused", id(self), self.prec, self.built, batch.a.plan is None)
+        if key not in route:
+            route[key] = bool(self.built and self._fold(batch) and self.prec in ("f32", "bf16x3") and self._knob["fused"]
+                              and self._knob["duo"] and self.f_in in (32, 64, 128) and self.hidden in (32, 64, 128)
+                              and D.gcn_conv_fused_ok(self.ctx, batch.n, self.f_in, self.hidden)
+                              and D.gcn_conv_fused_ok(self.ctx, batch.n, self.hidden, self.hidden))
+        return route[key]
 
     def _head_late(self, batch):
         """One-launch layers (see _fused; SUM / AVG pooling), at most 2 classes (the reference's binary labels) and no graph
@@ -442,6 +476,9 @@ class GCN2(_GraphRunner):
         batch = self.loss_and_grads(inputs, target, global_batch, _lr=float(lr))
         if not self._step_applied:
             self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
+        if fetch == "stash":
+            self.stash_metrics(global_batch or batch.n_graphs)
+            return None
         if not fetch:
             return None
         return self.fetch_metrics(global_batch or batch.n_graphs)
@@ -785,10 +822,13 @@ class GeneralGNN(_GraphRunner):
         batch = self.loss_and_grads(inputs, target, _lr=float(lr), global_batch=global_batch)
         if not self._step_applied:
             D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr)
+        n_graphs = global_batch or (self._counts["b"] if self._multi() else batch.n_graphs)
+        if fetch == "stash":
+            self.stash_metrics(n_graphs)
+            return None
         if not fetch:
             return None
         la = self.loss_acc.numpy()
-        n_graphs = global_batch or (self._counts["b"] if self._multi() else batch.n_graphs)
         return float(la[0]), float(la[1]) / float(n_graphs)
 
     def evaluate_batch(self, inputs, target):

@@ -72,12 +72,14 @@ def fit(model, loader_tr, loader_te=None, epochs=1, schedule=None, normalize=Non
     for inputs, target in loader_tr:
         step += 1
         batch = _as_batch(model, inputs, target, normalize)
-        loss, acc = model.train_step(batch, None, lr=schedule(it))
+        # the step's loss and accuracy stay on the device until the epoch ends (gcn.py:372 appends them to `results`, which
+        # is only read at :375): no host round trip per step, the host queues step k + 1 while the GPU runs step k
+        model.train_step(batch, None, lr=schedule(it), fetch="stash")
         it += 1
-        results.append((loss, acc))
         if step == loader_tr.steps_per_epoch:
             step = 0
             epoch += 1
+            results = model.collect_metrics()
             te = evaluate(model, loader_te, normalize)[0] if loader_te is not None else (float("nan"), float("nan"))
             tr = tuple(np.mean(results, 0))
             if verbose:

@@ -95,6 +95,10 @@ GCNX_API int gcnx_malloc(gcnx_ctx* ctx, size_t bytes, void** dptr);
 GCNX_API int gcnx_free(gcnx_ctx* ctx, void* dptr);
 GCNX_API int gcnx_memset(gcnx_ctx* ctx, void* dptr, int value, size_t bytes);
 GCNX_API int gcnx_h2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* gcnx_h2d without the wait: the bytes are staged in pinned memory before the call returns and copied in stream order
+ * (up to 16 KiB and outside capture; otherwise it is gcnx_h2d).  For per-batch descriptors: a synchronous copy makes every
+ * streamed step wait for the previous one. */
+GCNX_API int gcnx_h2d_async(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
 GCNX_API int gcnx_d2h(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
 GCNX_API int gcnx_d2d(gcnx_ctx* ctx, void* dst, const void* src, size_t bytes);
 GCNX_API int gcnx_sync(gcnx_ctx* ctx);

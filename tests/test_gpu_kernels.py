@@ -936,6 +936,26 @@ def test_graph_prep_coo_to_csr_norm_transpose(ctx):
     assert np.array_equal(at.rowptr.numpy(), trp) and np.array_equal(at.colidx.numpy(), tci) and np.array_equal(at.vals.numpy(), tv)
 
 
+def test_h2d_async_small_copies_in_stream_order(ctx):
+    """gcnx_h2d_async: the bytes are taken before the call returns (the source is overwritten right after), the copies
+    land in stream order, more of them than the staging ring has slots, and a copy larger than a slot takes gcnx_h2d."""
+    rng = np.random.default_rng(4)
+    dst = [ctx.empty(100, np.int32) for _ in range(80)]
+    src = np.empty(100, np.int32)
+    want = []
+    for d in dst:
+        src[:] = rng.integers(0, 1 << 30, 100)
+        want.append(src.copy())
+        d.copy_from_host(src, wait=False)
+        src[:] = -1
+    for d, w in zip(dst, want):
+        assert np.array_equal(d.numpy(), w)
+    big = rng.integers(0, 1 << 30, 10000).astype(np.int32)
+    dbig = ctx.empty(10000, np.int32)
+    dbig.copy_from_host(big, wait=False)
+    assert np.array_equal(dbig.numpy(), big)
+
+
 def test_sgd_and_graph_capture_replay(ctx):
     from gcnx import device as D
     rng = np.random.default_rng(2)

@@ -250,6 +250,20 @@ def test_training_trajectory_and_graph_replay(ctx):
     assert ref_hist[-1][0] != ref_hist[0][0]         # the weights moved
 
 
+def test_stashed_metrics_equal_the_per_step_reads(ctx):
+    """train_step(fetch="stash") + collect_metrics(): the (loss, accuracy) of every step without a host round trip per
+    step -- same numbers as reading them after each step, across a ring wrap, eager and graph replay."""
+    g = load_golden("gcn2_cfg1_tiny_weighted")
+    for use_graph in (False, True):
+        m, batch, hb = _model_from_golden(ctx, g, use_graph)
+        ref = [m.train_step(batch, None, lr=0.02) for _ in range(7)]
+        m2, batch2, _ = _model_from_golden(ctx, g, use_graph)
+        m2._MRING = 4                                            # wraps after four steps
+        for _ in range(7):
+            assert m2.train_step(batch2, None, lr=0.02, fetch="stash") is None
+        assert m2.collect_metrics() == ref and m2.collect_metrics() == []
+
+
 def test_ecoli_config2_full_size_vs_cpu_restatement(ctx):
     """BASELINE config 2 (B=32, F=128, fp32) at full size against the fp32 C restatement."""
     from oracle import c_oracle
