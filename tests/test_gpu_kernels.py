@@ -1079,14 +1079,15 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode, prec):
 
 @pytest.mark.parametrize("cce", ["logits", "probs"])
 @pytest.mark.parametrize("mode", ["sum", "avg"])
-@pytest.mark.parametrize("shape,h,c", [("ecoli", 128, 2), ("ecoli", 32, 1), ("ragged", 64, 2), ("many", 32, 2)])
+@pytest.mark.parametrize("shape,h,c", [("ecoli", 128, 2), ("ecoli", 32, 1), ("ragged", 64, 2), ("many", 32, 2), ("tall", 128, 2)])
 def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
     """gcnx_head_args: the forward launch leaves the pool's per-tile partial sums (gcnx_gcn_conv_fwd_pool) ->
     gcnx_gcn_conv_bwd_pool(head) adds them up and evaluates dPooled per graph itself -> gcnx_gemm_dw2(leaf) produces the
     head's outputs, against the sequence pool + head launch -> backward -> dw2 with the same operands.  "ragged":
     single-node graphs, so 32-row tiles span up to 13 graphs (several rounds of the in-kernel head); "many": more graphs
-    than one head workgroup holds (the leaf falls back to a launch of its own); "ecoli" at h = 128, c = 2 is the shape
-    the merged launch serves.  Two runs agree bit for bit."""
+    than one head workgroup holds (the leaf falls back to a launch of its own); "tall": graphs of 72 and 35 tiles (more
+    partial rows than one pass of the strided loads covers); "ecoli" at h = 128, c = 2 is the shape the merged launch
+    serves.  Two runs agree bit for bit."""
     from gcnx import device as D, synth
     from gcnx.device import DeviceCSR, Segments
     rng = np.random.default_rng(h + c)
@@ -1095,7 +1096,8 @@ def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
         rowptr, colidx, gp = hb.rowptr, hb.colidx, hb.graph_ptr
     else:
         sizes = (np.array([1, 1, 1, 2, 1, 50, 1, 1, 1, 1, 3, 1, 70, 1, 1], np.int64) if shape == "ragged"
-                 else rng.integers(1, 40, 90))
+                 else np.array([5, 2300, 31, 1100], np.int64) if shape == "tall"      # 72 and 35 tiles: more than one pass of
+                 else rng.integers(1, 40, 90))                                       # the eight waves' strided partial loads
         gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
         rows, cols = [], []
         for g in range(len(sizes)):                                     # self-loops and a chain inside every graph
