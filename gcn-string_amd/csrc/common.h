@@ -40,6 +40,13 @@ struct gcnx_ctx {
   int ev_next = 0;
   int num_cus = 256;
   std::string arch;
+  // Two auxiliary streams for launches of ONE call that write disjoint rows (the aggregation's tier kernels and its
+  // row-chunk part): gcnx_aux_fork / gcnx_aux_join below.  Created on first use.
+  hipStream_t aux_stream[2] = {};
+  static constexpr int kAuxEvents = 8;
+  hipEvent_t aux_ev[kAuxEvents][3] = {};
+  int aux_next = 0;
+  int knob_spmm_conc = 0;    // GCNX_SPMM_CONC=1: the plan path's three launches as concurrent branches
   // gcnx_h2d_async: a ring of pinned staging slots (allocated on first use), one event per slot -- a slot is reused only
   // after the copy out of it has completed
   static constexpr int kPinSlots = 32;
@@ -57,6 +64,10 @@ extern thread_local std::string gcnx_tls_error;
 
 int gcnx_fail(gcnx_ctx* ctx, int code, const char* fmt, ...);
 int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes);  // ensures ctx->ws has >= bytes
+// runtime.hip: the two auxiliary streams, ordered after everything submitted to ctx->stream so far (fork), and
+// ctx->stream ordered after everything submitted to them (join).  Both work inside stream capture.
+extern "C" int gcnx_aux_fork(gcnx_ctx* ctx, hipStream_t out[2]);
+extern "C" int gcnx_aux_join(gcnx_ctx* ctx);
 // gemm_stream.hip: X W (transpose = 1) / dH W^T (transpose = 0) on the streaming bf16 kernel; GCNX_ERR_UNSUPPORTED
 // (no message) when the shape is not one it is built for.
 int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose, float* c,

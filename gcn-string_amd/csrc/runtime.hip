@@ -92,6 +92,7 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   if (const char* k = getenv("GCNX_SPMM_SLAB")) ctx->knob_spmm_slab = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_SG")) ctx->knob_spmm_sg = atoi(k);
   if (const char* k = getenv("GCNX_GEMM_STREAM")) ctx->knob_gemm_stream = atoi(k);
+  if (const char* k = getenv("GCNX_SPMM_CONC")) ctx->knob_spmm_conc = atoi(k);
   if (ctx->arch.rfind("gfx950", 0) != 0) {
     int rc = gcnx_fail(nullptr, GCNX_ERR_UNSUPPORTED, "gcnx_ctx_create: device %d is %s; libgcnx is built for gfx950 only",
                        device, ctx->arch.c_str());
@@ -113,6 +114,9 @@ int gcnx_ctx_destroy(gcnx_ctx* ctx) {
   if (ctx->ws_other) (void)hipFree(ctx->ws_other);
   for (void* p : ctx->retired_ws) (void)hipFree(p);
   if (ctx->flag) (void)hipFree(ctx->flag);
+  for (int i = 0; i < 2; ++i) if (ctx->aux_stream[i]) { (void)hipStreamSynchronize(ctx->aux_stream[i]); (void)hipStreamDestroy(ctx->aux_stream[i]); }
+  for (int i = 0; i < gcnx_ctx::kAuxEvents; ++i)
+    for (int j = 0; j < 3; ++j) if (ctx->aux_ev[i][j]) (void)hipEventDestroy(ctx->aux_ev[i][j]);
   if (ctx->pin_base) {
     (void)hipHostFree(ctx->pin_base);
     for (int i = 0; i < gcnx_ctx::kPinSlots; ++i) if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
@@ -140,6 +144,7 @@ int gcnx_set_tuning(gcnx_ctx* ctx, const char* key, int value) {
   else if (k == "spmm_slab") ctx->knob_spmm_slab = value;
   else if (k == "spmm_sg") ctx->knob_spmm_sg = value;
   else if (k == "gemm_stream") ctx->knob_gemm_stream = value;
+  else if (k == "spmm_conc") ctx->knob_spmm_conc = value;
   else return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_set_tuning: unknown key '%s'", key);
   return GCNX_OK;
 }
@@ -253,6 +258,31 @@ static void gcnx_swap_streams(gcnx_ctx* ctx) {
   std::swap(ctx->ws, ctx->ws_other);
   std::swap(ctx->ws_bytes, ctx->ws_other_bytes);
   ctx->on_side = !ctx->on_side;
+}
+
+int gcnx_aux_fork(gcnx_ctx* ctx, hipStream_t out[2]) {
+  if (!ctx->aux_stream[0]) {
+    for (int i = 0; i < 2; ++i) GCNX_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking));
+    for (int i = 0; i < gcnx_ctx::kAuxEvents; ++i)
+      for (int j = 0; j < 3; ++j) GCNX_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[i][j], hipEventDisableTiming));
+  }
+  hipEvent_t* ev = ctx->aux_ev[ctx->aux_next % gcnx_ctx::kAuxEvents];
+  GCNX_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  for (int i = 0; i < 2; ++i) {
+    GCNX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[i], ev[0], 0));
+    out[i] = ctx->aux_stream[i];
+  }
+  return GCNX_OK;
+}
+
+int gcnx_aux_join(gcnx_ctx* ctx) {
+  hipEvent_t* ev = ctx->aux_ev[ctx->aux_next % gcnx_ctx::kAuxEvents];
+  ctx->aux_next++;
+  for (int i = 0; i < 2; ++i) {
+    GCNX_HIP(ctx, hipEventRecord(ev[1 + i], ctx->aux_stream[i]));
+    GCNX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev[1 + i], 0));
+  }
+  return GCNX_OK;
 }
 
 int gcnx_side_begin(gcnx_ctx* ctx) {

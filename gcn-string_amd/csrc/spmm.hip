@@ -1339,21 +1339,31 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
   const DuoFold bo{nullptr, nullptr, 0, 0, relu_bits};     // (graphs taller than a tile get no bits: their rows are folded from out)
   const int dmode = relu_bits ? kDuoBitsOut : kDuoPlain;
-  if (plan->n1 > 0) {
-    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, &bo, dmode);
-    if (rc) return rc;
+  // The three launches write disjoint rows.  GCNX_SPMM_CONC: as concurrent branches (two auxiliary streams), so that
+  // one launch's tail is filled by the next one's workgroups instead of draining the chip between them.
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipStream_t const home = ctx->stream;
+  const bool conc = ctx->knob_spmm_conc && (plan->n1 > 0) + (plan->n2 > 0) + (plan->nchunks > 0) >= 2;
+  if (conc) { int rc = gcnx_aux_fork(ctx, aux); if (rc) return rc; }
+  int rc = GCNX_OK;
+  if (plan->n2 > 0) {        // (the 1024-thread tier first: its workgroups are the hardest to place)
+    rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
+                                 plan->n2, &bo, dmode);
   }
-  if (plan->n2 > 0) {
-    int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                     plan->n2, &bo, dmode);
-    if (rc) return rc;
+  if (!rc && plan->n1 > 0) {
+    if (conc) ctx->stream = aux[0];
+    rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, &bo, dmode);
+    ctx->stream = home;
   }
-  if (plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
+  if (!rc && plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
+    if (conc) ctx->stream = aux[1];
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
                   plan->nchunks);
-    GCNX_LAUNCH_OK(ctx);
+    if (hipGetLastError() != hipSuccess) rc = gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_csr: row-chunk launch failed");
+    ctx->stream = home;
   }
-  return GCNX_OK;
+  if (conc) { const int rj = gcnx_aux_join(ctx); if (!rc) rc = rj; }
+  return rc;
 }
 
 int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,

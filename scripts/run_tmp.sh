@@ -1,4 +1,5 @@
 #!/bin/bash
-# scratch: whatever the current measurement needs (see scripts/README.md)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 2000 --warmup 50 --cpu-seconds 0 --no-config3
+for c in 0 1 0 1; do echo "== conc $c"; python3 scripts/spmm_bench.py --workload block1m --rounds 2 --iters 20 --conc $c 2>&1 | tail -3; done
+python3 scripts/spmm_bench.py --workload powerlaw --rounds 2 --iters 10 --conc 0 2>&1 | tail -2
+python3 scripts/spmm_bench.py --workload powerlaw --rounds 2 --iters 10 --conc 1 2>&1 | tail -2

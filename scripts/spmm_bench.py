@@ -15,6 +15,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--slabs", default="0")
 ap.add_argument("--unweighted", action="store_true")
+ap.add_argument("--conc", type=int, default=-1, help="1 / 0: the plan path's launches as concurrent branches or not (spmm_conc)")
 args = ap.parse_args()
 if args.workload == "block1m":       # the batches bench.py times (per-graph-seeded generators)
     sizes, pairs = synth.block_diag_plan()
@@ -25,6 +26,7 @@ else:
     hb = synth.power_law_batch(122, 8192, 256, seed=3, with_x=False, first_graph=0); f = 256
 vals = None if args.unweighted else synth.gcn_norm_host(hb.rowptr, hb.colidx)
 ctx = gcnx.Context(0)
+if args.conc >= 0: ctx.set_tuning("spmm_conc", args.conc)
 a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
 h = ctx.to_device(np.random.default_rng(0).standard_normal((hb.n, f), dtype=np.float32))
 out = ctx.empty((hb.n, f)); bias = ctx.zeros(f)
