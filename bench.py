@@ -345,11 +345,12 @@ def main():
         model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
     comm.barrier()
     ctx.sync()
-    evs = [ctx.event().record()]
+    evs = [ctx.event() for _ in range(args.steps + 1)]     # created outside the timed region
+    evs[0].record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
-        evs.append(ctx.event().record())        # per-step HIP events on the ctx stream (median)
+        evs[i + 1].record()                     # per-step HIP events on the ctx stream (median)
     ctx.sync()
     comm.barrier()
     elapsed = time.perf_counter() - t0
