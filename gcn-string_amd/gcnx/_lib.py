@@ -100,6 +100,9 @@ SIGNATURES = {
     "gcnx_gcn_conv_bwd_scratch_floats": [_i64, _i32],
     "gcnx_gcn_conv_bwd_pool": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _int, _i32, _i32, _vp, _i32, _int, _vp, _i64,
                                _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _int, _vp],
+    "gcnx_spmm_csr_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int],
+    "gcnx_f32_to_bf16": [_vp, _vp, _vp, _i64],
+    "gcnx_bf16_to_f32": [_vp, _vp, _vp, _i64],
     "gcnx_gcn_conv_fwd_pool": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _int, _vp, _i64, _vp, _i64, _vp, _int,
                                _vp, _i32, _vp, _vp],
     "gcnx_gemm_dw2": [_vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _int, _vp, _vp,

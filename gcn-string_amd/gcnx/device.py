@@ -496,6 +496,30 @@ def gcn_conv_fwd(ctx, a, x, w, bias, out, act="relu", s=None, wt=None, prec="f32
     return out
 
 
+def to_bf16(ctx, x):
+    """bf16 copy (uint16 bit patterns, round to nearest even) of a contiguous fp32 array (gcnx_f32_to_bf16)."""
+    assert x.contiguous and x.dtype == np.float32
+    y = ctx.empty(x.shape, np.uint16)
+    ctx._ck(ctx.lib.gcnx_f32_to_bf16(ctx.h, x.ptr, y.ptr, x.size))
+    return y
+
+
+def from_bf16(ctx, x):
+    assert x.contiguous and x.dtype == np.uint16
+    y = ctx.empty(x.shape, np.float32)
+    ctx._ck(ctx.lib.gcnx_bf16_to_f32(ctx.h, x.ptr, y.ptr, x.size))
+    return y
+
+
+def spmm_bf16(ctx, a, h, bias, out, act=None):
+    """out = bf16(act(A h + bias)) with h and out stored as bf16 (uint16 arrays), fp32 accumulation (gcnx_spmm_csr_bf16)."""
+    n, f = h.shape
+    assert a.n == n and out.shape == (n, f) and h.dtype == np.uint16 and out.dtype == np.uint16
+    ctx._ck(ctx.lib.gcnx_spmm_csr_bf16(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), h.ptr, h.ld, _p(bias), out.ptr, out.ld, n, f,
+                                       L.ACTS[act]))
+    return out
+
+
 def pool_tile_rows(n, b):
     """Rows of the per-tile partial-sum arrays gcn_conv_fwd(pool=...) fills: one per (32-row tile, graph) pair at most."""
     return (int(n) + 31) // 32 + int(b)

@@ -444,6 +444,18 @@ GCNX_API int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const f
                       float* dwb, int32_t fib, int32_t fob, int64_t n, int prec, float* params, float* grads,
                       int64_t n_params, float lr, const gcnx_pending_reduce* pending, const gcnx_head_args* leaf);
 
+/* ---- aggregation with bf16 features ("fp32 and bf16 both reported") ----
+ * out[t, :] = bf16(act(sum_e vals[e] * h[colidx[e], :] + bias)): GCNConv.call's / GeneralConv's aggregation (gcn.py:334) on
+ * activations stored as bf16 (uint16_t bit patterns), fp32 accumulation, round-to-nearest-even on the way out; bias fp32
+ * (may be NULL), vals may be NULL (ones).  f in {64, 128, 256}, n * ldh * 2 < 2^32 (GCNX_ERR_UNSUPPORTED otherwise);
+ * act: GCNX_ACT_NONE / GCNX_ACT_RELU.  A measured variant: the models keep fp32 activations.
+ * gcnx_f32_to_bf16 (round to nearest even) / gcnx_bf16_to_f32: contiguous arrays of `count` elements. */
+GCNX_API int gcnx_spmm_csr_bf16(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                      const uint16_t* h, int64_t ldh, const float* bias, uint16_t* out, int64_t ldo, int32_t n, int32_t f,
+                      int act);
+GCNX_API int gcnx_f32_to_bf16(gcnx_ctx* ctx, const float* x, uint16_t* y, int64_t count);
+GCNX_API int gcnx_bf16_to_f32(gcnx_ctx* ctx, const uint16_t* x, float* y, int64_t count);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new capability) ---- */
 GCNX_API int gcnx_comm_unique_id(char id[GCNX_UNIQUE_ID_BYTES]);
 GCNX_API int gcnx_comm_init_rank(gcnx_ctx* ctx, const char id[GCNX_UNIQUE_ID_BYTES], int nranks,

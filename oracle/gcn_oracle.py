@@ -138,6 +138,31 @@ def spmm_csr(rowptr, colidx, vals, h):
     return out
 
 
+# bf16 feature storage (the aggregation "fp32 and bf16 both reported").  bfloat16 is the upper half
+# of an IEEE float32; TensorFlow's float32 -> bfloat16 cast rounds to nearest even (tensorflow/core/lib/bfloat16).  The
+# reference itself runs fp32 throughout (gcn.py:320-340): this models the device's bf16-feature variant, PARITY UNPINNED.
+
+def bf16_bits(x):
+    """float32 -> bfloat16 bit patterns (uint16), round to nearest even; NaN not handled (never produced here)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + np.uint32(0x7fff))) >> 16).astype(np.uint16)
+
+
+def bf16_from_bits(b):
+    """bfloat16 bit patterns -> the float32 values they denote (exact)."""
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def spmm_csr_bf16(rowptr, colidx, vals, h_bits, bias=None, relu=False):
+    """The aggregation of spmm_csr on bf16-stored features: exact products and sums (float64) of the bf16 values, bias,
+    ReLU; returns the float64 result BEFORE the final rounding (the caller rounds with bf16_bits and allows one unit in
+    the last place: the device accumulates in fp32, in another order)."""
+    out = spmm_csr(rowptr, colidx, None if vals is None else np.asarray(vals, np.float64), bf16_from_bits(h_bits).astype(np.float64))
+    if bias is not None:
+        out = out + np.asarray(bias, np.float64)
+    return np.maximum(out, 0) if relu else out
+
+
 def spmm_csr_T(rowptr, colidx, vals, g):
     """dH = A^T dZ :  dH[colidx[e]] += vals[e] * g[row(e)]   (K2^T / K3^T)."""
     n = len(rowptr) - 1

@@ -615,6 +615,66 @@ def test_gemm_bf16_streaming_kernel(ctx, n, fi, fo, monkeypatch):
         c2.close()
 
 
+@pytest.mark.parametrize("f", [64, 128, 256])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_bf16_features(ctx, f, weighted):
+    """gcnx_spmm_csr_bf16 (bf16 in / bf16 out, fp32 accumulation) against the oracle's exact aggregation of the same bf16
+    values: every output within one bf16 unit in the last place of the correctly rounded result (the device sums in fp32,
+    in another order), the large majority identical; ragged last tile; the converters bit-exact (round to nearest even)."""
+    from gcnx import device as D, synth
+    o = O()
+    hb = synth.ecoli_batch(3, f, seed=f)
+    a, vals = _csr(ctx, hb, weighted)
+    rng = np.random.default_rng(f)
+    hf = rng.standard_normal((hb.n, f), dtype=np.float32)
+    hf[0, :4] = [1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, -1.0 - 2.0 ** -8, 0.0]          # ties
+    bias = rng.standard_normal(f).astype(np.float32)
+    h16 = D.to_bf16(ctx, ctx.to_device(hf))
+    assert np.array_equal(h16.numpy(), o.bf16_bits(hf))
+    assert np.array_equal(D.from_bf16(ctx, h16).numpy(), o.bf16_from_bits(o.bf16_bits(hf)))
+    out = ctx.empty((hb.n, f), np.uint16)
+    for relu in (True, False):
+        D.spmm_bf16(ctx, a, h16, ctx.to_device(bias), out, act="relu" if relu else None)
+        ref = o.spmm_csr_bf16(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals, h16.numpy(), bias, relu)
+        want = o.bf16_bits(ref.astype(np.float32))
+        got = out.numpy()
+        # the final rounding is worth half a unit in the last place of the result (2^-9 relative), the fp32 accumulation
+        # 2^-24 per operation relative to the sum of the terms' MAGNITUDES (a sum that cancels keeps that error)
+        mag = o.spmm_csr_bf16(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None if vals is None else np.abs(vals),
+                              o.bf16_bits(np.abs(o.bf16_from_bits(h16.numpy()))), np.abs(bias))
+        vg = o.bf16_from_bits(got).astype(np.float64)
+        assert np.all(np.abs(vg - ref) <= 2.0 ** -8 * np.abs(ref) + 2.0 ** -19 * mag)
+        assert (got == want).mean() > 0.97                                        # and the large majority bit-identical
+        if relu:
+            assert not (got & 0x8000).any()
+    D.spmm_bf16(ctx, a, h16, None, out)                                           # no bias
+    ref = o.spmm_csr_bf16(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals, h16.numpy())
+    assert (np.abs(out.numpy().astype(np.int32) - o.bf16_bits(ref.astype(np.float32)).astype(np.int32)) <= 1).mean() > 0.999
+
+
+def test_spmm_bf16_long_rows_and_refusals(ctx):
+    """Rows longer than the tile's LDS staging (the overflow path), and widths the kernel does not serve."""
+    from gcnx import device as D, synth
+    from gcnx._lib import GcnxError
+    o = O()
+    hb = synth.power_law_batch(n_graphs=1, graph_size=8192, f=64, seed=3)
+    a, vals = _csr(ctx, hb, True)
+    assert np.diff(hb.rowptr).max() > 1024
+    h16 = D.to_bf16(ctx, ctx.to_device(hb.x))
+    out = ctx.empty((hb.n, 64), np.uint16)
+    D.spmm_bf16(ctx, a, h16, None, out)
+    ref = o.spmm_csr_bf16(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), vals, h16.numpy())
+    got = o.bf16_from_bits(out.numpy()).astype(np.float64)
+    mag = o.spmm_csr_bf16(hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), np.abs(vals),
+                          o.bf16_bits(np.abs(o.bf16_from_bits(h16.numpy()))))
+    assert np.all(np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 2.0 ** -19 * mag)     # final rounding + fp32 accumulation (4096-entry rows)
+    assert (out.numpy() == o.bf16_bits(ref.astype(np.float32))).mean() > 0.97
+    with pytest.raises(GcnxError, match="f in"):
+        D.spmm_bf16(ctx, a, ctx.empty((hb.n, 96), np.uint16), None, ctx.empty((hb.n, 96), np.uint16))
+    D.spmm_bf16(ctx, D.DeviceCSR.from_host_csr(ctx, np.zeros(1, np.int32), np.zeros(0, np.int32), None, None),
+                ctx.empty((0, 64), np.uint16), None, ctx.empty((0, 64), np.uint16))   # empty input: a no-op
+
+
 @pytest.mark.parametrize("mode", ["sum", "avg", "max"])
 def test_segment_pool_forward_backward(ctx, mode):
     from gcnx import device as D

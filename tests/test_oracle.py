@@ -277,3 +277,24 @@ def test_lr_schedule_and_losses():
     assert np.isclose(O.cce_loss_from_logits(y, zs), (60.0 + np.log1p(np.exp(-60.0)) + np.log(1 + np.exp(0.2))) / 2)
     assert np.isclose(O.cce_loss(y, O.softmax(zs)), (-np.log(1e-7) + np.log(1 + np.exp(0.2))) / 2)
     assert np.all(O.softmax_cce_grad(y, O.softmax(zs))[0] == 0) and abs(O.softmax_cce_grad_from_logits(y, O.softmax(zs))[0, 0] + 0.5) < 1e-12
+
+
+def test_bf16_rounding_is_nearest_even():
+    """bf16_bits against a scalar restatement (struct): ties go to the even mantissa, everything else to the nearest."""
+    import struct
+    from oracle import gcn_oracle as o
+
+    def ref(x):
+        u = struct.unpack("<I", struct.pack("<f", x))[0]
+        lower, rest = u >> 16, u & 0xffff
+        if rest > 0x8000 or (rest == 0x8000 and (lower & 1)):
+            lower += 1
+        return lower & 0xffff
+
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-6, 6, 2000),
+                         np.array([1.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, -1.0 - 2.0 ** -8, 0.0, 2.0 ** -126, 65504.0], np.float32)])
+    assert [int(b) for b in o.bf16_bits(xs)] == [ref(float(x)) for x in xs]
+    assert o.bf16_bits(np.float32([1.0 + 2.0 ** -8]))[0] == 0x3f80 and o.bf16_bits(np.float32([1.0 + 3 * 2.0 ** -8]))[0] == 0x3f82
+    back = o.bf16_from_bits(o.bf16_bits(xs))
+    assert np.all(np.abs(back - xs) <= np.abs(xs) * 2.0 ** -8)
