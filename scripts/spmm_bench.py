@@ -32,8 +32,18 @@ h = ctx.to_device(np.random.default_rng(0).standard_normal((hb.n, f), dtype=np.f
 out = ctx.empty((hb.n, f)); bias = ctx.zeros(f)
 alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, f, vals is not None)
 print(f"N={hb.n} nnz={hb.nnz} F={f} alg={alg/1e6:.1f} MB")
+h16 = D.to_bf16(ctx, h) if f in (64, 128, 256) else None
+o16 = ctx.empty((hb.n, f), np.uint16) if h16 is not None else None
+alg16 = 4 * (hb.n + 1) + (8 if vals is not None else 4) * hb.nnz + 4 * hb.n * f
 for rnd in range(args.rounds):
     for slab in args.slabs.split(","):
+        if slab == "bf16":               # the bf16-feature kernel (gcnx_spmm_csr_bf16), on its own algorithmic bytes
+            for _ in range(3): D.spmm_bf16(ctx, a, h16, bias, o16, act="relu")
+            e0 = ctx.event().record()
+            for _ in range(args.iters): D.spmm_bf16(ctx, a, h16, bias, o16, act="relu")
+            ms = ctx.event().record().elapsed_ms_since(e0) / args.iters
+            print(f"round {rnd} slab     bf16: {ms*1e3:9.1f} us  {alg16/ms/1e6:8.1f} GB/s  frac {alg16/ms/1e6/8000:.3f}", flush=True)
+            continue
         # variants: "0" = what the library picks; "rows" / "tile" / "pipe" = that kernel; a number = rows kernel, that slab width
         if "GCNX_SPMM_KERNEL" not in os.environ:
             ctx.set_tuning("spmm_slab", 0)
