@@ -257,6 +257,11 @@ def bench_generalgnn(ctx, args):
     for _ in range(max(args.warmup, 3)):
         model.train_step(batch, None, lr=0.0002, fetch=False)
     ctx.sync()
+    burn_steps, t_burn = 0, time.perf_counter()           # untimed burn-in, as in main()
+    while (time.perf_counter() - t_burn) * 1e3 < args.burn_in_ms:
+        model.train_step(batch, None, lr=0.0002, fetch=False)
+        ctx.sync()
+        burn_steps += 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.train_step(batch, None, lr=0.0002, fetch=False)
@@ -264,6 +269,7 @@ def bench_generalgnn(ctx, args):
     el = time.perf_counter() - t0
     print(json.dumps({"metric": "graphs/sec (fwd+bwd) GeneralGNN (gcn.py:320 defaults)", "value": hb.n_graphs * args.steps / el,
                       "unit": "graphs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "burn_in": {"steps": burn_steps, "ms": args.burn_in_ms},
                       "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": args.prec, "data": "synthetic",
                       "config": {"workload": f"GeneralGNN(hidden=256, 4 x GeneralConv, BN, PReLU, cat) on {args.workload}: "
@@ -300,6 +306,9 @@ def main():
     ap.add_argument("--scipy-seconds", type=float, default=4.0, help="budget of the NumPy/SciPy baseline C2 (0 = skip)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra config-3 SpMM roofline reading")
     ap.add_argument("--spmm-iters", type=int, default=0, help="SpMM-only launches for the roofline (default 4*steps)")
+    ap.add_argument("--burn-in-ms", type=float, default=60.0,
+                    help="untimed repetitions of the step before the timed region until this much wall time has passed "
+                         "(0 = none); reported as burn_in in the JSON line")
     ap.add_argument("--allow-knobs", action="store_true", help="run although GCNX_* tuning knobs are set (they are recorded)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -343,6 +352,22 @@ def main():
 
     for _ in range(max(args.warmup, 3)):        # >= 3: eager run, capture, first replay
         model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
+    # Burn-in (untimed, reported in the JSON line): a step here is 0.1 ms, so W warm-up steps are well under a millisecond
+    # of GPU work and the chip is still coming out of idle when the timed region starts -- the first few hundred steps
+    # then run 5-8 % slower than the rest (20 steps after 5 warm-up steps: 0.110 ms/step; after 50 ms of work: 0.1025;
+    # a 2000-step run: 0.1017).  A training run is minutes long: the steady state is the quantity of interest, so the same
+    # step is repeated until `--burn-in-ms` of wall time have passed, then the K timed steps follow as the contract says.
+    # (The count is agreed between the ranks -- every step holds a collective: 5 probe steps, max over ranks.)
+    burn_steps = 0
+    if args.burn_in_ms > 0:
+        ctx.sync(); t_burn = time.perf_counter()
+        for _ in range(5):
+            model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
+        ctx.sync()
+        per = float(comm.allreduce_host([(time.perf_counter() - t_burn) / 5], "max")[0])
+        burn_steps = 5 + int(min(max(args.burn_in_ms * 1e-3 / per - 5, 0), 5000))
+        for _ in range(burn_steps - 5):
+            model.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
     comm.barrier()
     ctx.sync()
     evs = [ctx.event() for _ in range(args.steps + 1)]     # created outside the timed region
@@ -445,6 +470,9 @@ def main():
                        "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32"
                                                         f"{' inside the step graph' if world > 1 and model._comm_in_graph() else ''})",
                        "hip_graph": not args.no_graph, "gemm_precision": args.prec, "cce": model.cce_train},
+            "burn_in": {"steps": burn_steps, "ms": args.burn_in_ms,
+                        "what": "untimed repetitions of the same step after the W warm-up steps and before the timed region (clock / "
+                                "cache steady state; the timed region is exactly `steps` full steps)"},
             "device_ms_per_step": dev_ms / args.steps,
             "m1_median": {"ms_per_step": med_ms, "graphs_per_s": global_graphs / (med_ms * 1e-3),
                           "what": "median of per-step HIP-event times on the ctx stream, max over ranks (SURVEY 8(d) M1); "
