@@ -1139,19 +1139,21 @@ def test_gcn_conv_fused_backward_and_dw2(ctx, f1, f2, mode, prec):
 
 @pytest.mark.parametrize("cce", ["logits", "probs"])
 @pytest.mark.parametrize("mode", ["sum", "avg"])
-@pytest.mark.parametrize("shape,h,c", [("ecoli", 128, 2), ("ecoli", 32, 1), ("ragged", 64, 2), ("many", 32, 2), ("tall", 128, 2)])
+@pytest.mark.parametrize("shape,h,c", [("ecoli", 128, 2), ("ecoli", 32, 1), ("ragged", 64, 2), ("many", 32, 2), ("tall", 128, 2),
+                                       ("saturated", 64, 2)])
 def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
     """gcnx_head_args: the forward launch leaves the pool's per-tile partial sums (gcnx_gcn_conv_fwd_pool) ->
     gcnx_gcn_conv_bwd_pool(head) adds them up and evaluates dPooled per graph itself -> gcnx_gemm_dw2(leaf) produces the
     head's outputs, against the sequence pool + head launch -> backward -> dw2 with the same operands.  "ragged":
     single-node graphs, so 32-row tiles span up to 13 graphs (several rounds of the in-kernel head); "many": more graphs
     than one head workgroup holds (the leaf falls back to a launch of its own); "tall": graphs of 72 and 35 tiles (more
-    partial rows than one pass of the strided loads covers); "ecoli" at h = 128, c = 2 is the shape the merged launch
-    serves.  Two runs agree bit for bit."""
+    partial rows than one pass of the strided loads covers); "saturated": logits in the hundreds (the clip branch of the
+    eager CCE form inside the kernels: no gradient); "ecoli" at h = 128, c = 2 is the shape the merged launch serves.
+    Two runs agree bit for bit."""
     from gcnx import device as D, synth
     from gcnx.device import DeviceCSR, Segments
     rng = np.random.default_rng(h + c)
-    if shape == "ecoli":
+    if shape in ("ecoli", "saturated"):
         hb = synth.ecoli_batch(4, h, seed=h)
         rowptr, colidx, gp = hb.rowptr, hb.colidx, hb.graph_ptr
     else:
@@ -1191,6 +1193,8 @@ def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
             assert rel_err(tph[t + g], y2h[lo:hi].sum(0, dtype=np.float64)) < TIGHT
     s1 = ctx.to_device(rng.standard_normal((n, 32), dtype=np.float32)); s2 = ctx.to_device(rng.standard_normal((n, f1), dtype=np.float32))
     scale = np.sqrt(h) * (n / b if mode == "sum" else 1.0)              # logits of order 1: no saturated softmax, gradients flow
+    if shape == "saturated":                                            # |logits| in the hundreds: probabilities of exactly 0 / 1 --
+        scale /= 300.0                                                  # the eager form clips (no gradient), the logits form does not
     w3 = ctx.to_device((rng.standard_normal((h, c)) / scale).astype(np.float32))
     b3 = ctx.to_device(rng.standard_normal(c).astype(np.float32))
     y = ctx.to_device(np.eye(c, dtype=np.float32)[rng.integers(0, c, b)])
@@ -1224,7 +1228,13 @@ def test_head_inside_the_backward_launches(ctx, shape, h, c, mode, cce):
         if k != "params":
             assert np.array_equal(out["late"][k], out["late grads only"][k]), k
     assert out["late"]["la"][1] == out["early"]["la"][1]                # hit count
-    assert np.any(out["late"]["grads"][offs[5]:offs[6]] != 0) or c == 1  # db2 was produced (c == 1: all gradients vanish)
+    if shape != "saturated":
+        assert np.any(out["late"]["grads"][offs[5]:offs[6]] != 0) or c == 1  # db2 was produced (c == 1: all gradients vanish)
+    else:
+        p_ = out["late"]["probs"]
+        assert np.all((p_ < 1e-7) | (p_ > 1 - 1e-7))                        # every graph saturated
+        if cce == "probs":
+            assert not out["late"]["dp"].any() and not out["late"]["dz2"].any()   # clipped: no gradient at all
 
 
 def test_head_inside_the_backward_refusals_and_fallbacks(ctx):
