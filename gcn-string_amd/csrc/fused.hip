@@ -20,6 +20,12 @@
 //            needs only the 17 KiB tile and three fit a CU.  A operand: S[row = l & 15][k] from the row-major tile,
 //            row stride K + 4 floats (4 row + k spreads the 64 lanes over the 64 banks).
 //   epilogue in registers (bias / ReLU, or the ReLU mask and the tile's column sums): no barrier after the last MFMA.
+//
+// The global pool and the classifier head (GlobalSumPool / GlobalAvgPool -> Dense(softmax) -> CCE, gcn.py:332-337) ride in
+// these launches too when the labels are binary: the forward of the pooled layer leaves per-(tile, graph) column sums and
+// positive counts from its epilogue (gcnx_gcn_conv_fwd_pool), the backward adds up its tile's graphs' partial sums under
+// the staging latency and evaluates dPooled itself (gcnx_head_args) -- neither a pool nor a head launch stands between
+// the forward and the backward aggregation, and no workgroup ever waits for another.
 #include "common.h"
 
 namespace {
