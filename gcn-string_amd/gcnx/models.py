@@ -160,7 +160,8 @@ class GCN2(_GraphRunner):
         # tuning knobs (diagnostics), read ONCE here -- the sequence a model runs never changes under it
         self._knob = {"fold": os.environ.get("GCNX_FOLD", "1") != "0", "duo": os.environ.get("GCNX_DUO", "1") != "0",
                       "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1")),
-                      "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0"}
+                      "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0",
+                      "s_order": os.environ.get("GCNX_S_ORDER", "1") != "0"}
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
@@ -232,6 +233,8 @@ class GCN2(_GraphRunner):
             tr = D.pool_tile_rows(n, b)
             self._bufs["tp_part"], self._bufs["tp_cnt"] = v("tp_part", tr, h), v("tp_cnt", tr, h)
             self._bufs["pool_sum"], self._bufs["pool_cnt"] = v("pool_sum", b, h), v("pool_cnt", b, h)
+        elif self._s_order():
+            self._bufs["s1"] = v("s1", n, self.f_in)            # S1 = A X: layer 1 evaluated as (A X) W1, dW1 = S1^T dZ1
         for k, w in (("pooled", h), ("probs", c), ("dpooled", h)):
             self._bufs[k] = v(k, b, w)
         self._bufs["arg"] = v("arg", b, h, np.int32) if self.pool == "max" else None
@@ -251,8 +254,15 @@ class GCN2(_GraphRunner):
                            wt=bufs["w2t"] if keep else None, prec=prec,
                            pool=(batch.seg, bufs["tp_part"], bufs["tp_cnt"]) if late else None)
         else:
-            D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
-            D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
+            if self._s_order():
+                # layer 1 as (A X) W1: the same product as GCNConv's A (X W1), two launches either way -- but the layer's
+                # input needs no gradient, so with S1 = A X kept dW1 = S1^T dZ1 and the backward pass has no aggregation
+                # for this layer (one of the step's four, 575 us of 4.7 ms at config 3)
+                D.spmm(ctx, batch.a, batch.x, None, bufs["s1"])
+                D.gemm(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], act="relu", prec=prec)
+            else:
+                D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
+                D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
             D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
             # pooled layer on the tile kernels with a backward pass to follow: its launch also writes [Y2 > 0] as a bit
             # image, which the folded backward aggregation expands instead of reading Y2 again (1 GB -> 32 MB at config 3)
@@ -327,15 +337,15 @@ class GCN2(_GraphRunner):
             if lr is None:
                 D.dense_bwd(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], prec=prec, y_mask=bufs["y1"],
                             db_prev=g["b1"])                                   # dW2, dZ1, db1
-                D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                 # dH1 = A^T dZ1
-                D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)        # dW1 = X^T dH1
+                xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
+                D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                    # dW1 = X^T (A^T dZ1) or S1^T dZ1
                 return False
             # With the update in the same step, the reductions that finish the leaves dW2 / db1 wait for the last
             # launch: the split-K reduction of dW1 folds them in and applies the SGD step to every parameter.
             pend = D.dense_bwd_deferred(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], self._defer_scratch(batch),
                                         prec=prec, y_mask=bufs["y1"], db_prev=g["b1"])
-            D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                     # dH1 = A^T dZ1
-            D.gemm_dw_sgd(ctx, batch.x, bufs["h2"], g["w1"], self.flat_p, self.flat_g.flat(0, self.n_params), lr, prec=prec,
+            xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
+            D.gemm_dw_sgd(ctx, xs, dh1, g["w1"], self.flat_p, self.flat_g.flat(0, self.n_params), lr, prec=prec,
                           pending=pend)
             return True
         with ctx.side():
@@ -344,9 +354,21 @@ class GCN2(_GraphRunner):
             # (folded: db2 came out of the head -- from the pool's own count of positive entries)
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
         D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
-        D.spmm(ctx, at, bufs["dz2"], None, bufs["h2"])                         # dH1 = A^T dZ1
-        D.gemm_dw(ctx, batch.x, bufs["h2"], g["w1"], prec=prec)                # dW1 = X^T dH1
+        xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
+        D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                            # dW1 = X^T (A^T dZ1) or S1^T dZ1
         ctx.join()
+
+    def _s_order(self):
+        """Layer 1 as (A X) W1 in the two-launch (non-fused) paths: when the aggregation is not wider that way (F <= H)."""
+        return self._knob["s_order"] and self.built and self.f_in <= self.hidden
+
+    def _layer1_dw_operands(self, batch, bufs, at):
+        """The two operands of dW1 with dZ1 in bufs["dz2"]: (S1, dZ1) when the forward kept S1 = A X, otherwise
+        (X, A^T dZ1) -- after the backward aggregation of layer 1."""
+        if "s1" in bufs and not self._fused(batch):
+            return bufs["s1"], bufs["dz2"]
+        D.spmm(self.ctx, at, bufs["dz2"], None, bufs["h2"])                    # dH1 = A^T dZ1
+        return batch.x, bufs["h2"]
 
     def _defer_scratch(self, batch):
         """Device buffer that holds the deferred partial results of layer 2's dense backward (grow-only)."""

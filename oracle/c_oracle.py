@@ -21,8 +21,9 @@ def build():
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        src = os.path.join(_HERE, "gcn_oracle.c")
+        if not os.path.exists(LIB) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB)):
+            build()                                        # (make: a no-op when the library is current)
         _lib = C.CDLL(LIB)
         _lib.orc_max_threads.restype = C.c_int
     return _lib
@@ -74,15 +75,20 @@ class Gcn2Cpu:
         self.x = np.ascontiguousarray(batch.x, np.float32)
         self.y = np.ascontiguousarray(batch.y, np.float32)
 
-    def step(self, lr=0.0, denom=None, cce="logits", bf16_operands=False):
+    def step(self, lr=0.0, denom=None, cce="logits", bf16_operands=False, layer1_s_order=False):
         """cce "logits": the loss train_step computes under tf.function; "probs": the eager clip form.
-        bf16_operands: every dense product sees bf16-rounded operands (fp32 accumulate) -- the GCNX_PREC_BF16 model."""
+        bf16_operands: every dense product sees bf16-rounded operands (fp32 accumulate) -- the GCNX_PREC_BF16 model.
+        layer1_s_order: layer 1 as (A X) W1 -- the device's order when F <= H; matters for the bf16-operand model only
+        (which operands get rounded), the fp32 checks run against the reference's order A (X W1)."""
         b = self.b
         self.lib.orc_set_bf16_operands(C.c_int(1 if bf16_operands else 0))
+        s1 = np.empty(b.n * b.f, np.float32) if layer1_s_order else None
+        self.lib.orc_set_layer1_s_order(_f(s1))
         self.lib.orc_gcn2_step(_f(self.rowptr), _f(self.colidx), _f(self.vals), _f(self.gp), _f(self.x), _f(self.y),
                                C.c_int32(b.n), C.c_int32(b.n_graphs), C.c_int32(b.f), C.c_int32(self.h),
                                C.c_int32(self.c), _f(self.params), _f(self.grads), C.c_float(lr),
                                C.c_float(denom or b.n_graphs), _f(self.work), _f(self.out),
                                C.c_int(1 if cce == "logits" else 0))
         self.lib.orc_set_bf16_operands(C.c_int(0))
+        self.lib.orc_set_layer1_s_order(None)
         return float(self.out[0]), float(self.out[1]) / b.n_graphs

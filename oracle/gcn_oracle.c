@@ -47,6 +47,13 @@ API void orc_set_threads(int n) {
  * checked against an oracle fed the same rounded operands instead of a loose bound. */
 static int g_bf16 = 0;
 API void orc_set_bf16_operands(int on) { g_bf16 = on; }
+/* Layer 1 of orc_gcn2_step as (A X) W1 instead of A (X W1) -- the same product (gcn.py:334 computes the latter), in the
+ * order the device path takes when F <= H: the layer's input needs no gradient, so with S1 = A X saved its weight
+ * gradient is S1^T dZ1 and the backward aggregation of layer 1 disappears.  Only the bf16-operand MODEL needs this
+ * switch (the operands that get rounded are then S1 and dZ1 instead of X and A^T dZ1); the fp32 parity checks run
+ * against the reference's own order.  `s1` scratch: N * F floats, passed through orc_set_layer1_s_order. */
+static float* g_s1 = NULL;
+API void orc_set_layer1_s_order(float* s1_scratch) { g_s1 = s1_scratch; }
 static inline float opnd(float v) {
   if (!g_bf16) return v;
   uint32_t u;
@@ -279,8 +286,13 @@ API void orc_gcn2_step(const int32_t* rowptr, const int32_t* colidx, const float
   float* logits = dpooled + (int64_t)b * hdim;
   float* probs = logits + (int64_t)b * c;  float* dlogits = probs + (int64_t)b * c;
 
-  orc_gemm(x, f, w1, NULL, h, hdim, n, f, hdim, 0);
-  orc_spmm_csr(rowptr, colidx, vals, h, hdim, b1, y1, hdim, n, hdim, 1);
+  if (g_s1) {
+    orc_spmm_csr(rowptr, colidx, vals, x, f, NULL, g_s1, f, n, f, 0);
+    orc_gemm(g_s1, f, w1, b1, y1, hdim, n, f, hdim, 1);
+  } else {
+    orc_gemm(x, f, w1, NULL, h, hdim, n, f, hdim, 0);
+    orc_spmm_csr(rowptr, colidx, vals, h, hdim, b1, y1, hdim, n, hdim, 1);
+  }
   orc_gemm(y1, hdim, w2, NULL, h, hdim, n, hdim, hdim, 0);
   orc_spmm_csr(rowptr, colidx, vals, h, hdim, b2, y2, hdim, n, hdim, 1);
   orc_pool(gp, y2, hdim, pooled, b, hdim, 0, NULL);
@@ -302,8 +314,12 @@ API void orc_gcn2_step(const int32_t* rowptr, const int32_t* colidx, const float
   orc_gemm_dw(y1, hdim, h, hdim, gw2, n, hdim, hdim);
   orc_gemm_dx(h, hdim, w2, dz, hdim, n, hdim, hdim, y1, hdim);
   orc_colsum(dz, hdim, n, hdim, gb1);
-  orc_spmm_csr(rowptr, colidx, vals, dz, hdim, NULL, h, hdim, n, hdim, 0);
-  orc_gemm_dw(x, f, h, hdim, gw1, n, f, hdim);
+  if (g_s1) {
+    orc_gemm_dw(g_s1, f, dz, hdim, gw1, n, f, hdim);
+  } else {
+    orc_spmm_csr(rowptr, colidx, vals, dz, hdim, NULL, h, hdim, n, hdim, 0);
+    orc_gemm_dw(x, f, h, hdim, gw1, n, f, hdim);
+  }
   if (lr > 0.f) {
     const int64_t np_ = (int64_t)f * hdim + hdim + (int64_t)hdim * hdim + hdim + (int64_t)hdim * c + c;
     for (int64_t i = 0; i < np_; ++i) params[i] -= lr * grads[i];

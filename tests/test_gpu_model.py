@@ -758,7 +758,8 @@ def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     ref = {}
     for key, bf in (("f32", False), ("bf16", True)):
         cpu.params[:] = flat0
-        rl, ra = cpu.step(lr=0.0, bf16_operands=bf)
+        # (the bf16-operand MODEL follows the device's order of layer 1, (A X) W1 at F <= H: which operands get rounded)
+        rl, ra = cpu.step(lr=0.0, bf16_operands=bf, layer1_s_order=bf)
         ref[key] = (rl, ra, cpu.grads.copy())
     lr = np.float32(0.05)
     for prec, key, tol in (("f32", "f32", TOL), ("bf16x3", "f32", 3e-4), ("bf16", "bf16", 3e-4)):
