@@ -389,6 +389,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   splitk_reduce_body(part, slab, nsplit, out, total, blockIdx.x, s);
 }
 
+// The same reduction for MANY slabs (the streaming dW kernels leave one 256 KiB slab per CU): four outputs per thread
+// (16-byte loads), eight slabs in flight per thread.  With one output per thread and four loads in flight the 64 slabs
+// of a group were sixteen dependent round trips of 256-byte requests: 113 us for 67 MB at config 3.  Same summation
+// order per output as splitk_reduce_kernel (four groups of consecutive slabs, ascending, then (s0 + s1) + (s2 + s3)):
+// the results are bit-identical.  Needs total % 4 == 0, slab % 4 == 0 and 16-byte aligned pointers.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* __restrict__ part, int64_t slab, int nsplit,
+                                                                 float* __restrict__ out, int64_t total) {
+  __shared__ float4 s[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + el) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total) {
+    const int per = (nsplit + 3) / 4;
+    const int z0 = grp * per, z1 = min(nsplit, z0 + per);
+    int z = z0;
+    for (; z + 8 <= z1; z += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)(z + u) * slab + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; z < z1; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)z * slab + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  s[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0 && i < total) {
+    const float4 a = s[0][el], b = s[1][el], c = s[2][el], d = s[3][el];
+    *reinterpret_cast<float4*>(out + i) = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y),
+                                                      (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  }
+}
+
 // The last gradient and the optimizer step in one launch (gcnx_gemm_dw_sgd).  Workgroups, in order:
 //   [0, n_s)        fold this call's split-K slabs into dW (an interval of the flat gradient buffer) and update it;
 //   [.., + n_pc)    fold a PENDING column-sum reduction (gcnx_dense_bwd_deferred) and update its parameters;
@@ -1131,6 +1167,10 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
       const int ns = gcnx_gemm_dw_stream(ctx, x, ldx, dh, lddh, (float*)ctx->ws, n, fi, fo, prec, max_slices);
       if (ns < 0) return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_gemm_dw: streaming kernel launch failed");
       if (ns > 0) {
+        if (al16(dw))
+          hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(gcnx_cdiv(65536, 256)), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
+                             (int64_t)65536, ns, dw, (int64_t)65536);
+        else
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gcnx_cdiv(65536, 64)), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
                            (int64_t)65536, ns, dw, (int64_t)65536);
         GCNX_LAUNCH_OK(ctx);
