@@ -151,6 +151,16 @@ class DeviceArray:
         self._spmm_plan = None
 
     @classmethod
+    def _view(cls, base, nelem_off, shape):
+        """Contiguous view of ``base`` starting at element ``nelem_off`` with a shape of plain ints -- flat() without its
+        checks, for callers that build many views per step (the per-batch activation views of a streamed epoch)."""
+        self = object.__new__(cls)
+        self.ctx, self.ptr, self.shape, self.dtype = base.ctx, base.ptr + nelem_off * base.dtype.itemsize, shape, base.dtype
+        self.ld = shape[-1]
+        self._base, self._owner, self._spmm_plan = base, False, None
+        return self
+
+    @classmethod
     def alloc(cls, ctx, shape, dtype):
         shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize

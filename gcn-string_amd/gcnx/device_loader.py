@@ -79,7 +79,8 @@ def collate_on_device(ds, indices, bufs=None):
     be = np.concatenate([[0], np.cumsum(ds.nnz_sizes[sel])])
     n, nnz = int(bn[-1]), int(be[-1])
     desc = np.concatenate([sel, [0], bn, be]).astype(np.int32)
-    dview = bufs.desc.flat(0, desc.size)
+    V = D.DeviceArray._view                              # (views without flat()'s checks: eight per batch)
+    dview = V(bufs.desc, 0, (int(desc.size),))
     dview.copy_from_host(desc, wait=False)               # queued: the host runs ahead of the GPU across batches
     f, c = ds.n_features, ds.n_labels
     csr = ds.csr
@@ -87,11 +88,11 @@ def collate_on_device(ds, indices, bufs=None):
                                  csr.vals.ptr if csr.vals is not None else None, ds.x.ptr, ds.x.ld, f, ds.y.ptr, c,
                                  bufs.rowptr.ptr, bufs.colidx.ptr, bufs.vals.ptr if bufs.vals is not None else None,
                                  bufs.x.ptr, bufs.x.ld, bufs.y.ptr, bufs.gp.ptr, bufs.ids.ptr))
-    seg = D.Segments.from_device(ctx, bufs.gp.flat(0, b + 1), bn)
-    seg._ids = bufs.ids.flat(0, max(n, 1))               # (otherwise built on the host on first use and uploaded)
-    a = D.DeviceCSR(ctx, n, nnz, bufs.rowptr.flat(0, n + 1), bufs.colidx.flat(0, max(nnz, 1)),
-                    bufs.vals.flat(0, max(nnz, 1)) if bufs.vals is not None else None, seg.dev, b, ds.symmetric)
-    batch = DeviceBatch(ctx, bufs.x.flat(0, n * f, (n, f)), a, seg, bufs.y.flat(0, b * c, (b, c)))
+    seg = D.Segments.from_device(ctx, V(bufs.gp, 0, (b + 1,)), bn)
+    seg._ids = V(bufs.ids, 0, (max(n, 1),))              # (otherwise built on the host on first use and uploaded)
+    a = D.DeviceCSR(ctx, n, nnz, V(bufs.rowptr, 0, (n + 1,)), V(bufs.colidx, 0, (max(nnz, 1),)),
+                    V(bufs.vals, 0, (max(nnz, 1),)) if bufs.vals is not None else None, seg.dev, b, ds.symmetric)
+    batch = DeviceBatch(ctx, V(bufs.x, 0, (n, f)), a, seg, V(bufs.y, 0, (b, c)))
     batch._bufs = bufs                                   # keeps the capacity buffers alive with the batch
     return batch
 

@@ -71,7 +71,7 @@ class _Capacity:
             size = max(need, int(1.25 * cur.size) if cur is not None else 0, 1)
             cur = (self.ctx.zeros if zero else self.ctx.empty)(size, dtype)
             self.store[name] = cur
-        return cur.flat(0, need, (int(rows), int(width)))
+        return D.DeviceArray._view(cur, 0, (int(rows), int(width)))
 
 
 class _GraphRunner:
