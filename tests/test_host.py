@@ -25,6 +25,27 @@ def test_abi_exports_every_declared_symbol():
     assert lib.gcnx_version() >= 100
 
 
+def test_abi_structs_match_their_ctypes_mirrors(tmp_path):
+    """gcnx_pending_reduce and gcnx_head_args cross the boundary by pointer: the ctypes mirrors in gcnx/_lib.py must have
+    the layout a C compiler gives the declarations of include/gcnx.h (size and every field offset)."""
+    import ctypes as C
+    from gcnx import _lib
+    src = tmp_path / "layout.c"
+    fields = {"gcnx_pending_reduce": [f for f, _ in _lib.PendingReduce._fields_],
+              "gcnx_head_args": [f for f, _ in _lib.HeadArgs._fields_]}
+    body = "".join(f'  printf("{st} %zu", sizeof({st}));\n' +
+                   "".join(f'  printf(" %zu", offsetof({st}, {f}));\n' for f in fl) + '  printf("\\n");\n'
+                   for st, fl in fields.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gcnx.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    for line, (st, cls) in zip(out, (("gcnx_pending_reduce", _lib.PendingReduce), ("gcnx_head_args", _lib.HeadArgs))):
+        name, size, *offs = line.split()
+        assert name == st and int(size) == C.sizeof(cls), (st, size, C.sizeof(cls))
+        assert [int(o) for o in offs] == [getattr(cls, f).offset for f, _ in cls._fields_], st
+
+
 def test_no_cpu_fallback_without_gpu():
     """The product path must fail loudly when no HIP device exists (this container)."""
     import ctypes as C
