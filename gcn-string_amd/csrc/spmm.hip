@@ -87,6 +87,20 @@ struct FoldArgs {
   int32_t avg;         // 1: GlobalAvgPool (row scale 1 / n_g)
 };
 
+// Tuning builds only (make TUNING=1): per-wave lifetimes of the row-gather kernel, for the load-imbalance figure SURVEY
+// 8(d) asks for at config 5 (max / mean wave time).  g_wave_stamps: [blocks * 4] durations in s_memrealtime ticks (100 MHz),
+// set through gcnx_tuning_wave_stamps; NULL = off.
+#ifdef GCNX_TUNING
+__device__ unsigned long long* g_wave_stamps = nullptr;
+#define GCNX_WSTAMP_BEGIN const unsigned long long wst0_ = __builtin_amdgcn_s_memrealtime();
+#define GCNX_WSTAMP_END                                                                              \
+  if (g_wave_stamps && (threadIdx.x & 63) == 0)                                                      \
+    g_wave_stamps[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime() - wst0_;
+#else
+#define GCNX_WSTAMP_BEGIN
+#define GCNX_WSTAMP_END
+#endif
+
 template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false>
 __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   // 8 waves per SIMD = at most 64 VGPRs (latency regime)
    const int32_t* __restrict__ rowptr,
@@ -105,6 +119,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   __shared__ int32_t s_rp[RPC + 1];
   __shared__ float4 s_long[4][LPR];     // per-wave partial sums of a long row
 
+  GCNX_WSTAMP_BEGIN
   const int chunk = gcnx_xcd_remap(blockIdx.x, nchunks);
   int r0 = chunk * RPC;
   int r1 = min(n, r0 + RPC);
@@ -332,8 +347,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   // Hub rows (power-law batches: one row of a chunk can hold thousands of entries).  Walked by a single wave such a
   // row alone set the kernel's duration (config 5: a 4096-entry row = 2 ms); here every wave of the workgroup takes
   // a quarter of its entries and the four partial sums are combined in wave order (deterministic).
-  if (e1 - e0 <= kLongRow) return;               // no row of this chunk can be that long (uniform)
-  if (!__syncthreads_or(saw_long)) return;       // ... and none was (one barrier; the scan below costs more)
+  if (e1 - e0 <= kLongRow) { GCNX_WSTAMP_END return; }           // no row of this chunk can be that long (uniform)
+  if (!__syncthreads_or(saw_long)) { GCNX_WSTAMP_END return; }   // ... and none was (one barrier; the scan below costs more)
   const int nnz_all = rowptr[n];
   for (int r = r0; r < r1; ++r) {                // uniform over the workgroup
     const int a = s_rp[r - r0] - e0, b = s_rp[r - r0 + 1] - e0;
@@ -410,6 +425,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
       *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = t;
     }
   }
+  GCNX_WSTAMP_END
 }
 
 // Broadcast of lane J's value to the lanes of its row group as a DPP quad_perm move (VALU; no
@@ -1108,6 +1124,16 @@ struct gcnx_spmm_plan {
   int2* pipe_chunks = nullptr;          // ... and the 32-row chunks of the graphs too tall for it (> 1248 rows), for the rows kernel
   int npipe_chunks = 0;
 };
+
+#ifdef GCNX_TUNING
+// Tuning builds only (not in include/gcnx.h): where spmm_rows_kernel leaves its per-wave lifetimes; NULL switches them off.
+extern "C" __attribute__((visibility("default"))) int gcnx_tuning_wave_stamps(gcnx_ctx* ctx, unsigned long long* dev_buf) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_stamps), &dev_buf, sizeof(dev_buf), 0, hipMemcpyHostToDevice, ctx->stream));
+  GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GCNX_OK;
+}
+#endif
 
 extern "C" {
 
