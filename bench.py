@@ -239,7 +239,7 @@ def cpu_baseline_scipy(hb, hidden, params_flat, budget_s):
 
 def env_knobs():
     """GCNX_* tuning knobs present in the environment (diagnostics: some change kernel selection)."""
-    allowed = {"GCNX_RUN_ID", "GCNX_CPU_THREADS", "GCNX_BENCH_TIMEOUT", "GCNX_LIB"}
+    allowed = {"GCNX_RUN_ID", "GCNX_CPU_THREADS", "GCNX_BENCH_TIMEOUT", "GCNX_LIB", "GCNX_ROCTX"}   # (ROCTX: trace markers only)
     return {k: v for k, v in os.environ.items() if k.startswith("GCNX_") and k not in allowed}
 
 

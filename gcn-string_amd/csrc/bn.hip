@@ -374,6 +374,7 @@ int gcnx_bn_finalize(gcnx_ctx* ctx, const float* sums, float count, int32_t f, f
 int gcnx_bn_moments(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f, float momentum, float eps,
                     float* mean, float* inv, float* moving_mean, float* moving_var) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "batch norm (moments)");
   GCNX_REQUIRE(ctx, n > 0 && f >= 0, "gcnx_bn_moments: needs at least one row");
   if (f == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, z && ldz >= f && mean && inv, "gcnx_bn_moments: NULL pointer / bad ldz");
@@ -400,6 +401,7 @@ int gcnx_bn_moments(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32
 int gcnx_bn_act(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32_t f, const float* mean, const float* inv,
                 const float* gamma, const float* beta, int act, const float* alpha, float* y, int64_t ldy) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "batch norm (apply)");
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_bn_act: negative size");
   GCNX_REQUIRE(ctx, act >= GCNX_ACT_NONE && act <= GCNX_ACT_PRELU, "gcnx_bn_act: unknown activation %d", act);
   if (n == 0 || f == 0) return GCNX_OK;

@@ -40,6 +40,10 @@ struct gcnx_ctx {
   int ev_next = 0;
   int num_cus = 256;
   std::string arch;
+  // roctx ranges around the kernel classes (GCNX_ROCTX=1: librocprofiler-sdk-roctx is loaded at ctx creation; shown by
+  // rocprofv3 --marker-trace).  NULL = off: a range then costs one branch.
+  int (*roctx_push)(const char*) = nullptr;
+  int (*roctx_pop)() = nullptr;
   // Two auxiliary streams for launches of ONE call that write disjoint rows (the aggregation's tier kernels and its
   // row-chunk part): gcnx_aux_fork / gcnx_aux_join below.  Created on first use.
   hipStream_t aux_stream[2] = {};
@@ -129,6 +133,16 @@ int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, 
 
 #define GCNX_CHECK_CTX(ctx) \
   do { if (!(ctx)) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "%s: ctx is NULL", __func__); } while (0)
+
+// A named range over the launches of one entry point (tracing: SURVEY section 5).  Place behind GCNX_CHECK_CTX.
+struct GcnxRange {
+  gcnx_ctx* c;
+  GcnxRange(gcnx_ctx* ctx, const char* name) : c(ctx && ctx->roctx_push ? ctx : nullptr) { if (c) c->roctx_push(name); }
+  ~GcnxRange() { if (c && c->roctx_pop) c->roctx_pop(); }
+  GcnxRange(const GcnxRange&) = delete;
+  GcnxRange& operator=(const GcnxRange&) = delete;
+};
+#define GCNX_RANGE(ctx, name) GcnxRange gcnx_range_((ctx), (name))
 
 #define GCNX_HIP(ctx, expr)                                                                   \
   do {                                                                                        \

@@ -534,6 +534,7 @@ int gcnx_gcn_conv_fwd_pool(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
                            int64_t lds, float* out, int64_t ldo, float* wt_out, int prec, const int32_t* node_graph, int32_t b,
                            float* tile_part, float* tile_cnt) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "GCNConv forward (one launch)");
   GCNX_REQUIRE(ctx, (!tile_part && !tile_cnt) || (tile_part && tile_cnt && node_graph && b > 0 && fal16(tile_part) && fal16(tile_cnt)),
                "gcnx_gcn_conv_fwd_pool: the pool's partial sums need node_graph, b > 0 and two 16-byte aligned outputs");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gcn_conv_fwd: negative size");
@@ -572,6 +573,7 @@ int gcnx_gcn_conv_bwd_pool(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t
                            float* scratch, int64_t scratch_floats, gcnx_pending_reduce* pending, int prec,
                            const gcnx_head_args* head) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "GCNConv backward (one launch)");
   if (prec != GCNX_PREC_F32 && prec != GCNX_PREC_BF16X3)
     return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gcn_conv_bwd_pool: precision %d (GCNX_PREC_F32 or GCNX_PREC_BF16X3 here)", prec);
   if (pending) *pending = gcnx_pending_reduce{nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr};

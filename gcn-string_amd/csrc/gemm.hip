@@ -956,6 +956,7 @@ extern "C" {
 int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias, float* out,
               int64_t ldo, int64_t n, int32_t fi, int32_t fo, int prec, int act, const float* alpha) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (X W)");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm: negative size");
   GCNX_REQUIRE(ctx, act >= GCNX_ACT_NONE && act <= GCNX_ACT_PRELU, "gcnx_gemm: unknown activation %d", act);
   GCNX_REQUIRE(ctx, act != GCNX_ACT_PRELU || alpha, "gcnx_gemm: PReLU needs alpha");
@@ -978,6 +979,7 @@ int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const 
 int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx, int64_t lddx, int64_t n,
                  int32_t fi, int32_t fo, int prec, int accumulate, const float* y_mask, int64_t ldy, float* db) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (dX)");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dx: negative size");
   GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dx: unknown precision %d", prec);
   GCNX_REQUIRE(ctx, !(accumulate && (y_mask || db)), "gcnx_gemm_dx: accumulate cannot be combined with mask/db");
@@ -1073,6 +1075,7 @@ int gcnx_dense_bwd_deferred(gcnx_ctx* ctx, const float* x, int64_t ldx, const fl
                             int64_t ldy, float* db_prev, float* dw, float* scratch, int64_t scratch_floats,
                             gcnx_pending_reduce* pending) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "dense backward (dX + dW)");
   GCNX_REQUIRE(ctx, pending != nullptr, "gcnx_dense_bwd_deferred: pending is NULL");
   return dense_bwd_impl(ctx, x, ldx, dh, lddh, w, n, fi, fo, prec, dx, lddx, y_mask, ldy, db_prev, dw, scratch, scratch_floats,
                         pending);
@@ -1148,6 +1151,7 @@ extern "C" {
 int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n,
                  int32_t fi, int32_t fo, int prec) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (dW)");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dw: negative size");
   GCNX_REQUIRE(ctx, prec >= GCNX_PREC_F32 && prec <= GCNX_PREC_BF16X3, "gcnx_gemm_dw: unknown precision %d", prec);
   if (fi == 0 || fo == 0) return GCNX_OK;
@@ -1254,6 +1258,7 @@ int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh
                      int32_t fi, int32_t fo, int prec, float* params, float* grads, int64_t n_params, float lr,
                      const gcnx_pending_reduce* pending) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (dW) + update");
   if (pending && !pending->colpart && !pending->slabs) pending = nullptr;
   if (pending) {
     GCNX_REQUIRE(ctx, !pending->colpart || (pending->cout >= grads && pending->cout + pending->cf <= grads + n_params &&
@@ -1316,6 +1321,7 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
                   int32_t fob, int64_t n, int prec, float* params, float* grads, int64_t n_params, float lr,
                   const gcnx_pending_reduce* pending, const gcnx_head_args* leaf) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMMs (dW1 + dW2) + head leaves + update");
   if (leaf) {
     GCNX_REQUIRE(ctx, leaf->pool_sum && leaf->graph_ptr && leaf->w && leaf->y && leaf->probs && leaf->loss_acc && leaf->dw && leaf->dpooled &&
                           leaf->pooled && leaf->b > 0 && leaf->h > 0 && leaf->h % 4 == 0 && leaf->c >= 1 && leaf->c <= gcnx_head::kHeadMaxC &&

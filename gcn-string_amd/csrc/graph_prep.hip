@@ -290,6 +290,7 @@ int gcnx_collate(gcnx_ctx* ctx, const int32_t* desc, int32_t b, const int32_t* n
                  int32_t* o_rowptr, int32_t* o_colidx, float* o_vals, float* o_x, int64_t ldo, float* o_y,
                  int32_t* o_graph_ptr, int32_t* o_node_graph) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "device-side collate");
   GCNX_REQUIRE(ctx, b >= 0 && f >= 0 && c >= 0, "gcnx_collate: negative size");
   if (b == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, desc && node_ptr && rowptr && colidx && o_rowptr && o_colidx && o_graph_ptr, "gcnx_collate: NULL pointer");

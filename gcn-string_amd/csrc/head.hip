@@ -48,6 +48,7 @@ int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const f
                                 float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp, float* db_relu,
                                 int cce_mode) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "pool + classifier head");
   GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_pool_dense_softmax_cce: bad shape");
   GCNX_REQUIRE(ctx, pool_mode >= GCNX_POOL_SUM && pool_mode <= GCNX_POOL_MAX, "gcnx_pool_dense_softmax_cce: unknown pool mode %d",
                pool_mode);

@@ -563,6 +563,7 @@ int gcnx_act_bias_grad(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float
 int gcnx_segment_pool(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, float* pooled, int32_t b,
                       int32_t f, int mode, int32_t* argmax) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "global pool");
   GCNX_REQUIRE(ctx, b >= 0 && f >= 0, "gcnx_segment_pool: negative size");
   GCNX_REQUIRE(ctx, mode >= GCNX_POOL_SUM && mode <= GCNX_POOL_MAX, "gcnx_segment_pool: unknown mode %d", mode);
   if (b == 0 || f == 0) return GCNX_OK;
@@ -592,6 +593,7 @@ int gcnx_segment_pool_bwd(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* 
                           int32_t n, int32_t b, int32_t f, int mode, const int32_t* argmax, const float* y,
                           int64_t ldy, float* db) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "global pool bwd");
   GCNX_REQUIRE(ctx, n >= 0 && b >= 0 && f >= 0, "gcnx_segment_pool_bwd: negative size");
   GCNX_REQUIRE(ctx, mode >= GCNX_POOL_SUM && mode <= GCNX_POOL_MAX, "gcnx_segment_pool_bwd: unknown mode %d", mode);
   if (f == 0) return GCNX_OK;
@@ -649,6 +651,7 @@ int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, con
 int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t b, int32_t c, float denom,
                      float* probs, float* loss_acc, float* dlogits, int cce_mode) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "softmax + CCE");
   GCNX_REQUIRE(ctx, b >= 0 && c >= 1, "gcnx_softmax_cce: bad size b=%d c=%d", b, c);
   if (b == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, logits && y && probs && loss_acc, "gcnx_softmax_cce: NULL pointer");
@@ -662,6 +665,7 @@ int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t
 
 int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "SGD update");
   GCNX_REQUIRE(ctx, n >= 0, "gcnx_sgd: negative size");
   if (n == 0) return GCNX_OK;
   GCNX_REQUIRE(ctx, params && grads, "gcnx_sgd: NULL pointer");

@@ -4,6 +4,7 @@
 #include <utility>
 
 #include "common.h"
+#include <dlfcn.h>
 #include <cstring>
 
 thread_local std::string gcnx_tls_error;
@@ -93,6 +94,17 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   if (const char* k = getenv("GCNX_SPMM_SG")) ctx->knob_spmm_sg = atoi(k);
   if (const char* k = getenv("GCNX_GEMM_STREAM")) ctx->knob_gemm_stream = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_CONC")) ctx->knob_spmm_conc = atoi(k);
+  if (const char* k = getenv("GCNX_ROCTX")) {
+    if (atoi(k)) {                        // tracing aid: named ranges around the kernel classes (rocprofv3 --marker-trace)
+      void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) {
+        ctx->roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        ctx->roctx_pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!ctx->roctx_push || !ctx->roctx_pop) ctx->roctx_push = nullptr, ctx->roctx_pop = nullptr;
+      }
+    }
+  }
   if (ctx->arch.rfind("gfx950", 0) != 0) {
     int rc = gcnx_fail(nullptr, GCNX_ERR_UNSUPPORTED, "gcnx_ctx_create: device %d is %s; libgcnx is built for gfx950 only",
                        device, ctx->arch.c_str());

@@ -1268,6 +1268,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
                          int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
                          const gcnx_spmm_plan* plan, uint32_t* relu_bits) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation (GCNConv / GeneralConv SpMM)");
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr: negative size");
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_spmm_csr: activation %d not supported here", act);
   if (n == 0 || f == 0) return GCNX_OK;
@@ -1397,6 +1398,7 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
                            int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode,
                            const gcnx_spmm_plan* plan, const void* y_bits) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation bwd (pool' folded)");
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0 && b >= 0, "gcnx_spmm_csr_pool_bwd: negative size");
   GCNX_REQUIRE(ctx, mode == GCNX_POOL_SUM || mode == GCNX_POOL_AVG,
                "gcnx_spmm_csr_pool_bwd: pool mode %d has no folded form (use gcnx_segment_pool_bwd + gcnx_spmm_csr)", mode);

@@ -154,6 +154,7 @@ extern "C" {
 int gcnx_spmm_csr_bf16(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const uint16_t* h,
                        int64_t ldh, const float* bias, uint16_t* out, int64_t ldo, int32_t n, int32_t f, int act) {
   GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation (bf16 features)");
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr_bf16: negative size");
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_spmm_csr_bf16: activation %d not supported here", act);
   if (n == 0 || f == 0) return GCNX_OK;
