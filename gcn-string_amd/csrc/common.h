@@ -76,7 +76,8 @@ extern "C" int gcnx_aux_join(gcnx_ctx* ctx);
 // (no message) when the shape is not one it is built for.
 int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose, float* c,
                         int64_t ldc, int64_t m, int prec, const float* bias, const float* alpha, int act, const float* mask,
-                        int64_t ldmask, int accumulate, float* colsum_out /* column sums of c, or NULL */);
+                        int64_t ldmask, int accumulate, float* colsum_out /* column sums of c, or NULL */,
+                        const void* mask_bits = nullptr /* bit image read instead of mask */, void* bits_out = nullptr /* written */);
 // gemm_stream.hip: X^T dH for fi = fo = 256 on the streaming bf16 kernel: writes [slices][256 * 256] partial products to
 // `slabs` (room for max_slices of them) and returns the number of slices; 0 = shape not handled, < 0 = launch error.
 int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* slabs, int64_t n,

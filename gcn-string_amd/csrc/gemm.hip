@@ -976,6 +976,44 @@ int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const 
   return GCNX_OK;
 }
 
+// The ReLU mask of a Dense layer as a BIT IMAGE between its forward and its backward product (large batches on the
+// streaming bf16 kernel): gcnx_gemm_relu_bits is gcnx_gemm(act = RELU) that also writes [out > 0] -- 32 bytes per row, in
+// the kernel's lane order (private to the pair) -- and gcnx_gemm_dx_bits masks dX with it instead of reading the saved
+// activation again: 1 GB -> 32 MB per step at config 3.  GCNX_ERR_UNSUPPORTED (no launch) when the shape / precision is
+// not the streaming kernel's one-plane form: use gcnx_gemm / gcnx_gemm_dx then.
+int gcnx_gemm_relu_bits(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias, float* out, int64_t ldo,
+                        int64_t n, int32_t fi, int32_t fo, int prec, void* bits) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (X W)");
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_relu_bits: negative size");
+  GCNX_REQUIRE(ctx, x && w && out && bits, "gcnx_gemm_relu_bits: NULL pointer");
+  GCNX_REQUIRE(ctx, ldx >= fi && ldo >= fo, "gcnx_gemm_relu_bits: leading dimension too small");
+  int rc = GCNX_ERR_UNSUPPORTED;
+  if (prec == GCNX_PREC_BF16 && fo == 256 && al16(out) && ldo % 4 == 0)
+    rc = gcnx_gemm_stream_nn(ctx, x, ldx, w, fi, fo, 1, out, ldo, n, prec, bias, nullptr, GCNX_ACT_RELU, nullptr, 0, 0, nullptr, nullptr, bits);
+  if (rc == GCNX_ERR_UNSUPPORTED)
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm_relu_bits: the bit image is written by the streaming bf16 kernel only "
+                     "(GCNX_PREC_BF16, fi = fo = 256, n >= 32768, aligned operands): use gcnx_gemm");
+  return rc;
+}
+
+int gcnx_gemm_dx_bits(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx, int64_t lddx, int64_t n,
+                      int32_t fi, int32_t fo, int prec, const void* mask_bits, float* db) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (dX)");
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dx_bits: negative size");
+  GCNX_REQUIRE(ctx, dh && w && dx && mask_bits, "gcnx_gemm_dx_bits: NULL pointer");
+  GCNX_REQUIRE(ctx, lddh >= fo && lddx >= fi, "gcnx_gemm_dx_bits: leading dimension too small");
+  int rc = GCNX_ERR_UNSUPPORTED;
+  if (prec == GCNX_PREC_BF16 && fi == 256 && al16(dx) && lddx % 4 == 0 && (!db || al16(db)))
+    rc = gcnx_gemm_stream_nn(ctx, dh, lddh, w, fi, fo, 0, dx, lddx, n, prec, nullptr, nullptr, GCNX_ACT_NONE, nullptr, 0, 0, db, mask_bits,
+                             nullptr);
+  if (rc == GCNX_ERR_UNSUPPORTED)
+    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm_dx_bits: the bit image is read by the streaming bf16 kernel only "
+                     "(GCNX_PREC_BF16, fi = fo = 256, n >= 32768, aligned operands): use gcnx_gemm_dx with the saved activation");
+  return rc;
+}
+
 int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx, int64_t lddx, int64_t n,
                  int32_t fi, int32_t fo, int prec, int accumulate, const float* y_mask, int64_t ldy, float* db) {
   GCNX_CHECK_CTX(ctx);

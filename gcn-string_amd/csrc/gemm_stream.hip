@@ -39,7 +39,11 @@ constexpr int kSRows = 32;                 // rows per wave
 constexpr int kSWaves = 8;                 // waves per workgroup
 // K steps of activation loads in flight per wave: 4 (128 KiB per CU); with a fused ReLU mask the mask pieces ride in
 // the same ring, and two steps of activations + mask (96 KiB per CU) are what fits 256 registers without spills.
-template <bool MASK> struct StreamDepth { static constexpr int value = MASK ? 2 : 4; };
+// MASK: 0 none, 1 the saved fp32 activation [M, ldmask] (its > 0 bits are collected on the way), 2 a BIT IMAGE of it
+// written by the forward launch that produced the activation (ep.bits_out): 32 bytes per row instead of 1 KiB -- one
+// 64-bit word per lane and row block, in this kernel's own lane order (word (row, q) = the nibbles of column tiles
+// 0 .. 15 for the lane's 4-column group q), so it is private to the two launches.  bf16 shape only (RT = 1, CW = 256).
+template <int MASK> struct StreamDepth { static constexpr int value = MASK == 1 ? 2 : 4; };
 
 struct StreamEpi {
   const float* bias;      // [ncol] or null
@@ -49,6 +53,8 @@ struct StreamEpi {
   int act;
   int accumulate;
   float* colpart;         // [pairs, ncol] column sums of what each workgroup wrote (BiasAddGrad partials) or null
+  const unsigned long long* mbits_in;   // MASK == 2: the bit image [M][4]
+  unsigned long long* bits_out;         // forward: write the bit image of (output > 0) here (RT == 1 only) or null
 };
 
 // Weight operand -> bf16 planes in MFMA-fragment order.  Element (col, k) of plane p of column half h lives at
@@ -97,7 +103,7 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, sbf16x8
 // hipcc from re-serialising it): the weight fragments of block b + 1 are read from LDS and a quarter of the NEXT K
 // step's activations is converted fp32 -> bf16 (hi, lo) while the MFMAs of block b issue; the activation loads that
 // replace the converted ring slot go out at the end of the step.
-template <int NP, int CW, int RT, int KSTEPS, bool MASK>
+template <int NP, int CW, int RT, int KSTEPS, int MASK>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __restrict__ a, int64_t lda, const __bf16* __restrict__ wimg,
                                                              float* __restrict__ c, int64_t ldc, int64_t M, int ncol, StreamEpi ep,
                                                              int n_rb, int halves) {
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   constexpr int BLOCK = ROWS * kSWaves;                  // rows per workgroup step
   constexpr int IMG = NP * KSTEPS * CW * 32;             // bf16 elements of the LDS image
   static_assert(KSTEPS % kSDepth == 0 && NB % NF == 0 && RT * CT == 16, "pipeline shape");
+  static_assert(MASK != 2 || RT == 1, "the bit image has one word per lane and row block");
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   float* lbias = reinterpret_cast<float*>(lds + IMG);    // [CW] bias, [CW] alpha
   float* wsum = lbias + 2 * CW;                          // [waves][CW] column sums of the rows each wave wrote (ep.colpart)
@@ -152,11 +159,22 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   const __amdgpu_buffer_rsrc_t ars =
       __builtin_amdgcn_make_buffer_rsrc((void*)a, (short)0, (GCNX_STREAM_ABL & 1) ? 0 : (int)((uint64_t)M * (uint64_t)lda * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(MASK ? ep.mask : a), (short)0, MASK ? (int)((uint64_t)M * (uint64_t)ep.ldmask * 4u) : 0, 0x00020000);
+      (void*)(MASK == 1 ? (const void*)ep.mask : MASK == 2 ? (const void*)ep.mbits_in : (const void*)a), (short)0,
+      MASK == 1 ? (int)((uint64_t)M * (uint64_t)ep.ldmask * 4u) : MASK == 2 ? (int)((uint64_t)M * 32u) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs =
       __builtin_amdgcn_make_buffer_rsrc((void*)c, (short)0, (GCNX_STREAM_ABL & 2) ? 0 : (int)((uint64_t)M * (uint64_t)ldc * 4u), 0x00020000);
   const unsigned lda4 = (unsigned)lda * 4u, ldm4 = (unsigned)ep.ldmask * 4u, ldc4 = (unsigned)ldc * 4u;
   const int wrow = wave * ROWS + rl;                     // this lane's row inside a block (tile 0; tile t = + 16 t)
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(ep.bits_out ? (void*)ep.bits_out : (void*)c), (short)0, ep.bits_out ? (int)((uint64_t)M * 32u) : 0, 0x00020000);
+  // MASK == 2: the 64 mask bits of this lane for row block `un_` (rows past M read zeros)
+  auto load_bits = [&](int un_) -> unsigned long long {
+    const int64_t row_ = (int64_t)(pair + un_ * npairs) * BLOCK + wrow;
+    const unsigned off_ = (un_ < nunits && row_ < M) ? (unsigned)row_ * 32u + (unsigned)q * 8u : 0xFFFFFFE0u;
+    typedef unsigned int su32x2 __attribute__((ext_vector_type(2)));
+    const su32x2 w_ = __builtin_bit_cast(su32x2, __builtin_amdgcn_raw_buffer_load_b64(mrs, off_, 0, 0));
+    return (unsigned long long)w_[0] | ((unsigned long long)w_[1] << 32);
+  };
 
   float4 pf[kSDepth][NF];                                // activation ring: [step % depth][tile * 2 + (0: k 0..3, 1: k 4..7)]
   float4 mk[kSDepth][2];                                 // MASK: the mask pieces that ride with the same step
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
       pf[SLOT][tt * 2] = sbuf4(ars, off_);                                                                         \
       pf[SLOT][tt * 2 + 1] = sbuf4(ars, off_ + 16u);                                                               \
     }                                                                                                              \
-    if (MASK) {                                                                                                    \
+    if (MASK == 1) {                                                                                               \
       _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                              \
         const int piece_ = ks_ * 2 + m;                   /* 0 .. 15 = tile * CT + column tile */                  \
         const int tt = piece_ / CT, ct = piece_ % CT;                                                              \
@@ -226,13 +244,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   unsigned wofs = (unsigned)lane * 8u;
 #pragma unroll
   for (int f = 0; f < NF; ++f) GS_CONVERT(0, f, xh[0], xl[0])
-  if (MASK) {
+  if (MASK == 1) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const float4 v = mk[0][m];
       mbits |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (m * 4);
     }
   }
+  unsigned long long mnext64 = 0;                        // MASK == 2: the next unit's word, in flight during this unit
+  if (MASK == 2) mbits = load_bits(0);
   GS_ISSUE(kSDepth, 0)
   GS_WREAD(0, 0, wh[0], wl[0])
 
@@ -241,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
     // The image never changes, so without this the compiler hoists ALL fragment reads out of the unit loop -- up to
     // 128 KiB of "loop-invariant" registers, i.e. spills.  An opaque lane offset per unit keeps them per block.
     asm volatile("" : "+v"(wofs));
+    if (MASK == 2) mnext64 = load_bits(t0 / KSTEPS + 1);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int xc = ks & 1, xn = xc ^ 1;                // activation fragment sets: current / next step
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
           const int f = b / (NB / NF);
           GS_CONVERT(nslot, f, xh[xn], xl[xn])
         }
-        if (MASK && b == NB - 1) {
+        if (MASK == 1 && b == NB - 1) {
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const float4 v = mk[nslot][m];
@@ -291,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
       }
     }
     // epilogue of the unit: lane (rl, q) holds columns c0 + 16 ct + 4 q .. + 3 of rows rb * BLOCK + wave * ROWS + 16 tt + rl
+    unsigned long long obits = 0;                        // forward with ep.bits_out: (output > 0), nibble ct
 #pragma unroll
     for (int tt = 0; tt < RT; ++tt) {
       const int64_t row = rb * BLOCK + wrow + tt * 16;
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
           v.x = v.x > 0.f ? v.x : al.x * v.x; v.y = v.y > 0.f ? v.y : al.y * v.y;
           v.z = v.z > 0.f ? v.z : al.z * v.z; v.w = v.w > 0.f ? v.w : al.w * v.w;
         }
-        if (MASK) {
+        if (MASK != 0) {
           const unsigned b = (unsigned)(mbits >> ((tt * CT + ct) * 4)) & 15u;
           v.x = (b & 1u) ? v.x : 0.f; v.y = (b & 2u) ? v.y : 0.f; v.z = (b & 4u) ? v.z : 0.f; v.w = (b & 8u) ? v.w : 0.f;
         }
@@ -315,6 +337,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
         // (a load or store inside a branch makes hipcc drain the whole prefetch ring with vmcnt(0))
         const unsigned off = (row < M && col < ncol) ? (unsigned)row * ldc4 + (unsigned)col * 4u : 0xFFFFFFE0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(si32x4, sf32x4{v.x, v.y, v.z, v.w}), crs, off, 0, GCNX_STREAM_STORE_AUX);
+        if (RT == 1 && MASK == 0)
+          obits |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (ct * 4);
         if (ep.colpart) {
           // column sums of what was written, without reading it back: the 16 rows of the tile are summed across the
           // lanes rl = 0 .. 15 (fixed tree), lane rl = 0 adds the result to its wave's LDS row -- the same lane in
@@ -333,7 +357,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
         }
       }
     }
-    mbits = mnext;                                       // the first two mask pieces of the next unit are already in
+    if (RT == 1 && MASK == 0 && ep.bits_out) {           // (uniform) one 8-byte store per lane: 32 bytes per row
+      typedef unsigned int su32x2 __attribute__((ext_vector_type(2)));
+      const int64_t row = rb * BLOCK + wrow;
+      const su32x2 w2 = {(unsigned)obits, (unsigned)(obits >> 32)};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) int, w2), brs,
+                                            row < M ? (unsigned)row * 32u + (unsigned)q * 8u : 0xFFFFFFE0u, 0, 0);
+    }
+    if (MASK == 2) mbits = mnext64;
+    else mbits = mnext;                                  // the first two mask pieces of the next unit are already in
     mnext = 0;
   }
   if (ep.colpart) {                                      // the workgroup's column sums: its 8 waves in a fixed order
@@ -359,10 +391,13 @@ int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img,
   static_assert(lds_bytes <= 160 * 1024, "weight image must fit the CU's LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, false>),
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, true>),
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if constexpr (RT == 1)
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
   const int n_rb = gcnx_cdiv(m, 16 * RT * kSWaves);
@@ -370,11 +405,16 @@ int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img,
   if (halves == 2) grid &= ~1;
   const int npairs = grid / halves;
   if (npairs > n_rb) grid = n_rb * halves;
-  if (ep.mask)
-    hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, true>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
+  if (ep.mbits_in) {
+    if constexpr (RT == 1)
+      hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, 2>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
+                         ldc, m, ncol, ep, n_rb, halves);
+    else return GCNX_ERR_UNSUPPORTED;
+  } else if (ep.mask)
+    hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, 1>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
                        ldc, m, ncol, ep, n_rb, halves);
   else
-    hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, false>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
+    hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, 0>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
                        ldc, m, ncol, ep, n_rb, halves);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
@@ -386,9 +426,13 @@ int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img,
 // setting an error message) when the shape is not one it is built for; the caller then takes the tiled kernel.
 int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float* w, int fi, int fo, int transpose, float* c,
                         int64_t ldc, int64_t m, int prec, const float* bias, const float* alpha, int act, const float* mask,
-                        int64_t ldmask, int accumulate, float* colsum_out) {
+                        int64_t ldmask, int accumulate, float* colsum_out, const void* mask_bits, void* bits_out) {
   const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
   const int np = prec == GCNX_PREC_BF16X3 ? 2 : 1;
+  // the bit image of a ReLU output (bits_out: written; mask_bits: read instead of `mask`): plain bf16 shape only
+  if ((mask_bits || bits_out) && (np != 1 || (reinterpret_cast<uintptr_t>(mask_bits) & 7) || (reinterpret_cast<uintptr_t>(bits_out) & 7) ||
+                                  (uint64_t)m * 32u >= 0xFFFFFF00ull))
+    return GCNX_ERR_UNSUPPORTED;
   if (accumulate) return GCNX_ERR_UNSUPPORTED;   // (a read-modify-write epilogue would drain the prefetch ring: tiled kernel)
   if (ctx->knob_gemm_stream == 0) return GCNX_ERR_UNSUPPORTED;
   const bool shape_ok = K == 256 && ncol % 4 == 0 && ncol <= 256 && ncol >= 64 && m >= 32 * 1024 &&
@@ -416,7 +460,8 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
   hipLaunchKernelGGL(stream_wprep_kernel, dim3(gcnx_cdiv((long long)img_elems, 256)), dim3(256), 0, ctx->stream, w, fi, fo, transpose,
                      np, cw, ksteps, ncol, img);
   GCNX_LAUNCH_OK(ctx);
-  const StreamEpi ep{bias, alpha, mask, ldmask, act, accumulate, colsum_out ? (float*)ctx->ws : nullptr};
+  const StreamEpi ep{bias, alpha, mask_bits ? nullptr : mask, ldmask, act, accumulate, colsum_out ? (float*)ctx->ws : nullptr,
+                     (const unsigned long long*)mask_bits, (unsigned long long*)bits_out};
   if (colsum_out)   // workgroups without row blocks (short inputs) do not run: their partial rows must read as zero
     GCNX_HIP(ctx, hipMemsetAsync(ctx->ws, 0, (size_t)prow * ncol * sizeof(float), ctx->stream));
   rc = np == 2 ? launch_stream<2, 128, 2, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves)

@@ -77,6 +77,8 @@ SIGNATURES = {
     "gcnx_act_bias_grad": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp],
     "gcnx_gemm_dw": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int],
     "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],
+    "gcnx_gemm_relu_bits": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp],
+    "gcnx_gemm_dx_bits": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp, _vp],
     "gcnx_dense_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp],
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
     "gcnx_spmm_csr_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],

@@ -422,6 +422,19 @@ def gemm(ctx, x, w, bias, out, act=None, prec="f32", alpha=None):
     return out
 
 
+def gemm_relu_bits(ctx, x, w, bias, out, bits, prec="bf16"):
+    """out = relu(x w + bias) and the bit image of [out > 0] for gemm_dx(mask_bits=...) (gcnx_gemm_relu_bits).  Returns
+    False -- nothing launched -- when the streaming bf16 kernel does not serve the shape: call gemm(act="relu") then."""
+    n, fi = x.shape
+    fo = w.shape[1]
+    assert w.shape[0] == fi and out.shape == (n, fo) and bits.nbytes >= n * 32
+    rc = ctx.lib.gcnx_gemm_relu_bits(ctx.h, _p(x), x.ld, _p(w), _p(bias), _p(out), out.ld, n, fi, fo, L.PRECS[prec], bits.ptr)
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
 def spmm(ctx, a, h, bias, out, act=None):
     n, f = h.shape
     assert a.n == n and out.shape == (n, f)
@@ -627,10 +640,16 @@ def gemm_dw(ctx, x, dh, dw, prec="f32"):
     return dw
 
 
-def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None):
+def gemm_dx(ctx, dh, w, dx, prec="f32", accumulate=False, y_mask=None, db=None, mask_bits=None):
+    """dx = dh w^T (* [y_mask > 0], db = column sums).  mask_bits: the bit image gemm_relu_bits wrote for the same
+    activation -- read instead of y_mask (gcnx_gemm_dx_bits)."""
     n, fo = dh.shape
     fi = w.shape[0]
     assert w.shape[1] == fo and dx.shape == (n, fi)
+    if mask_bits is not None:
+        assert not accumulate
+        ctx._ck(ctx.lib.gcnx_gemm_dx_bits(ctx.h, _p(dh), dh.ld, _p(w), _p(dx), dx.ld, n, fi, fo, L.PRECS[prec], mask_bits.ptr, _p(db)))
+        return dx
     ctx._ck(ctx.lib.gcnx_gemm_dx(ctx.h, _p(dh), dh.ld, _p(w), _p(dx), dx.ld, n, fi, fo, L.PRECS[prec],
                                  1 if accumulate else 0, _p(y_mask), y_mask.ld if y_mask is not None else 0, _p(db)))
     return dx

@@ -259,7 +259,15 @@ class GCN2(_GraphRunner):
                 # input needs no gradient, so with S1 = A X kept dW1 = S1^T dZ1 and the backward pass has no aggregation
                 # for this layer (one of the step's four, 575 us of 4.7 ms at config 3)
                 D.spmm(ctx, batch.a, batch.x, None, bufs["s1"])
-                D.gemm(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], act="relu", prec=prec)
+                # with a backward pass to follow and the streaming bf16 kernel serving the product: [Y1 > 0] also as a bit
+                # image, which the dX launch of the backward pass reads instead of Y1 (1 GB -> 32 MB at config 3)
+                bufs["y1bits_ok"] = False
+                if with_loss == "grads" and prec == "bf16" and self.hidden == 256 and batch.n >= 32768:
+                    if bufs.get("y1bits") is None or bufs["y1bits"].size < 8 * batch.n:
+                        bufs["y1bits"] = ctx.empty(8 * batch.n, np.int32)
+                    bufs["y1bits_ok"] = D.gemm_relu_bits(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], bufs["y1bits"], prec=prec)
+                if not bufs["y1bits_ok"]:
+                    D.gemm(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], act="relu", prec=prec)
             else:
                 D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
                 D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
@@ -358,7 +366,8 @@ class GCN2(_GraphRunner):
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
             # (folded: db2 came out of the head -- from the pool's own count of positive entries)
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
-        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"])   # dZ1, db1
+        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"],
+                  mask_bits=bufs["y1bits"] if bufs.get("y1bits_ok") else None)                       # dZ1, db1
         xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
         D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                            # dW1 = X^T (A^T dZ1) or S1^T dZ1
         ctx.join()
