@@ -42,7 +42,7 @@ constexpr int kSWaves = 8;                 // waves per workgroup
 // MASK: 0 none, 1 the saved fp32 activation [M, ldmask] (its > 0 bits are collected on the way), 2 a BIT IMAGE of it
 // written by the forward launch that produced the activation (ep.bits_out): 32 bytes per row instead of 1 KiB -- one
 // 64-bit word per lane and row block, in this kernel's own lane order (word (row, q) = the nibbles of column tiles
-// 0 .. 15 for the lane's 4-column group q), so it is private to the two launches.  bf16 shape only (RT = 1, CW = 256).
+// 0 .. 15 for the lane's 4-column group q), so it is private to the two launches -- which must have the same shape.
 template <int MASK> struct StreamDepth { static constexpr int value = MASK == 1 ? 2 : 4; };
 
 struct StreamEpi {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   constexpr int BLOCK = ROWS * kSWaves;                  // rows per workgroup step
   constexpr int IMG = NP * KSTEPS * CW * 32;             // bf16 elements of the LDS image
   static_assert(KSTEPS % kSDepth == 0 && NB % NF == 0 && RT * CT == 16, "pipeline shape");
-  static_assert(MASK != 2 || RT == 1, "the bit image has one word per lane and row block");
+
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   float* lbias = reinterpret_cast<float*>(lds + IMG);    // [CW] bias, [CW] alpha
   float* wsum = lbias + 2 * CW;                          // [waves][CW] column sums of the rows each wave wrote (ep.colpart)
@@ -160,17 +160,20 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
       __builtin_amdgcn_make_buffer_rsrc((void*)a, (short)0, (GCNX_STREAM_ABL & 1) ? 0 : (int)((uint64_t)M * (uint64_t)lda * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(MASK == 1 ? (const void*)ep.mask : MASK == 2 ? (const void*)ep.mbits_in : (const void*)a), (short)0,
-      MASK == 1 ? (int)((uint64_t)M * (uint64_t)ep.ldmask * 4u) : MASK == 2 ? (int)((uint64_t)M * 32u) : 0, 0x00020000);
+      MASK == 1 ? (int)((uint64_t)M * (uint64_t)ep.ldmask * 4u) : MASK == 2 ? (int)((uint64_t)M * (uint64_t)halves * 32u) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs =
       __builtin_amdgcn_make_buffer_rsrc((void*)c, (short)0, (GCNX_STREAM_ABL & 2) ? 0 : (int)((uint64_t)M * (uint64_t)ldc * 4u), 0x00020000);
   const unsigned lda4 = (unsigned)lda * 4u, ldm4 = (unsigned)ep.ldmask * 4u, ldc4 = (unsigned)ldc * 4u;
   const int wrow = wave * ROWS + rl;                     // this lane's row inside a block (tile 0; tile t = + 16 t)
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(ep.bits_out ? (void*)ep.bits_out : (void*)c), (short)0, ep.bits_out ? (int)((uint64_t)M * 32u) : 0, 0x00020000);
+      (void*)(ep.bits_out ? (void*)ep.bits_out : (void*)c), (short)0, ep.bits_out ? (int)((uint64_t)M * (uint64_t)halves * 32u) : 0, 0x00020000);
+  // The image: word ((row * halves + half) * 4 + q) = the 16 nibbles (tile tt, column tile ct) of the lane whose FIRST row
+  // (tt = 0) is `row` -- with two row tiles per wave only every other 16-row group has words, the array is indexed by
+  // the row all the same (halves * 32 bytes per row).
   // MASK == 2: the 64 mask bits of this lane for row block `un_` (rows past M read zeros)
   auto load_bits = [&](int un_) -> unsigned long long {
     const int64_t row_ = (int64_t)(pair + un_ * npairs) * BLOCK + wrow;
-    const unsigned off_ = (un_ < nunits && row_ < M) ? (unsigned)row_ * 32u + (unsigned)q * 8u : 0xFFFFFFE0u;
+    const unsigned off_ = (un_ < nunits && row_ < M) ? ((unsigned)row_ * (unsigned)halves + (unsigned)half) * 32u + (unsigned)q * 8u : 0xFFFFFFE0u;
     typedef unsigned int su32x2 __attribute__((ext_vector_type(2)));
     const su32x2 w_ = __builtin_bit_cast(su32x2, __builtin_amdgcn_raw_buffer_load_b64(mrs, off_, 0, 0));
     return (unsigned long long)w_[0] | ((unsigned long long)w_[1] << 32);
@@ -337,8 +340,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
         // (a load or store inside a branch makes hipcc drain the whole prefetch ring with vmcnt(0))
         const unsigned off = (row < M && col < ncol) ? (unsigned)row * ldc4 + (unsigned)col * 4u : 0xFFFFFFE0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(si32x4, sf32x4{v.x, v.y, v.z, v.w}), crs, off, 0, GCNX_STREAM_STORE_AUX);
-        if (RT == 1 && MASK == 0)
-          obits |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (ct * 4);
+        if (MASK == 0)
+          obits |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << ((tt * CT + ct) * 4);
         if (ep.colpart) {
           // column sums of what was written, without reading it back: the 16 rows of the tile are summed across the
           // lanes rl = 0 .. 15 (fixed tree), lane rl = 0 adds the result to its wave's LDS row -- the same lane in
@@ -357,12 +360,12 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
         }
       }
     }
-    if (RT == 1 && MASK == 0 && ep.bits_out) {           // (uniform) one 8-byte store per lane: 32 bytes per row
+    if (MASK == 0 && ep.bits_out) {                      // (uniform) one 8-byte store per lane and row block
       typedef unsigned int su32x2 __attribute__((ext_vector_type(2)));
       const int64_t row = rb * BLOCK + wrow;
       const su32x2 w2 = {(unsigned)obits, (unsigned)(obits >> 32)};
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) int, w2), brs,
-                                            row < M ? (unsigned)row * 32u + (unsigned)q * 8u : 0xFFFFFFE0u, 0, 0);
+                                            row < M ? ((unsigned)row * (unsigned)halves + (unsigned)half) * 32u + (unsigned)q * 8u : 0xFFFFFFE0u, 0, 0);
     }
     if (MASK == 2) mbits = mnext64;
     else mbits = mnext;                                  // the first two mask pieces of the next unit are already in
@@ -395,9 +398,8 @@ int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if constexpr (RT == 1)
-      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NP, CW, RT, KSTEPS, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
   const int n_rb = gcnx_cdiv(m, 16 * RT * kSWaves);
@@ -405,12 +407,10 @@ int launch_stream(gcnx_ctx* ctx, const float* a, int64_t lda, const __bf16* img,
   if (halves == 2) grid &= ~1;
   const int npairs = grid / halves;
   if (npairs > n_rb) grid = n_rb * halves;
-  if (ep.mbits_in) {
-    if constexpr (RT == 1)
-      hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, 2>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
-                         ldc, m, ncol, ep, n_rb, halves);
-    else return GCNX_ERR_UNSUPPORTED;
-  } else if (ep.mask)
+  if (ep.mbits_in)
+    hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, 2>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
+                       ldc, m, ncol, ep, n_rb, halves);
+  else if (ep.mask)
     hipLaunchKernelGGL((gemm_stream_kernel<NP, CW, RT, KSTEPS, 1>), dim3(grid), dim3(512), lds_bytes, ctx->stream, a, lda, img, c,
                        ldc, m, ncol, ep, n_rb, halves);
   else
@@ -429,9 +429,10 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
                         int64_t ldmask, int accumulate, float* colsum_out, const void* mask_bits, void* bits_out) {
   const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
   const int np = prec == GCNX_PREC_BF16X3 ? 2 : 1;
-  // the bit image of a ReLU output (bits_out: written; mask_bits: read instead of `mask`): plain bf16 shape only
-  if ((mask_bits || bits_out) && (np != 1 || (reinterpret_cast<uintptr_t>(mask_bits) & 7) || (reinterpret_cast<uintptr_t>(bits_out) & 7) ||
-                                  (uint64_t)m * 32u >= 0xFFFFFF00ull))
+  // the bit image of a ReLU output (bits_out: written; mask_bits: read instead of `mask`): full-width outputs only (both
+  // launches of a pair must split the columns the same way), 64 bytes per row reserved
+  if ((mask_bits || bits_out) && (ncol != 256 || (reinterpret_cast<uintptr_t>(mask_bits) & 7) || (reinterpret_cast<uintptr_t>(bits_out) & 7) ||
+                                  (uint64_t)m * 64u >= 0xFFFFFF00ull))
     return GCNX_ERR_UNSUPPORTED;
   if (accumulate) return GCNX_ERR_UNSUPPORTED;   // (a read-modify-write epilogue would drain the prefetch ring: tiled kernel)
   if (ctx->knob_gemm_stream == 0) return GCNX_ERR_UNSUPPORTED;

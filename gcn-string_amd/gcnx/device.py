@@ -427,7 +427,7 @@ def gemm_relu_bits(ctx, x, w, bias, out, bits, prec="bf16"):
     False -- nothing launched -- when the streaming bf16 kernel does not serve the shape: call gemm(act="relu") then."""
     n, fi = x.shape
     fo = w.shape[1]
-    assert w.shape[0] == fi and out.shape == (n, fo) and bits.nbytes >= n * 32
+    assert w.shape[0] == fi and out.shape == (n, fo) and bits.nbytes >= n * 64
     rc = ctx.lib.gcnx_gemm_relu_bits(ctx.h, _p(x), x.ld, _p(w), _p(bias), _p(out), out.ld, n, fi, fo, L.PRECS[prec], bits.ptr)
     if rc == L.ERR_UNSUPPORTED:
         return False

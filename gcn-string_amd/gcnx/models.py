@@ -262,9 +262,9 @@ class GCN2(_GraphRunner):
                 # with a backward pass to follow and the streaming bf16 kernel serving the product: [Y1 > 0] also as a bit
                 # image, which the dX launch of the backward pass reads instead of Y1 (1 GB -> 32 MB at config 3)
                 bufs["y1bits_ok"] = False
-                if with_loss == "grads" and prec == "bf16" and self.hidden == 256 and batch.n >= 32768:
-                    if bufs.get("y1bits") is None or bufs["y1bits"].size < 8 * batch.n:
-                        bufs["y1bits"] = ctx.empty(8 * batch.n, np.int32)
+                if with_loss == "grads" and prec in ("bf16", "bf16x3") and self.hidden == 256 and batch.n >= 32768:
+                    if bufs.get("y1bits") is None or bufs["y1bits"].size < 16 * batch.n:
+                        bufs["y1bits"] = ctx.empty(16 * batch.n, np.int32)
                     bufs["y1bits_ok"] = D.gemm_relu_bits(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], bufs["y1bits"], prec=prec)
                 if not bufs["y1bits_ok"]:
                     D.gemm(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], act="relu", prec=prec)

@@ -244,10 +244,10 @@ GCNX_API int gcnx_act_bias_grad(gcnx_ctx* ctx, const float* dy, int64_t lddy, co
 GCNX_API int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh,
                  float* dw, int64_t n, int32_t fi, int32_t fo, int prec);
 /* The ReLU mask of a Dense / GCNConv kernel product as a bit image between the forward and the backward product of
- * large batches: gcnx_gemm_relu_bits = gcnx_gemm(act = GCNX_ACT_RELU) that also writes [out > 0] to `bits` (n * 32
- * bytes, 8-byte aligned; layout private to the pair), gcnx_gemm_dx_bits = gcnx_gemm_dx masked by that image instead of
+ * large batches: gcnx_gemm_relu_bits = gcnx_gemm(act = GCNX_ACT_RELU) that also writes [out > 0] to `bits` (n * 64
+ * bytes reserved, 8-byte aligned; layout private to the pair, which must use the same precision), gcnx_gemm_dx_bits = gcnx_gemm_dx masked by that image instead of
  * the saved activation (ReluGrad after MatMul grad, gcn.py:337) -- 32 bytes per row read where the activation is 1 KiB.
- * Served by the streaming bf16 kernel only (GCNX_PREC_BF16, fi = fo = 256, n >= 32768): GCNX_ERR_UNSUPPORTED
+ * Served by the streaming bf16 kernels only (GCNX_PREC_BF16 / BF16X3, fi = fo = 256, n >= 32768): GCNX_ERR_UNSUPPORTED
  * otherwise, and nothing is launched. */
 GCNX_API int gcnx_gemm_relu_bits(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias, float* out,
                         int64_t ldo, int64_t n, int32_t fi, int32_t fo, int prec, void* bits);

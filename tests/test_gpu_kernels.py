@@ -675,8 +675,9 @@ def test_spmm_bf16_long_rows_and_refusals(ctx):
                 ctx.empty((0, 64), np.uint16), None, ctx.empty((0, 64), np.uint16))   # empty input: a no-op
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("n", [40000, 33001])
-def test_gemm_relu_bit_image_between_forward_and_dx(ctx, n):
+def test_gemm_relu_bit_image_between_forward_and_dx(ctx, n, prec):
     """gcnx_gemm_relu_bits / gcnx_gemm_dx_bits (streaming bf16 kernel): the forward product also writes [out > 0] as a bit
     image, the backward product masks dX with it -- both bit-identical to gcnx_gemm(act = relu) / gcnx_gemm_dx(y_mask) on
     the saved activation, db included; ragged last row block; shapes the kernel does not serve are refused (no launch)."""
@@ -687,20 +688,20 @@ def test_gemm_relu_bit_image_between_forward_and_dx(ctx, n):
     w2 = ctx.to_device((rng.standard_normal((256, 256)) / 16).astype(np.float32))
     dh = ctx.to_device(rng.standard_normal((n, 256), dtype=np.float32))
     y_ref, y_bits = ctx.empty((n, 256)), ctx.empty((n, 256))
-    bits = ctx.zeros(8 * n, np.int32)
-    D.gemm(ctx, x, w1, b1, y_ref, act="relu", prec="bf16")
-    assert D.gemm_relu_bits(ctx, x, w1, b1, y_bits, bits, prec="bf16")
+    bits = ctx.zeros(16 * n, np.int32)
+    D.gemm(ctx, x, w1, b1, y_ref, act="relu", prec=prec)
+    assert D.gemm_relu_bits(ctx, x, w1, b1, y_bits, bits, prec=prec)
     assert np.array_equal(y_ref.numpy(), y_bits.numpy())
     assert 0.3 < (y_ref.numpy() > 0).mean() < 0.7
     dx_ref, dx_bits, db_ref, db_bits = ctx.empty((n, 256)), ctx.empty((n, 256)), ctx.empty(256), ctx.empty(256)
-    D.gemm_dx(ctx, dh, w2, dx_ref, prec="bf16", y_mask=y_ref, db=db_ref)
-    D.gemm_dx(ctx, dh, w2, dx_bits, prec="bf16", db=db_bits, mask_bits=bits)
+    D.gemm_dx(ctx, dh, w2, dx_ref, prec=prec, y_mask=y_ref, db=db_ref)
+    D.gemm_dx(ctx, dh, w2, dx_bits, prec=prec, db=db_bits, mask_bits=bits)
     assert np.array_equal(dx_ref.numpy(), dx_bits.numpy()) and np.array_equal(db_ref.numpy(), db_bits.numpy())
     assert np.array_equal(dx_bits.numpy() != 0, (y_ref.numpy() > 0) & (dx_bits.numpy() != 0))      # zero wherever the mask is
-    # not served: fp32-grade split products, narrow outputs, short inputs -- refused without a launch
-    assert not D.gemm_relu_bits(ctx, x, w1, b1, y_bits, bits, prec="bf16x3")
+    # not served: fp32 products, short inputs -- refused without a launch
+    assert not D.gemm_relu_bits(ctx, x, w1, b1, y_bits, bits, prec="f32")
     small = ctx.to_device(rng.standard_normal((1000, 256), dtype=np.float32))
-    assert not D.gemm_relu_bits(ctx, small, w1, b1, ctx.empty((1000, 256)), bits, prec="bf16")
+    assert not D.gemm_relu_bits(ctx, small, w1, b1, ctx.empty((1000, 256)), bits, prec=prec)
 
 
 @pytest.mark.parametrize("mode", ["sum", "avg", "max"])
