@@ -498,7 +498,7 @@ int gcnx_pool_split(const gcnx_ctx* ctx, int32_t b, int32_t f, int mode, int hal
     nsplit = (half_wgs_per_cu * ctx->num_cus / 2 + base_wgs - 1) / base_wgs;
     if (nsplit < 2) nsplit = 2;
     if (nsplit > 16) nsplit = 16;
-    if (const char* e = getenv("GCNX_POOL_SPLIT")) { const int v = atoi(e); if (v >= 2 && v <= 16) nsplit = v; }   // tuning knob
+    if (ctx->knob_pool_split >= 2 && ctx->knob_pool_split <= 16) nsplit = ctx->knob_pool_split;   // tuning knob, read once at context creation
   }
   return nsplit;
 }

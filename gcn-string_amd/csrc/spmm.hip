@@ -550,27 +550,50 @@ __device__ __forceinline__ void tile_dma32(float* buf, const float* __restrict__
 // and THREADS = 1024 with all 160 KiB (one workgroup per CU; graphs up to kSoloCap32 rows).
 constexpr int kDuoLdsFloats = 20352;             // 81 408 B: two workgroups fit one CU's 160 KiB
 constexpr int kSoloLdsFloats = 40960;            // 160 KiB
-constexpr int kDuoCap32 = 604;                   // rows of a 32-column tile (+ zero row + bias + row pointers)
-constexpr int kSoloCap32 = 1236;
+constexpr int kDuoCap32 = 632;                   // rows of a 32-column tile (+ zero row + bias)
+constexpr int kSoloCap32 = 1276;
 template <int THREADS, int FT> struct DuoShape {
   static constexpr int LDSF = THREADS == 512 ? kDuoLdsFloats : kSoloLdsFloats;
-  static constexpr int CAP = (FT == 32 ? (THREADS == 512 ? kDuoCap32 : kSoloCap32) : ((LDSF - 2 * FT - 2) / (FT + 1)) & ~3);
+  static constexpr int CAP = (FT == 32 ? (THREADS == 512 ? kDuoCap32 : kSoloCap32) : ((LDSF / FT) - 2) & ~3);
 };
 
-#define GCNX_DSTEP4(J, MC, MV, BASE, BB)                                                                       \
-  if ((J) == 0 || __builtin_amdgcn_ballot_w64((BASE) + 4 * (J) < (BB)) != 0) {                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      const int off = quad_bcast<4, (J)>(MC[i]);                                                               \
-      f32x2 w2 = f32x2{1.f, 1.f};                                                                              \
-      if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[i]))); w2 = f32x2{w, w}; } \
-      _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                        \
-        const float4 hv = *reinterpret_cast<const float4*>(tb[j] + off);                                       \
-        if (WEIGHTED) {                                                                                        \
-          acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hv.x, hv.y}, acc[j][0]);                             \
-          acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hv.z, hv.w}, acc[j][1]);                             \
-        } else {                                                                                               \
-          acc[j][0] += f32x2{hv.x, hv.y};                                                                      \
-          acc[j][1] += f32x2{hv.z, hv.w};                                                                      \
+// Row order of the tile kernels (r3).  A graph's output rows are dealt to the quads in DEGREE order (longest first, ties
+// in row order; gcnx_spmm_plan binds it to a rowptr): the 16 rows of a wave then have about the same number of entries,
+// so the 4-entry steps a wave skips are the steps NO row of it needs (at mean degree 10 a wave of rows in natural order
+// nearly always holds one row of 13+ entries and walks all 16 slots: 37 % of the LDS reads fetched the zero row; and 29 %
+// of the waves held a row of more than 16 entries and stalled on its on-demand fetch in the middle of the reduction).
+// Record of position p of graph g (p = 0 .. ng - 1): the row's first CSR entry and (local row | degree << 16).
+struct __attribute__((aligned(8))) RowRec { int a; unsigned w; };
+
+// LDS byte address of a tile row: base + (16-bit half of `packed`) * row_bytes in one instruction.
+template <int HI>
+__device__ __forceinline__ unsigned tile_addr(unsigned packed, unsigned row_bytes, unsigned base) {
+  unsigned a;
+  if (HI) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a) : "v"(packed), "v"(row_bytes), "v"(base));
+  else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(a) : "v"(packed), "v"(row_bytes), "v"(base));
+  return a;
+}
+
+// One 4-entry step of a row group: the entries [4 J, 4 J + 4) (+ FIRST) of every row live in lane J of the row's quad as two
+// packed 16-bit tile-row pairs (PC) and four weights (MV); a DPP quad broadcast hands them to the quad's lanes.  The
+// step runs if any row of the wave has an entry in it (DEG: the lane's row degree).
+#define GCNX_DSTEP4(J, PC, MV, DEG, FIRST)                                                                     \
+  if (((J) == 0 && (FIRST) == 0) || __builtin_amdgcn_ballot_w64((DEG) > (FIRST) + 4 * (J)) != 0) {              \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                            \
+      const unsigned pk = (unsigned)quad_bcast<4, (J)>((int)PC[k]);                                            \
+      _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                       \
+        const unsigned a0 = hh ? tile_addr<1>(pk, RB, tb0) : tile_addr<0>(pk, RB, tb0);                        \
+        f32x2 w2 = f32x2{1.f, 1.f};                                                                            \
+        if (WEIGHTED) { const float w = __int_as_float(quad_bcast<4, (J)>(__float_as_int(MV[2 * k + hh]))); w2 = f32x2{w, w}; } \
+        _Pragma("unroll") for (int j = 0; j < CPL; ++j) {                                                      \
+          const f32x4v hq = *reinterpret_cast<const __attribute__((address_space(3))) f32x4v*>(a0 + (j ? tbd : 0u)); \
+          if (WEIGHTED) {                                                                                      \
+            acc[j][0] = __builtin_elementwise_fma(w2, f32x2{hq.x, hq.y}, acc[j][0]);                           \
+            acc[j][1] = __builtin_elementwise_fma(w2, f32x2{hq.z, hq.w}, acc[j][1]);                           \
+          } else {                                                                                             \
+            acc[j][0] += f32x2{hq.x, hq.y};                                                                    \
+            acc[j][1] += f32x2{hq.z, hq.w};                                                                    \
+          }                                                                                                    \
         }                                                                                                      \
       }                                                                                                        \
     }                                                                                                          \
@@ -595,27 +618,27 @@ enum { kDuoPlain = 0, kDuoFold = 1, kDuoBitsOut = 2, kDuoFoldBits = 3 };
 
 template <int THREADS, int FT, int LPR, bool WEIGHTED, int MODE = kDuoPlain>
 __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ vals,
-    const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-    const int2* __restrict__ graphs /* (row0, ng), largest first */, int upg /* units per graph */,
-    int sg /* column slabs per unit */, int act, int nunits, int n, int dbg_rt, DuoFold fo) {
+    const int32_t* __restrict__ rowptr, const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
+    const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias,
+    float* __restrict__ out, int64_t ldo, const int2* __restrict__ graphs /* (row0, ng), largest first */,
+    int upg /* units per graph */, int sg /* column slabs per unit */, int act, int nunits, int n, int dbg_rt, DuoFold fo) {
   // Phase-ablation bits (results are wrong by design when set).  The HOST passes 0 unless this is a tuning build
   // (launch_duo), so a release library cannot be talked into wrong results; the tests stay in the kernel as uniform
   // branches on purpose: with them folded away at compile time hipcc's allocation of this 128-VGPR kernel spilled 6.
   const int dbg = dbg_rt;
   constexpr bool FOLD = MODE == kDuoFold || MODE == kDuoFoldBits;
-  static_assert(MODE == kDuoPlain || MODE == kDuoFold || FT == 32, "the bit image has one 32-bit word per row and slab");
-  constexpr int CPL = FT / (4 * LPR);           // float4 chunks per lane (2 only with LPR = 4, FT = 32)
+  static_assert(FT == 32 && LPR == 4, "one quad per row, two 64-byte halves per tile row (the xor-64 chunk addressing)");
+  constexpr int CPL = FT / (4 * LPR);           // float4 chunks per lane
   constexpr int RPW = 64 / LPR;                 // rows per wave
   constexpr int SPAN = (THREADS / 64) * RPW;
   constexpr int CAP = DuoShape<THREADS, FT>::CAP;
   constexpr int NI = (CAP + SPAN - 1) / SPAN;   // row groups per unit: their first 16 entries live in registers
-  constexpr int RB = FT * 4;                    // bytes per tile row
-  static_assert((CAP + 2) * FT + CAP + 2 <= DuoShape<THREADS, FT>::LDSF, "tile + zero row + bias + row pointers must fit");
+  constexpr unsigned RB = FT * 4;               // bytes per tile row
+  static_assert((CAP + 2) * FT <= DuoShape<THREADS, FT>::LDSF, "tile + zero row + bias must fit");
   static_assert(NI <= 5, "index registers");
+  static_assert(CAP < 65536, "16-bit tile rows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lbias = lds + (CAP + 1) * FT;          // this step's bias slice
-  int* rp = reinterpret_cast<int*>(lds + (CAP + 2) * FT);   // the unit's row pointers (ng + 1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int sub = lane % LPR, slot = sub & 3;
   const int rbase = (tid >> 6) * RPW + lane / LPR;
@@ -625,9 +648,9 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
   // the 2 quarters (row parity, j): expected 2.75 LDS cycles per read.  Quads 2..5 therefore read their chunks in
   // the opposite order (chunk j ^ 1 first): each group then has two quads on either chunk, 1.75 expected.
   const int csw = (CPL == 2) ? ((((lane >> 2) + 2) >> 2) & 1) : 0;
-  const char* tb[CPL];                          // LDS base of this lane's j-th chunk
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) tb[j] = reinterpret_cast<const char*>(lds) + (sub + LPR * (j ^ csw)) * 16;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned tb0 = lds0 + (sub + LPR * csw) * 16;   // LDS address of this lane's FIRST chunk of tile row 0
+  const unsigned tbd = csw ? (unsigned)-64 : 64u;       // ... and the distance to its second chunk
   // workgroup id folded per XCD (ids are dealt round-robin to the 8 XCDs): consecutive virtual ids share an L2
   const int G = gridDim.x;
   const int w = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
@@ -643,18 +666,40 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
     const int un = unit_of(round + 1);
     const bool has_next = un < nunits;
     const int2 gn = has_next ? graphs[un / upg] : g;
-    // index burst of the unit: row pointers and the first 16 entries of every row this lane group owns, once
-    // for all sg slabs (they share rows and entries).  In flight together with the first tile.
-    int mc[NI][4];
-    float mv[NI][4];
+    // index burst of the unit: (local row, degree) and the first 16 entries of every row this quad owns -- 32 for the
+    // first row group, where the degree order puts the long rows -- once for all sg slabs (they share rows and
+    // entries).  In flight together with the first tile.
+    unsigned rw[NI];                            // local row | degree << 16 (0 entries for positions past the graph)
+    unsigned pc[NI][2], pc2[2];                 // tile rows of the entries, 16-bit pairs: entry 2k | entry 2k + 1 << 16
+    float mv[NI][4], mv2[4];
     {
-      int a[NI], b[NI];
-      tile_load_rowptr<NI, SPAN, LPR>(rowptr, g.x, g.y, a, b);
-      if (!(dbg & 8)) tile_load_entries<NI, WEIGHTED, RB>(ebufs, g.x, CAP, a, b, mc, mv);
+      int a[NI];
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        const int pos = rbase + t * SPAN;
+        const RowRec rr = rowrec[g.x + min(pos, g.y - 1)];    // clamped: always in bounds
+        a[t] = rr.a;
+        rw[t] = pos < g.y ? rr.w : (rr.w & 0xFFFFu);          // positions past the graph: no entries, no store
+      }
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        int c4[4];
+        if (!(dbg & 8)) fetch_entries<WEIGHTED, 1>(ebufs, a[t], slot, a[t] + (int)(rw[t] >> 16), g.x, CAP, c4, mv[t]);
+        else { c4[0] = c4[1] = c4[2] = c4[3] = CAP; mv[t][0] = mv[t][1] = mv[t][2] = mv[t][3] = 0.f; }
+        pc[t][0] = (unsigned)c4[0] | ((unsigned)c4[1] << 16);
+        pc[t][1] = (unsigned)c4[2] | ((unsigned)c4[3] << 16);
+      }
+      {
+        int c4[4];
+        if (!(dbg & 8)) fetch_entries<WEIGHTED, 1>(ebufs, a[0] + 16, slot, a[0] + (int)(rw[0] >> 16), g.x, CAP, c4, mv2);
+        else { c4[0] = c4[1] = c4[2] = c4[3] = CAP; mv2[0] = mv2[1] = mv2[2] = mv2[3] = 0.f; }
+        pc2[0] = (unsigned)c4[0] | ((unsigned)c4[1] << 16);
+        pc2[1] = (unsigned)c4[2] | ((unsigned)c4[3] << 16);
+      }
     }
     for (int s = 0; s < sg; ++s) {
       const int c0 = cbase + s * FT;
-      // The previous reduction no longer reads the tile / bias / row pointers.  Its LDS reads were consumed by
+      // The previous reduction no longer reads the tile / bias.  Its LDS reads were consumed by
       // the arithmetic, so a bare s_barrier is enough: __syncthreads() would also drain the output stores
       // (vmcnt(0) of its release fence) before the next tile may even be requested.
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -669,7 +714,6 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           t4[i] = make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
         }
       } else if (!(dbg & 1)) tile_dma32<FT / 4, THREADS, CAP * (FT / 4)>(lds, h + (int64_t)g.x * ldh + c0, ld32, g.y);
-      if (s == 0) for (int i = tid; i <= g.y; i += THREADS) rp[i] = rowptr[g.x + i];
       if (FOLD) {
         if (tid < FT) lbias[tid] = fo.dp[(int64_t)fo.gids[u / upg] * fo.lddp + c0 + tid] * (fo.avg ? 1.0f / (float)g.y : 1.0f);
       } else {
@@ -684,31 +728,44 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
 #pragma unroll
       for (int t = 0; t < NI; ++t) if (t * SPAN < g.y) {
         __builtin_amdgcn_sched_barrier(0);      // one row group at a time: bounded live ranges
-        const int r = rbase + t * SPAN;
-        const int rc = min(r, g.y - 1);
-        const int at = rp[rc], bt = r < g.y ? rp[rc + 1] : at;
+        const int pos = rbase + t * SPAN;
+        const int deg = (int)(rw[t] >> 16);
         f32x2 acc[CPL][2];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
         if (!(dbg & 2)) {
-          GCNX_DSTEP4(0, mc[t], mv[t], at, bt)
-          GCNX_DSTEP4(1, mc[t], mv[t], at, bt)
-          GCNX_DSTEP4(2, mc[t], mv[t], at, bt)
-          GCNX_DSTEP4(3, mc[t], mv[t], at, bt)
-          int base = at + 16;
-          while (__builtin_amdgcn_ballot_w64(base < bt) != 0) {   // rows longer than 16 entries (2 % at degree 10)
-            int xc[4];
-            float xv[4];
-            fetch_entries<WEIGHTED, RB>(ebufs, base, slot, bt, g.x, CAP, xc, xv);
-            GCNX_DSTEP4(0, xc, xv, base, bt)
-            GCNX_DSTEP4(1, xc, xv, base, bt)
-            GCNX_DSTEP4(2, xc, xv, base, bt)
-            GCNX_DSTEP4(3, xc, xv, base, bt)
-            base += 16;
+          GCNX_DSTEP4(0, pc[t], mv[t], deg, 0)
+          GCNX_DSTEP4(1, pc[t], mv[t], deg, 0)
+          GCNX_DSTEP4(2, pc[t], mv[t], deg, 0)
+          GCNX_DSTEP4(3, pc[t], mv[t], deg, 0)
+          int base = 16;
+          if (t == 0) {                         // (the degree order puts a graph's long rows here: 16 more entries in registers)
+            if (__builtin_amdgcn_ballot_w64(deg > 16) != 0) {
+              GCNX_DSTEP4(0, pc2, mv2, deg, 16)
+              GCNX_DSTEP4(1, pc2, mv2, deg, 16)
+              GCNX_DSTEP4(2, pc2, mv2, deg, 16)
+              GCNX_DSTEP4(3, pc2, mv2, deg, 16)
+            }
+            base = 32;
+          }
+          if (__builtin_amdgcn_ballot_w64(deg > base) != 0) {   // longer rows: the rest on demand (power-law batches)
+            const int ea = rowrec[g.x + min(pos, g.y - 1)].a;
+            while (__builtin_amdgcn_ballot_w64(deg > base) != 0) {
+              int xc[4];
+              float xv[4];
+              fetch_entries<WEIGHTED, 1>(ebufs, ea + base, slot, ea + deg, g.x, CAP, xc, xv);
+              unsigned xp[2] = {(unsigned)xc[0] | ((unsigned)xc[1] << 16), (unsigned)xc[2] | ((unsigned)xc[3] << 16)};
+              GCNX_DSTEP4(0, xp, xv, deg, base)
+              GCNX_DSTEP4(1, xp, xv, deg, base)
+              GCNX_DSTEP4(2, xp, xv, deg, base)
+              GCNX_DSTEP4(3, xp, xv, deg, base)
+              base += 16;
+            }
           }
         }
         [[maybe_unused]] unsigned bword = 0;
-        if (r < g.y && !(dbg & 4)) {
+        const int r = (int)(rw[t] & 0xFFFFu);   // the row of the graph this quad owns in this group
+        if (pos < g.y && !(dbg & 4)) {
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
             const float4 bvj = *reinterpret_cast<const float4*>(lbias + (sub + LPR * (j ^ csw)) * 4);
@@ -726,7 +783,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
         if constexpr (MODE == kDuoBitsOut) {      // the quad's four lanes hold the row's 32 columns: one word per row
           bword |= __shfl_xor(bword, 1);
           bword |= __shfl_xor(bword, 2);
-          if (sub == 0 && r < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
+          if (sub == 0 && pos < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
         }
       }
     }
@@ -1017,9 +1074,9 @@ __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restr
 template <int LPR>
 void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                 const int2* chunk_list = nullptr, int list_len = 0, const FoldArgs* fold = nullptr) {
+                 const int2* chunk_list = nullptr, int list_len = 0, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk) {
   const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
-  const bool small = !chunk_list && n < 16 * 1024 * kRowsPerChunk / 4;   // < 128k rows
+  const bool small = chunk_list ? list_rpc <= kRowsPerChunkSmall : n < 16 * 1024 * kRowsPerChunk / 4;   // < 128k rows
   const int nchunks = chunk_list ? list_len : gcnx_cdiv(n, small ? kRowsPerChunkSmall : kRowsPerChunk);
   const int span = LPR * 4;
   for (int col0 = 0; col0 < f; col0 += span) {
@@ -1038,20 +1095,20 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                    int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr) {
+                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk) {
   int lanes = f / 4;
   // Tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in floats
   // forces the lanes-per-row split of the rows kernel; results are identical.
   if (ctx->knob_spmm_slab >= 16 && ctx->knob_spmm_slab / 4 < lanes) lanes = ctx->knob_spmm_slab / 4;
-  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
-  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
-  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
-  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
-  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold);
+  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
+  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
+  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
+  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
+  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
 }
 
 template <int THREADS, int FT, int LPR>
-int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const int32_t* colidx, const float* vals, const float* h,
                int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
                const int2* graphs, int ngraphs, const DuoFold* fold = nullptr, int mode = kDuoPlain) {
   constexpr int lds_bytes = DuoShape<THREADS, FT>::LDSF * 4;
@@ -1085,8 +1142,8 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, cons
   const DuoFold nofold{nullptr, nullptr, 0, 0, nullptr};
   const DuoFold fo = fold ? *fold : nofold;
 #define GCNX_DUO_LAUNCH(W, M)                                                                                                \
-  hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, W, M>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, colidx, \
-                     vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo)
+  hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, W, M>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, rowrec, \
+                     colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo)
   if (vals) {
     switch (mode) {
       case kDuoFold: GCNX_DUO_LAUNCH(true, kDuoFold); break;
@@ -1112,7 +1169,16 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, cons
 // What the diagonal-block structure of a disjoint batch buys: which graphs fit an LDS tile (and
 // at which slab width), largest first so the work queue ends on small items; 32-row chunks of
 // the graphs that do not, for the rows kernel.  Built once per batch; owned by the caller.
+struct RowOrder {                       // the tile kernels' degree order of one rowptr (device pointer): see RowRec
+  const int32_t* rowptr = nullptr;
+  RowRec* dev = nullptr;
+  int n = 0;
+};
 struct gcnx_spmm_plan {
+  std::vector<int32_t> bp;              // host copy of block_ptr
+  RowOrder orders[4];                   // row orders bound so far (a normalised / unweighted / transposed view may share the plan)
+  int norders = 0, next_evict = 0;
+  int chunk_rpc = kRowsPerChunk;        // rows per chunk of the row-chunk list
   int nblocks = 0;
   int n1 = 0, n2 = 0, nchunks = 0;      // tier-1 graphs, tier-2 graphs, row chunks of larger graphs
   long long tile_rows = 0;
@@ -1135,6 +1201,100 @@ extern "C" __attribute__((visibility("default"))) int gcnx_tuning_wave_stamps(gc
 }
 #endif
 
+// Every device allocation of a plan, freed in one place (also on every failure path of gcnx_spmm_plan_create).
+static void plan_free(gcnx_spmm_plan* p) {
+  if (!p) return;
+  if (p->dev) (void)hipFree(p->dev);
+  if (p->gids) (void)hipFree(p->gids);
+  if (p->items) (void)hipFree(p->items);
+  if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
+  for (int i = 0; i < p->norders; ++i) if (p->orders[i].dev) (void)hipFree(p->orders[i].dev);
+  delete p;
+}
+
+template <class T>
+static hipError_t plan_upload(gcnx_ctx* ctx, T** dev, const std::vector<T>& host) {
+  *dev = nullptr;
+  if (host.empty()) return hipSuccess;
+  hipError_t e = hipMalloc((void**)dev, host.size() * sizeof(T));
+  if (e == hipSuccess) e = hipMemcpyAsync(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  return e;
+}
+
+// The tile kernels' row order for one rowptr: per graph that fits a tile, its rows by decreasing degree (ties in row
+// order: a counting sort), as RowRec records at the graph's own positions.  Built on the host from a copy of rowptr
+// (synchronises; once per (plan, rowptr)).
+static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* rowptr, int32_t n, RowOrder* slot) {
+  try {
+    std::vector<int32_t> rp((size_t)n + 1);
+    hipError_t e = hipMemcpyAsync(rp.data(), rowptr, rp.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_bind: %s", hipGetErrorString(e));
+    std::vector<RowRec> rec((size_t)n);
+    std::vector<int> count, start;
+    for (int g = 0; g < p->nblocks; ++g) {
+      const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
+      if (ng <= 0) continue;
+      if (r0 < 0 || r0 + ng > n) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_bind: block %d leaves the %d rows of this operator", g, n);
+      if (ng > p->cap2) {                          // not a tile graph: identity (never read by the tile kernels)
+        for (int i = 0; i < ng; ++i) rec[(size_t)r0 + i] = RowRec{rp[r0 + i], (unsigned)0};
+        continue;
+      }
+      // degree order inside windows of `win` consecutive rows (win >= ng: the whole graph)
+      const int span = ng <= p->cap1 ? 128 : 256;             // rows per row group of the tier that takes this graph
+      const int win = ctx->knob_spmm_sort_win > 0 ? ctx->knob_spmm_sort_win * span : ng;
+      for (int w0 = 0; w0 < ng; w0 += win) {
+        const int wn = std::min(win, ng - w0);
+        int dmax = 0;
+        for (int i = w0; i < w0 + wn; ++i) {
+          const int d = rp[r0 + i + 1] - rp[r0 + i];
+          if (d < 0) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_bind: rowptr decreases at row %d", r0 + i);
+          dmax = std::max(dmax, d);
+        }
+        if (dmax > 65535) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_bind: a row of a tile graph has %d entries", dmax);
+        count.assign((size_t)dmax + 2, 0);
+        for (int i = w0; i < w0 + wn; ++i) ++count[rp[r0 + i + 1] - rp[r0 + i]];
+        start.assign((size_t)dmax + 2, 0);           // start[d] = first position of degree d: longer rows first
+        int pos = w0;
+        for (int d = dmax; d >= 0; --d) { start[d] = pos; pos += count[d]; }
+        for (int i = w0; i < w0 + wn; ++i) {
+          const int d = rp[r0 + i + 1] - rp[r0 + i];
+          rec[(size_t)r0 + start[d]++] = RowRec{rp[r0 + i], (unsigned)i | ((unsigned)d << 16)};
+        }
+      }
+    }
+    RowRec* dev = nullptr;
+    e = plan_upload(ctx, &dev, rec);
+    if (e != hipSuccess) { if (dev) (void)hipFree(dev); return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_bind: %s", hipGetErrorString(e)); }
+    if (slot->dev) (void)hipFree(slot->dev);
+    slot->rowptr = rowptr; slot->dev = dev; slot->n = n;
+  } catch (const std::bad_alloc&) {
+    return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_bind: out of host memory");
+  }
+  return GCNX_OK;
+}
+
+// The order bound to `rowptr`, built on first use (outside stream capture).  force: rebuild (the CSR behind the pointer changed).
+static int plan_order(gcnx_ctx* ctx, const gcnx_spmm_plan* cplan, const int32_t* rowptr, int32_t n, bool force, const RowRec** out) {
+  gcnx_spmm_plan* p = const_cast<gcnx_spmm_plan*>(cplan);   // (a cache behind an opaque handle; a ctx is single-threaded by contract)
+  RowOrder* slot = nullptr;
+  for (int i = 0; i < p->norders; ++i)
+    if (p->orders[i].rowptr == rowptr && p->orders[i].n == n) slot = &p->orders[i];
+  if (slot && !force) { *out = slot->dev; return GCNX_OK; }
+  if (ctx->capturing)
+    return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: the plan has no row order for this rowptr yet and building one synchronises: "
+                     "call gcnx_spmm_plan_bind (or run the call once) before capturing");
+  if (!slot) {
+    if (p->norders < 4) slot = &p->orders[p->norders++];
+    else { slot = &p->orders[p->next_evict]; p->next_evict = (p->next_evict + 1) % 4; (void)hipStreamSynchronize(ctx->stream); }
+  }
+  const int rc = plan_build_order(ctx, p, rowptr, n, slot);
+  if (rc) return rc;
+  *out = slot->dev;
+  return GCNX_OK;
+}
+
 extern "C" {
 
 int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nblocks, gcnx_spmm_plan** out) {
@@ -1143,23 +1303,33 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
   *out = nullptr;
   GCNX_REQUIRE(ctx, nblocks >= 0 && (nblocks == 0 || block_ptr), "gcnx_spmm_plan_create: bad block list");
   GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_spmm_plan_create synchronises and cannot be captured");
+  gcnx_spmm_plan* p = nullptr;
   try {
-    std::vector<int32_t> bp((size_t)nblocks + 1, 0);
+    p = new gcnx_spmm_plan();
+    std::vector<int32_t>& bp = p->bp;
+    bp.assign((size_t)nblocks + 1, 0);
     if (nblocks > 0) {
-      GCNX_HIP(ctx, hipMemcpyAsync(bp.data(), block_ptr, bp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      GCNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      hipError_t e = hipMemcpyAsync(bp.data(), block_ptr, bp.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { plan_free(p); return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
     }
     std::vector<int2> t1, t2, ch;
     std::vector<std::pair<int, int>> by_row;       // (row0, graph index) of the tile graphs
     long long tile_rows = 0;
-    int cap1 = kDuoCap32, cap2 = kSoloCap32;
+    const int cap1 = kDuoCap32, cap2 = kSoloCap32;
+    // graphs taller than any tile go to the row gather as plan-listed chunks.  8-row chunks (r3): the gather re-reads a
+    // graph's feature rows ~degree times and only the XCD's 4 MiB L2 can serve that; with 32-row chunks 7 workgroups per CU
+    // x 32 CUs hold ~7 000 rows = 4-5 such graphs (2 MB of features each) in flight per XCD and the re-reads went to HBM
+    // (r2 PMC: 496 MB fetched for 116 MB of rows); 8-row chunks keep it to about one graph.
+    const int rpc = ctx->knob_spmm_tall_rpc == 32 ? kRowsPerChunk : kRowsPerChunkSmall;
+    p->chunk_rpc = rpc;
     for (int g = 0; g < nblocks; ++g) {
       const int r0 = bp[g], ng = bp[g + 1] - bp[g];
-      if (ng < 0) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g);
+      if (ng < 0) { plan_free(p); return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g); }
       if (ng == 0) continue;
       if (ng <= cap1) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
       else if (ng <= cap2) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
-      else for (int r = r0; r < r0 + ng; r += kRowsPerChunk) ch.push_back(make_int2(r, std::min(r + kRowsPerChunk, r0 + ng)));
+      else for (int r = r0; r < r0 + ng; r += rpc) ch.push_back(make_int2(r, std::min(r + rpc, r0 + ng)));
     }
     auto by_size = [](const int2& x, const int2& y) { return x.y != y.y ? x.y > y.y : x.x < y.x; };
     std::sort(t1.begin(), t1.end(), by_size);
@@ -1169,33 +1339,17 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     for (const std::vector<int2>* tv : {&t1, &t2})
       for (const int2& rec : *tv)
         gids.push_back(std::lower_bound(by_row.begin(), by_row.end(), std::make_pair(rec.x, 0))->second);
-    gcnx_spmm_plan* p = new gcnx_spmm_plan();
     p->nblocks = nblocks;
     p->n1 = (int)t1.size(); p->n2 = (int)t2.size(); p->nchunks = (int)ch.size();
     p->tile_rows = tile_rows;
     p->cap1 = cap1; p->cap2 = cap2;
-    const size_t total = t1.size() + t2.size() + ch.size();
-    if (total) {
-      std::vector<int2> all;
-      all.reserve(total);
-      all.insert(all.end(), t1.begin(), t1.end());
-      all.insert(all.end(), t2.begin(), t2.end());
-      all.insert(all.end(), ch.begin(), ch.end());
-      hipError_t e = hipMalloc((void**)&p->dev, total * sizeof(int2));
-      if (e != hipSuccess) { delete p; return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_create: hipMalloc: %s", hipGetErrorString(e)); }
-      e = hipMemcpyAsync(p->dev, all.data(), total * sizeof(int2), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
-    }
-    if (!gids.empty()) {
-      hipError_t e = hipMalloc((void**)&p->gids, gids.size() * sizeof(int32_t));
-      if (e == hipSuccess) e = hipMemcpyAsync(p->gids, gids.data(), gids.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) { if (p->gids) (void)hipFree(p->gids); if (p->dev) (void)hipFree(p->dev); delete p;
-                             return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
-    }
+    std::vector<int2> all;
+    all.reserve(t1.size() + t2.size() + ch.size());
+    all.insert(all.end(), t1.begin(), t1.end());
+    all.insert(all.end(), t2.begin(), t2.end());
+    all.insert(all.end(), ch.begin(), ch.end());
     // work items of the pipelined kernel: every graph of up to 1248 rows (costliest first); taller ones as 32-row chunks
-    // for the rows kernel (list appended behind the items' own chunk list below)
+    // for the rows kernel
     std::vector<PipeItem> items;
     std::vector<int2> tall;
     for (int g = 0; g < nblocks; ++g) {
@@ -1208,27 +1362,17 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     p->nitems = (int)items.size();
     for (const PipeItem& it : items) p->n16 += it.ng > kPipeCap32 ? 1 : 0;    // sorted by size: they come first
     p->npipe_chunks = (int)tall.size();
-    if (!tall.empty()) {
-      hipError_t e = hipMalloc((void**)&p->pipe_chunks, tall.size() * sizeof(int2));
-      if (e == hipSuccess) e = hipMemcpyAsync(p->pipe_chunks, tall.data(), tall.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) { if (p->pipe_chunks) (void)hipFree(p->pipe_chunks); if (p->dev) (void)hipFree(p->dev); delete p;
-                             return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e)); }
-    }
-    if (!items.empty()) {
-      hipError_t e = hipMalloc((void**)&p->items, items.size() * sizeof(PipeItem));
-      if (e == hipSuccess) e = hipMemcpyAsync(p->items, items.data(), items.size() * sizeof(PipeItem), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) {
-        if (p->items) (void)hipFree(p->items);
-        if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
-        if (p->dev) (void)hipFree(p->dev);
-        delete p;
-        return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e));
-      }
+    hipError_t e = plan_upload(ctx, &p->dev, all);
+    if (e == hipSuccess) e = plan_upload(ctx, &p->gids, gids);
+    if (e == hipSuccess) e = plan_upload(ctx, &p->pipe_chunks, tall);
+    if (e == hipSuccess) e = plan_upload(ctx, &p->items, items);
+    if (e != hipSuccess) {
+      plan_free(p);
+      return gcnx_fail(ctx, e == hipErrorOutOfMemory ? GCNX_ERR_NOMEM : GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e));
     }
     *out = p;
   } catch (const std::bad_alloc&) {
+    plan_free(p);
     return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_create: out of host memory");
   }
   return GCNX_OK;
@@ -1238,12 +1382,16 @@ int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
   GCNX_CHECK_CTX(ctx);
   if (!plan) return GCNX_OK;
   (void)hipStreamSynchronize(ctx->stream);
-  if (plan->dev) (void)hipFree(plan->dev);
-  if (plan->gids) (void)hipFree(plan->gids);
-  if (plan->items) (void)hipFree(plan->items);
-  if (plan->pipe_chunks) (void)hipFree(plan->pipe_chunks);
-  delete plan;
+  plan_free(plan);
   return GCNX_OK;
+}
+
+int gcnx_spmm_plan_bind(gcnx_ctx* ctx, gcnx_spmm_plan* plan, const int32_t* rowptr, int32_t n) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, plan && rowptr && n >= 0, "gcnx_spmm_plan_bind: NULL plan / rowptr");
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_spmm_plan_bind synchronises and cannot be captured");
+  const RowRec* unused = nullptr;
+  return plan_order(ctx, plan, rowptr, n, true, &unused);
 }
 
 static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
@@ -1364,6 +1512,8 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
     return GCNX_OK;
   }
   // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
+  const RowRec* rowrec = nullptr;
+  if (plan->n1 + plan->n2 > 0) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec); if (rb) return rb; }
   const DuoFold bo{nullptr, nullptr, 0, 0, relu_bits};     // (graphs taller than a tile get no bits: their rows are folded from out)
   const int dmode = relu_bits ? kDuoBitsOut : kDuoPlain;
   // The three launches write disjoint rows.  GCNX_SPMM_CONC: as concurrent branches (two auxiliary streams), so that
@@ -1374,18 +1524,18 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   if (conc) { int rc = gcnx_aux_fork(ctx, aux); if (rc) return rc; }
   int rc = GCNX_OK;
   if (plan->n2 > 0) {        // (the 1024-thread tier first: its workgroups are the hardest to place)
-    rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
+    rc = launch_duo<1024, 32, 4>(ctx, rowptr, rowrec, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
                                  plan->n2, &bo, dmode);
   }
   if (!rc && plan->n1 > 0) {
     if (conc) ctx->stream = aux[0];
-    rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, &bo, dmode);
+    rc = launch_duo<512, 32, 4>(ctx, rowptr, rowrec, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, &bo, dmode);
     ctx->stream = home;
   }
   if (!rc && plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     if (conc) ctx->stream = aux[1];
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks);
+                  plan->nchunks, nullptr, plan->chunk_rpc);
     if (hipGetLastError() != hipSuccess) rc = gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_csr: row-chunk launch failed");
     ctx->stream = home;
   }
@@ -1422,21 +1572,23 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
   }
   // y_bits (the forward's gcnx_spmm_csr_relu_bits image of y): the tiers expand it instead of reading y
   const int dmode = y_bits ? kDuoFoldBits : kDuoFold;
+  const RowRec* rowrec = nullptr;
+  if (plan->n1 + plan->n2 > 0) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec); if (rb) return rb; }
   if (plan->n1 > 0) {
     const DuoFold df{plan->gids, dpooled, lddp, fo.avg, (uint32_t*)y_bits};
-    int rc = launch_duo<512, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev, plan->n1, &df,
+    int rc = launch_duo<512, 32, 4>(ctx, rowptr, rowrec, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev, plan->n1, &df,
                                     dmode);
     if (rc) return rc;
   }
   if (plan->n2 > 0) {
     const DuoFold df{plan->gids + plan->n1, dpooled, lddp, fo.avg, (uint32_t*)y_bits};
-    int rc = launch_duo<1024, 32, 4>(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1,
+    int rc = launch_duo<1024, 32, 4>(ctx, rowptr, rowrec, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1,
                                      plan->n2, &df, dmode);
     if (rc) return rc;
   }
   if (plan->nchunks > 0) {
     dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks, &fo);
+                  plan->nchunks, &fo, plan->chunk_rpc);
     GCNX_LAUNCH_OK(ctx);
   }
   return GCNX_OK;

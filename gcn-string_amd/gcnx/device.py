@@ -288,6 +288,11 @@ class DeviceCSR:
             self.ctx._ck(self.ctx.lib.gcnx_spmm_plan_create(self.ctx.h, holder.ptr, self.n_blocks, C.byref(h)))
             p = _Plan(self.ctx, h)
             holder._spmm_plan = p
+        if self._plan is not p:
+            # the tile kernels' degree order of THIS operator's rows (gcnx_spmm_plan_bind: synchronises, so it happens here,
+            # once per view, and never inside a captured call)
+            self.ctx._ck(self.ctx.lib.gcnx_spmm_plan_bind(self.ctx.h, p.h, self.rowptr.ptr, self.n))
+            self._plan = p
         return p.h
 
     @classmethod

@@ -183,6 +183,13 @@ GCNX_API int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* 
 GCNX_API int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nblocks,
                                    gcnx_spmm_plan** out);
 GCNX_API int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan);
+/* The tile kernels deal a graph's output rows to their lanes in degree order (longest rows first), which they read from
+ * a per-rowptr record list the plan builds from a host copy of rowptr (synchronises; kept per rowptr POINTER, up to four
+ * per plan: the normalised, unweighted and transposed views of one batch share the plan).  gcnx_spmm_csr and
+ * gcnx_spmm_csr_pool_bwd build it on first use with a rowptr; call this (a) before capturing such a call into a HIP graph
+ * unless it has run once already, (b) again whenever the row pointers behind an already bound pointer change.  Like the
+ * plan itself it only changes scheduling -- and the order in which a row's output is WRITTEN, never its value. */
+GCNX_API int gcnx_spmm_plan_bind(gcnx_ctx* ctx, gcnx_spmm_plan* plan, const int32_t* rowptr, int32_t n);
 /* K2/K3 SparseTensorDenseMatMul / gather+unsorted_segment_sum:
  * out[t,:] = act( sum_e vals[e] * h[colidx[e],:] + bias ), e over row t.
  * GCNConv.call (bias AFTER aggregation) and GeneralConv.propagate (vals NULL).

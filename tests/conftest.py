@@ -38,6 +38,54 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30)) if a.size else 0.0
 
 
+def elem_err(a, b):
+    """The smallest t for which np.allclose(a, b, rtol=t, atol=t * max|b|) holds: max_i |a_i - b_i| / (|b_i| + max|b|).
+    The element-wise reading of "1e-4 relative" next to rel_err's max-norm reading: never larger than
+    rel_err, and at least half of it."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if not a.size:
+        return 0.0
+    top = max(float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + top)))
+
+
+def strict_rel_err(a, b, floor=1e-3):
+    """max_i |a_i - b_i| / |b_i| over the entries with |b_i| >= floor * max|b| (informational: the purely element-wise
+    relative error where it is meaningful in fp32; entries below the floor are covered by rel_err / elem_err only)."""
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    if not a.size:
+        return 0.0
+    keep = np.abs(b) >= floor * max(float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a[keep] - b[keep]) / np.abs(b[keep]))) if keep.any() else 0.0
+
+
+PARITY_REPORT = []     # (what, rel_err, elem_err, strict_rel_err, tol) of every assert_close call of the session
+
+
+def assert_close(a, b, tol, what=""):
+    """Both readings of the tolerance: max-norm (rel_err < tol) and element-wise (allclose(rtol=tol, atol=tol * max|ref|));
+    the three error figures are kept for the session's parity report (gpurun_out/parity_report.json on the GPU box)."""
+    a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    r, e, s = rel_err(a64, b64), elem_err(a64, b64), strict_rel_err(a64, b64)
+    PARITY_REPORT.append({"what": str(what), "rel_err": r, "elem_err": e, "strict_rel_err_above_1e-3": s, "tol": tol})
+    top = max(float(np.max(np.abs(b64))), 1e-30) if b64.size else 1.0
+    assert r < tol, (what, "max-norm", r, tol)
+    assert np.allclose(a64, b64, rtol=tol, atol=tol * top), (what, "element-wise", e, tol)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY_REPORT:
+        return
+    try:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as fh:
+            json.dump(PARITY_REPORT, fh, indent=1)
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def ctx():
     import gcnx

@@ -65,12 +65,12 @@ def test_spmm_long_rows_overflowing_the_lds_stage(ctx):
 def test_spmm_tile_kernel_all_tiers_forced(ctx, weighted, monkeypatch):
     """The LDS-tile kernels on a batch that holds every scheduling class: graphs at and around the limits of the
     pipelined kernel (624 rows: 32-column slabs; 1024: 16-column slabs; taller: row chunks) and of the round-1
-    tier kernels (604 / 1236), taller ones, a single-node graph, rows with > 16 and > 32 entries (second register set / tail from global memory;
+    tier kernels (632 / 1276 since r3; 604 / 1236 before), taller ones, a single-node graph, rows with > 16 and > 32 entries (second register set / tail from global memory;
     on-demand index fetch) -- pipelined kernel, tier kernels and row gather against the oracle."""
     from gcnx import device as D, synth
     import scipy.sparse as sp
     rng = np.random.default_rng(11)
-    sizes = [1, 40, 100, 604, 605, 624, 625, 632, 633, 768, 769, 1024, 1025, 1236, 1237, 1264, 1265, 300, 2000, 7]
+    sizes = [1, 40, 100, 604, 605, 624, 625, 632, 633, 768, 769, 1024, 1025, 1236, 1237, 1264, 1265, 1276, 1277, 300, 2000, 7]
     blocks = []
     for i, m in enumerate(sizes):
         dens = 0.5 if m in (40, 100) else min(1.0, 9.0 / m)   # ~20-entry rows (40 nodes) and ~50-entry rows (100 nodes)
