@@ -51,21 +51,22 @@ def launch_ranks(n, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     run_id = uuid.uuid4().hex
+    import tempfile
     procs = []
+    # rank 0's stdout goes to a temporary FILE, read back after it exits: a pipe that is only read at the end would block
+    # the rank (and with it every other rank, until the time limit) once it has written more than the pipe buffer holds
+    out0_file = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GCNX_RUN_ID=run_id, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = None
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
     rc = 0
     deadline = time.time() + float(os.environ.get("GCNX_BENCH_TIMEOUT", "3000"))
     pending = set(range(n))
     while pending:
         for r in sorted(pending):
             p = procs[r]
-            if r == 0 and out0 is None and p.poll() is not None:
-                out0 = p.stdout.read()
             code = p.poll()
             if code is None:
                 continue
@@ -82,8 +83,9 @@ def launch_ranks(n, argv):
             rc = rc or 124
             break
         time.sleep(0.05)
-    if out0 is None:
-        out0 = procs[0].stdout.read() or b""
+    out0_file.seek(0)
+    out0 = out0_file.read()
+    out0_file.close()
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     return rc

@@ -991,9 +991,8 @@ int gcnx_gemm_relu_bits(gcnx_ctx* ctx, const float* x, int64_t ldx, const float*
   int rc = GCNX_ERR_UNSUPPORTED;
   if (prec != GCNX_PREC_F32 && fo == 256 && al16(out) && ldo % 4 == 0)
     rc = gcnx_gemm_stream_nn(ctx, x, ldx, w, fi, fo, 1, out, ldo, n, prec, bias, nullptr, GCNX_ACT_RELU, nullptr, 0, 0, nullptr, nullptr, bits);
-  if (rc == GCNX_ERR_UNSUPPORTED)
-    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm_relu_bits: the bit image is written by the streaming bf16 kernels only "
-                     "(GCNX_PREC_BF16 / BF16X3, fi = fo = 256, n >= 32768, aligned operands): use gcnx_gemm");
+  // (UNSUPPORTED is an answer, not a failure: returned without a message, ctx's last error stays what it was -- a caller
+  // that probes every step must not pay for formatting one, nor find a stale "unsupported" text after its fallback worked)
   return rc;
 }
 
@@ -1008,10 +1007,7 @@ int gcnx_gemm_dx_bits(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float*
   if (prec != GCNX_PREC_F32 && fi == 256 && al16(dx) && lddx % 4 == 0 && (!db || al16(db)))
     rc = gcnx_gemm_stream_nn(ctx, dh, lddh, w, fi, fo, 0, dx, lddx, n, prec, nullptr, nullptr, GCNX_ACT_NONE, nullptr, 0, 0, db, mask_bits,
                              nullptr);
-  if (rc == GCNX_ERR_UNSUPPORTED)
-    return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_gemm_dx_bits: the bit image is read by the streaming bf16 kernels only "
-                     "(GCNX_PREC_BF16 / BF16X3, fi = fo = 256, n >= 32768, aligned operands): use gcnx_gemm_dx with the saved activation");
-  return rc;
+  return rc;                                   // (UNSUPPORTED without a message, as above)
 }
 
 int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx, int64_t lddx, int64_t n,

@@ -34,8 +34,8 @@ def _rendezvous_path(env=None):
         key = f"{run_id}_{port}"
     elif "TORCHELASTIC_RUN_ID" in env:               # torchrun: its workers are children of ONE elastic agent
         key = f"{env['TORCHELASTIC_RUN_ID']}_{env.get('TORCHELASTIC_RESTART_COUNT', '0')}_{port}_{os.getppid()}"
-    else:                                            # some other launcher that exported neither: the port is all there is
-        key = f"port{port}"
+    else:                                            # some other launcher that exported neither: its pid (the ranks' common
+        key = f"port{port}_{os.getppid()}"           # parent) keeps a crashed earlier run's file on the same port from matching
     return os.path.join(tempfile.gettempdir(), f"gcnx_uid_{key}")
 
 

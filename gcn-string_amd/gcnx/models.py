@@ -262,9 +262,9 @@ class GCN2(_GraphRunner):
                 # with a backward pass to follow and the streaming bf16 kernel serving the product: [Y1 > 0] also as a bit
                 # image, which the dX launch of the backward pass reads instead of Y1 (1 GB -> 32 MB at config 3)
                 bufs["y1bits_ok"] = False
-                if with_loss == "grads" and prec in ("bf16", "bf16x3") and self.hidden == 256 and batch.n >= 32768:
-                    if bufs.get("y1bits") is None or bufs["y1bits"].size < 16 * batch.n:
-                        bufs["y1bits"] = ctx.empty(16 * batch.n, np.int32)
+                if (with_loss == "grads" and prec in ("bf16", "bf16x3") and self.hidden == 256 and self.f_in == 256
+                        and batch.n >= 32768):            # (the streaming kernel's shape: K = 256 too)
+                    bufs["y1bits"] = self._cap.view("y1bits", batch.n, 16, np.int32)     # grow-only storage, stable pointers
                     bufs["y1bits_ok"] = D.gemm_relu_bits(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], bufs["y1bits"], prec=prec)
                 if not bufs["y1bits_ok"]:
                     D.gemm(ctx, bufs["s1"], p["w1"], p["b1"], bufs["y1"], act="relu", prec=prec)
@@ -276,8 +276,7 @@ class GCN2(_GraphRunner):
             # image, which the folded backward aggregation expands instead of reading Y2 again (1 GB -> 32 MB at config 3)
             bufs["y2bits_ok"] = False
             if with_loss == "grads" and self._fold(batch) and batch.a.plan is not None and self.hidden % 32 == 0:
-                if bufs.get("y2bits") is None or bufs["y2bits"].size < (self.hidden // 32) * batch.n:
-                    bufs["y2bits"] = ctx.empty((self.hidden // 32) * batch.n, np.int32)
+                bufs["y2bits"] = self._cap.view("y2bits", batch.n, self.hidden // 32, np.int32)
                 bufs["y2bits_ok"] = D.spmm_relu_bits(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"])
             if not bufs["y2bits_ok"]:
                 D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")

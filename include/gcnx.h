@@ -255,7 +255,7 @@ GCNX_API int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const floa
  * bytes reserved, 8-byte aligned; layout private to the pair, which must use the same precision), gcnx_gemm_dx_bits = gcnx_gemm_dx masked by that image instead of
  * the saved activation (ReluGrad after MatMul grad, gcn.py:337) -- 32 bytes per row read where the activation is 1 KiB.
  * Served by the streaming bf16 kernels only (GCNX_PREC_BF16 / BF16X3, fi = fo = 256, n >= 32768): GCNX_ERR_UNSUPPORTED
- * otherwise, and nothing is launched. */
+ * otherwise, nothing is launched and -- UNSUPPORTED being an answer, not a failure -- gcnx_last_error is left as it was. */
 GCNX_API int gcnx_gemm_relu_bits(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias, float* out,
                         int64_t ldo, int64_t n, int32_t fi, int32_t fo, int prec, void* bits);
 GCNX_API int gcnx_gemm_dx_bits(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx, int64_t lddx,
