@@ -13,7 +13,7 @@ only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*; the data path is libgcnx + RC
 Workloads (BASELINE.json configs):
   ecoli    config 2: B=32 E. coli-shaped graphs per GPU, F=128, fp32 (the metric's own config)
   block1m  config 3/4: 1M nodes / 10M entries / F=256 disjoint batch (strong scaling: sharded),
-           bf16 MFMA weight GEMMs (--prec bf16x3 by default: split-bf16, fp32-grade results)
+           bf16 MFMA weight GEMMs (plain bf16 operands by default; --prec bf16x3: split-bf16, 2^-18 per operand)
   powerlaw config 5: power-law degrees, max degree 4096
 """
 from __future__ import annotations
@@ -34,7 +34,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
 # config 2 is quoted in fp32; config 3 / 4 state "bf16 MFMA weight GEMM": plain bf16 operands, fp32 accumulate and fp32
-# activations (--prec bf16x3 = split-bf16, fp32-grade results at three MFMA passes; --prec f32 = the fp32 MFMA path)
+# activations (--prec bf16x3 = split-bf16, hi + lo = 16 significand bits per operand at three MFMA passes: every gradient of the
+# config-3 step within 3e-6 of an fp64 reference on the same side of the ReLU kinks; --prec f32 = the fp32 MFMA path)
 CONFIG_PREC = {"ecoli": "f32", "block1m": "bf16", "powerlaw": "bf16x3"}
 
 
@@ -299,7 +300,7 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--prec", default=None, choices=["f32", "bf16", "bf16x3"],
                     help="GEMM arithmetic; default per workload: ecoli f32 (config 2 is an fp32 config), block1m / powerlaw "
-                         "bf16x3 (config 3's bf16 MFMA weight GEMM as split-bf16: three MFMA passes, fp32-grade results)")
+                         "bf16x3 (config 3's bf16 MFMA weight GEMM as split-bf16: three MFMA passes, 2^-18 relative per operand)")
     ap.add_argument("--model", default="gcn2", choices=["gcn2", "generalgnn"],
                     help="gcn2 = the BN-free 2-layer GCNConv model of BASELINE.md (default, the metric's model); "
                          "generalgnn = the reference's live model gcn.py:320 (F_in=16, hidden=256; single GPU)")
@@ -466,7 +467,7 @@ def main():
             "config": {"workload": {"ecoli": "config2: E. coli-shaped DisjointLoader batch, B=32 graphs per GPU, F=128, fp32, "
                                              "2-layer GCNConv(relu)+GlobalSumPool+Dense softmax, CCE (from-logits form of tf.function), SGD",
                                     "block1m": f"config3/4: 1M-node/10M-entry disjoint batch, F=256, same model, weight GEMMs {args.prec} "
-                                               "(bf16x3 = split-bf16 on the bf16 MFMA, fp32-grade; bf16 = plain bf16 operands)",
+                                               "(bf16x3 = split-bf16 on the bf16 MFMA, 2^-18 per operand; bf16 = plain bf16 operands)",
                                     "powerlaw": f"config5: power-law degrees (max 4096), 8192-node graphs, F=256, weight GEMMs {args.prec}"}[args.workload],
                        "global_graphs": global_graphs, "nodes_per_gpu": hb.n, "nnz_per_gpu": hb.nnz, "features": hb.f,
                        "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32"

@@ -57,7 +57,7 @@ typedef enum {
 typedef enum { GCNX_ACT_NONE = 0, GCNX_ACT_RELU = 1, GCNX_ACT_PRELU = 2 } gcnx_act;
 typedef enum { GCNX_POOL_SUM = 0, GCNX_POOL_AVG = 1, GCNX_POOL_MAX = 2 } gcnx_pool;
 /* GEMM arithmetic: F32 = exact fp32 MFMA (v_mfma_f32_*_f32); BF16 = inputs rounded to bf16,
- * fp32 accumulate; BF16X3 = hi/lo bf16 split, three MFMA passes, fp32-grade accuracy. */
+ * fp32 accumulate; BF16X3 = hi/lo bf16 split (16 significand bits per operand, 2^-18 relative), three MFMA passes. */
 typedef enum { GCNX_PREC_F32 = 0, GCNX_PREC_BF16 = 1, GCNX_PREC_BF16X3 = 2 } gcnx_prec;
 typedef enum { GCNX_NORM_SPEKTRAL = 0, GCNX_NORM_PYG = 1 } gcnx_norm_mode;
 typedef enum { GCNX_RED_SUM = 0, GCNX_RED_MAX = 1 } gcnx_redop;
