@@ -313,6 +313,11 @@ def main():
                     help="untimed repetitions of the step before the timed region until this much wall time has passed "
                          "(0 = none); reported as burn_in in the JSON line")
     ap.add_argument("--allow-knobs", action="store_true", help="run although GCNX_* tuning knobs are set (they are recorded)")
+    ap.add_argument("--emulate-rank", type=int, default=None, metavar="R",
+                    help="single-GPU proxy of an N-GPU run (VERDICT r2, next 3): build rank R's shard of the workload as --of N "
+                         "ranks would cut it (shard.partition_by_cost, loss normalised by the GLOBAL batch) and run its step on "
+                         "this one GPU without a communicator; scripts/scaling_proxy.py takes the max over R against the 1-GPU step")
+    ap.add_argument("--of", type=int, default=8, metavar="N", help="world size --emulate-rank cuts the workload for")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.prec is None:
@@ -344,7 +349,12 @@ def main():
     if args.model == "generalgnn":
         return bench_generalgnn(ctx, args)
     comm = gcomm.Communicator(ctx, rank, world)
-    hb, hidden, global_graphs = make_shard(args.workload, rank, world, scaling)
+    if args.emulate_rank is not None:
+        if world != 1 or not 0 <= args.emulate_rank < args.of:
+            raise SystemExit("--emulate-rank R --of N is a single-process mode with 0 <= R < N")
+        hb, hidden, global_graphs = make_shard(args.workload, args.emulate_rank, args.of, scaling)
+    else:
+        hb, hidden, global_graphs = make_shard(args.workload, rank, world, scaling)
 
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, hb.vals, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
@@ -486,6 +496,14 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr, "traffic_source": src, "algorithmic_bytes": alg, "avg_launch_us": 1e3 * spmm_ms, "launches": iters},
         }
+        if args.emulate_rank is not None:
+            # `value` stays this process's own rate (its shard's graphs per second); the proxy's reading is ms_per_step
+            shard_graphs = hb.n_graphs
+            rec["value"] = shard_graphs * args.steps / elapsed
+            rec["emulated"] = {"rank": args.emulate_rank, "of": args.of, "scaling": scaling, "shard_graphs": shard_graphs,
+                               "global_graphs": global_graphs, "shard_cost_nnz_plus_n": int(hb.nnz + hb.n),
+                               "what": "rank R's shard of an N-rank run on ONE GPU, no communicator: the step time a rank would "
+                                       "need before its all-reduce; NOT a multi-GPU measurement"}
         if knobs:
             rec["env_knobs"] = knobs
         if fused is not None:
@@ -493,7 +511,7 @@ def main():
         if big is not None:
             rec["roofline_config3"] = big
             rec["roofline_config3_bf16"] = big_bf16
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and args.emulate_rank is None:
             rec["cpu_baseline"] = cpu_baseline(hb, hidden, params0, args.cpu_seconds)
             if args.scipy_seconds > 0:
                 rec["cpu_baseline_scipy"] = cpu_baseline_scipy(hb, hidden, params0, args.scipy_seconds)

@@ -1132,8 +1132,12 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
   // 1024-thread shape, 8 slabs = 1.9 units by 10 %)
   const int slabs = f / FT;
   int sg = 1;
+  // (r3, one workgroup per CU: >= 1.5 units per workgroup is enough -- the snake deal pairs the tall graphs of the first
+  // round with the short ones of the second -- and at the shard sizes of an 8-GPU run the larger slab groups win:
+  // 200 graphs: 4 slabs per unit 80 us against 85 (2) and 107 (8: fewer units than CUs); 400 graphs: 8 slabs 153 against 156)
+  const long long need = THREADS == 512 ? 6LL * full : 3LL * full;            // in half units
   for (int c = 8; c > 1; c >>= 1)
-    if (slabs % c == 0 && (long long)ngraphs * (slabs / c) >= 3LL * full) { sg = c; break; }
+    if (slabs % c == 0 && 2LL * ngraphs * (slabs / c) >= need) { sg = c; break; }
   if (ctx->knob_spmm_sg >= 1 && slabs % ctx->knob_spmm_sg == 0) sg = ctx->knob_spmm_sg;
   const int upg = slabs / sg;
   const long long nunits = (long long)ngraphs * upg;
@@ -1316,7 +1320,7 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     std::vector<int2> t1, t2, ch;
     std::vector<std::pair<int, int>> by_row;       // (row0, graph index) of the tile graphs
     long long tile_rows = 0;
-    const int cap1 = kDuoCap32, cap2 = kSoloCap32;
+    const int cap1 = ctx->knob_spmm_cap1 >= 0 ? std::min(ctx->knob_spmm_cap1, kDuoCap32) : kDuoCap32, cap2 = kSoloCap32;
     // graphs taller than any tile go to the row gather as plan-listed chunks.  8-row chunks (r3): the gather re-reads a
     // graph's feature rows ~degree times and only the XCD's 4 MiB L2 can serve that; with 32-row chunks 7 workgroups per CU
     // x 32 CUs hold ~7 000 rows = 4-5 such graphs (2 MB of features each) in flight per XCD and the re-reads went to HBM

@@ -161,7 +161,8 @@ class GCN2(_GraphRunner):
         self._knob = {"fold": os.environ.get("GCNX_FOLD", "1") != "0", "duo": os.environ.get("GCNX_DUO", "1") != "0",
                       "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1")),
                       "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0",
-                      "s_order": os.environ.get("GCNX_S_ORDER", "1") != "0"}
+                      "s_order": os.environ.get("GCNX_S_ORDER", "1") != "0",
+                      "buckets": os.environ.get("GCNX_COMM_BUCKETS", "1") != "0"}
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
@@ -303,9 +304,12 @@ class GCN2(_GraphRunner):
         else:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], None, bufs["probs"], **head)
 
-    def _backward(self, batch, bufs, lr=None):
-        """All gradients; with ``lr`` (single process) the SGD step too -- returns True if it was applied here."""
+    def _backward(self, batch, bufs, lr=None, buckets=False):
+        """All gradients; with ``lr`` (single process) the SGD step too -- returns True if it was applied here.
+        buckets (multi-GPU): the gradient all-reduce is issued from here in two buckets where the sequence allows it
+        (the two-launch layers of large batches); ``self._reduced_in_backward`` tells the caller."""
         ctx, p, g, prec = self.ctx, self.p, self.g, self.prec
+        self._reduced_in_backward = False
         at = batch.a.transpose()
         # The gradient leaves of layer 2 (db2, dW2: nothing later in the backward pass reads them) run in ONE side
         # section, concurrently with the main chain dX -> db1 -> A^T -> dW1.  One fork and one join per step: each
@@ -344,8 +348,12 @@ class GCN2(_GraphRunner):
             if lr is None:
                 D.dense_bwd(ctx, bufs["y1"], bufs["h"], p["w2"], bufs["dz2"], g["w2"], prec=prec, y_mask=bufs["y1"],
                             db_prev=g["b1"])                                   # dW2, dZ1, db1
+                if buckets:
+                    self._allreduce_tail_bucket()                              # beside layer 1's dW (and its aggregation)
                 xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
                 D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                    # dW1 = X^T (A^T dZ1) or S1^T dZ1
+                if buckets:
+                    self._allreduce_head_bucket()
                 return False
             # With the update in the same step, the reductions that finish the leaves dW2 / db1 wait for the last
             # launch: the split-K reduction of dW1 folds them in and applies the SGD step to every parameter.
@@ -365,11 +373,41 @@ class GCN2(_GraphRunner):
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
             # (folded: db2 came out of the head -- from the pool's own count of positive entries)
             D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
+        if buckets:
+            # Multi-GPU ("enqueue behind the layer-1 dW GEMM"): the gradients of layers 2 and 3
+            # and the metric tail -- {dW2, db2, dW3, db3, loss, #correct}, the contiguous tail of the flat buffer -- are
+            # final here, so their all-reduce runs on the side stream while layer 1's backward (dX, dW1: two of the step's
+            # five weight GEMMs) runs on the main one; {dW1, db1} follows as a second bucket behind the join (collectives of
+            # one communicator never overlap each other).  A transport that cannot be captured (the thread-rank test
+            # communicator reduces through the host) issues the same two buckets in line.
+            ctx.join()
+            self._allreduce_tail_bucket()
         D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"],
                   mask_bits=bufs["y1bits"] if bufs.get("y1bits_ok") else None)                       # dZ1, db1
         xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
         D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                            # dW1 = X^T (A^T dZ1) or S1^T dZ1
         ctx.join()
+        if buckets:
+            self._allreduce_head_bucket()
+
+    def _allreduce_tail_bucket(self):
+        """{dW2, db2, dW3, db3, loss, #correct}: on the side stream (a second branch of a captured step) when the transport
+        enqueues on a stream; in line otherwise."""
+        import contextlib
+        off = self._bucket_split()
+        tail = self.flat_g.flat(off, self.n_params + 2 - off)
+        with (self.ctx.side() if getattr(self.comm, "capturable", False) else contextlib.nullcontext()):
+            self.comm.allreduce_sum(tail)
+
+    def _allreduce_head_bucket(self):
+        """{dW1, db1}, behind the join: collectives of one communicator never overlap each other."""
+        self.ctx.join()
+        self.comm.allreduce_sum(self.flat_g.flat(0, self._bucket_split()))
+        self._reduced_in_backward = True
+
+    def _bucket_split(self):
+        """First element of the all-reduce's second-layer bucket in the flat gradient buffer: [w1, b1 | w2, b2, w3, b3, loss, acc]."""
+        return int(np.prod(self.p["w1"].shape)) + int(np.prod(self.p["b1"].shape))
 
     def _s_order(self):
         """Layer 1 as (A X) W1 in the two-launch (non-fused) paths: when the aggregation is not wider that way (F <= H)."""
@@ -476,11 +514,15 @@ class GCN2(_GraphRunner):
         multi = self._world() > 1
         fused_comm = multi and _lr is not None and self._comm_in_graph()
 
+        # (the bucketed form needs the side stream inside the step: with a capturable communicator only when the collective
+        # is recorded into the step graph anyway, or the step runs eagerly)
+        buckets = multi and self._knob["buckets"] and (fused_comm or not self.use_graph)
+
         def seq():
             self._forward(batch, bufs, "grads", denom)
-            if self._backward(batch, bufs, None if multi else _lr):
+            if self._backward(batch, bufs, None if multi else _lr, buckets=buckets):
                 return
-            if fused_comm:
+            if fused_comm and not self._reduced_in_backward:
                 self.comm.allreduce_sum(self.flat_g)
             if _lr is not None and (fused_comm or not multi):
                 # the update rides in the same captured graph (one graph launch per step)
@@ -500,7 +542,7 @@ class GCN2(_GraphRunner):
             self._comm_capture_failed = True
             self._drop_graphs()
             return self.loss_and_grads(batch, None, global_batch, _lr)
-        if multi and not fused_comm:
+        if multi and not fused_comm and not self._reduced_in_backward:
             self.comm.allreduce_sum(self.flat_g)
         self._last_batch = batch
         return batch

@@ -15,11 +15,18 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--slabs", default="0")
 ap.add_argument("--unweighted", action="store_true")
+ap.add_argument("--shard", default="", help="r,w: rank r's shard of w (block1m; the cut bench.py makes)")
 ap.add_argument("--conc", type=int, default=-1, help="1 / 0: the plan path's launches as concurrent branches or not (spmm_conc)")
 args = ap.parse_args()
 if args.workload == "block1m":       # the batches bench.py times (per-graph-seeded generators)
     sizes, pairs = synth.block_diag_plan()
-    hb = synth.block_diag_shard(0, len(sizes), sizes, pairs, 256, seed=2, with_x=False); f = 256
+    lo, hi = 0, len(sizes)
+    if args.shard:
+        from gcnx import shard as _sh
+        r, w = (int(v) for v in args.shard.split(","))
+        bounds = _sh.partition_by_cost(sizes + 2 * pairs + sizes, w)
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+    hb = synth.block_diag_shard(lo, hi, sizes, pairs, 256, seed=2, with_x=False); f = 256
 elif args.workload == "ecoli":
     hb = synth.ecoli_shard(0, 32, 128, seed=1); f = 128
 else:

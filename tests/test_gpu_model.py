@@ -328,11 +328,14 @@ def test_rccl_path_single_rank(ctx):
     assert np.array_equal(d.numpy(), x) and float(c1.allreduce_host([3.5], "max")[0]) == 3.5
 
 
-def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx):
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx, hidden):
     """The code path a rank of an N-GPU run takes -- gradients (fold-only reductions), ncclAllReduce and SGD recorded into
     ONE HIP graph -- with a real RCCL communicator.  One GPU is all there is here, so the communicator has one rank and
     the wrapper only CLAIMS a world of two: the collective is then the identity and the step must equal the plain
-    single-process step bit for bit (same kernels, same order), through capture and replay."""
+    single-process step bit for bit (same kernels, same order), through capture and replay.  hidden = 128: the one-launch
+    layers with one flat all-reduce; hidden = 256: the two-launch layers, the all-reduce in two buckets -- the first on the
+    side stream (a second branch of the captured graph) beside layer 1's backward."""
     import ctypes as C
     from gcnx import _lib as L, synth
     from gcnx.comm import Communicator
@@ -348,13 +351,14 @@ def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx):
             ctx._ck(ctx.lib.gcnx_comm_init_rank(ctx.h, uid.raw, 1, 0, C.byref(h)))
             self.h, self._scratch, self._path = h, ctx.zeros(4), None
 
-    hb = synth.ecoli_batch(6, 128, seed=21)
+    # (hidden = 256: 130 graphs, so that the batch has a tile plan and takes the large-batch sequence the buckets live in)
+    hb = synth.ecoli_batch(6 if hidden == 128 else 130, 128, seed=21)
     vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
 
     def run(comm):
         a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
         batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
-        m = GCN2(ctx, 2, seed=5, comm=comm)
+        m = GCN2(ctx, 2, hidden=hidden, seed=5, comm=comm)
         out = [m.train_step(batch, None, lr=0.05, global_batch=hb.n_graphs) for _ in range(4)]   # eager, capture, replay x2
         return m, out
 
@@ -362,8 +366,9 @@ def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx):
     try:
         m2, o2 = run(comm)
         assert m2._comm_in_graph() and not getattr(m2, "_comm_capture_failed", False)
-        assert m2._fused(DeviceBatch(ctx, ctx.to_device(hb.x), DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr),
-                                     Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y)))
+        assert (hidden == 128) == m2._fused(DeviceBatch(ctx, ctx.to_device(hb.x), DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr),
+                                                        Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y)))
+        assert m2._reduced_in_backward == (hidden == 256)
         m1, o1 = run(None)
         assert o1 == o2
         for w1, w2 in zip(m1.get_weights(), m2.get_weights()):
@@ -372,11 +377,15 @@ def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx):
         comm.close()
 
 
-def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
+@pytest.mark.parametrize("hidden,n_calls", [(32, 1), (48, 2)])
+def test_gcn2_world_size_2_on_one_gpu_equals_single_rank(hidden, n_calls):
     """The sharded step on the DEVICE path at world_size 2: two ranks (threads, each with its own Context on device
     0, a host-mediated communicator of the Communicator interface, tests/thread_comm.py) take graph shards of one
-    batch, normalise the loss by the global batch, all-reduce the flat gradient (+ loss/accuracy tail) once and
-    apply SGD -- and land on the 1-rank loss, accuracy, gradients and updated weights (fp32 reduction order)."""
+    batch, normalise the loss by the global batch, all-reduce the flat gradient (+ loss/accuracy tail) and
+    apply SGD -- and land on the 1-rank loss, accuracy, gradients and updated weights (fp32 reduction order).
+    hidden = 32: the one-launch layers, ONE flat all-reduce; hidden = 48: the two-launch layers of large batches, where
+    the all-reduce goes out in two buckets (r3) -- {dW2, db2, dW3, db3, metrics} as soon as layer 2's gradients are
+    final, {dW1, db1} behind layer 1's backward."""
     import gcnx
     from gcnx import synth, shard
     from gcnx.models import DeviceBatch, GCN2
@@ -392,7 +401,7 @@ def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
         return DeviceBatch(ctx, ctx.to_device(part.x), a, seg, ctx.to_device(part.y, np.float32))
 
     ctx0 = gcnx.Context(0)
-    ref = GCN2(ctx0, 2, hidden=32, seed=5, use_graph=False)
+    ref = GCN2(ctx0, 2, hidden=hidden, seed=5, use_graph=False)
     ref_loss, ref_acc = ref.train_step(make_batch(ctx0, hb), None, lr=0.05)
     ref_g, ref_w = ref.gradients(), ref.get_weights()
     ctx0.close()
@@ -400,7 +409,7 @@ def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
     def rank_fn(rank, make_comm):
         ctx = gcnx.Context(0)
         part, global_b = shard.shard_batch(hb, rank, 2)
-        m = GCN2(ctx, 2, hidden=32, seed=5, use_graph=False, comm=make_comm(ctx))
+        m = GCN2(ctx, 2, hidden=hidden, seed=5, use_graph=False, comm=make_comm(ctx))
         loss, acc = m.train_step(make_batch(ctx, part), None, lr=0.05, global_batch=global_b)
         out = (loss, acc, m.gradients(), m.get_weights(), m.comm.calls)
         ctx.close()
@@ -408,7 +417,7 @@ def test_gcn2_world_size_2_on_one_gpu_equals_single_rank():
 
     res = ThreadWorld(2).run(rank_fn)
     for loss, acc, g, w, calls in res:
-        assert calls == 1                                  # ONE all-reduce per step
+        assert calls == n_calls                            # one flat all-reduce, or the two buckets
         assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)) and acc == pytest.approx(ref_acc)
         for k in g:
             assert rel_err(g[k], ref_g[k]) < 2e-5, k
