@@ -87,6 +87,10 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
 // `slabs` (room for max_slices of them) and returns the number of slices; 0 = shape not handled, < 0 = launch error.
 int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* slabs, int64_t n,
                         int32_t fi, int32_t fo, int prec, int max_slices);
+// gemm_stream.hip: X^T dH for fi = 256 p, fo = 256 at mid-size batches (n >= 2048): streaming kernel over (row slices) x (column
+// panels of x) + one reduction launch, result in dw.  1 = ran, 0 = shape not served, < 0 = launch error.
+int gcnx_gemm_dw_panels(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n,
+                        int32_t fi, int32_t fo, int prec);
 #ifdef __HIPCC__
 // Column sums of a few hundred partial rows [rows][f] (f % 4 == 0): workgroup bx owns 8 columns (two float4 lanes)
 // x 128 row groups and folds the 128 partial sums in a fixed tree through LDS.  (colsum_kernel's 64 columns x 16 row

@@ -1215,6 +1215,11 @@ int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, in
         return GCNX_OK;
       }
     }
+    if (n < 32 * 1024 || fi != 256) {      // mid-size batches / wide inputs (GeneralGNN): panels of the streaming kernel
+      const int pr = gcnx_gemm_dw_panels(ctx, x, ldx, dh, lddh, dw, n, fi, fo, prec);
+      if (pr < 0) return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_gemm_dw: streaming kernel (panels) launch failed");
+      if (pr > 0) return GCNX_OK;
+    }
     const int tiles_h = gcnx_cdiv(fi, HM) * gcnx_cdiv(fo, HN);
     int ns = (int)((4LL * ctx->num_cus + tiles_h - 1) / tiles_h);
     const int64_t ksteps_h = (n + HK - 1) / HK;

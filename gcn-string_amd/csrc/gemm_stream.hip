@@ -526,7 +526,10 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
   const int64_t r_end = min(n, r_begin + rows_per_wg);
   const int nsteps = r_begin < r_end ? (int)((r_end - r_begin + 31) / 32) : 0;
 
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)((uint64_t)n * (uint64_t)ldx * 4u), 0x00020000);
+  // blockIdx.y (r3): a 256-column panel of a wider x -- dW of a Dense layer with fi = 256 p inputs (GeneralGNN's concat
+  // skips) as p products over the same row slices; panel q's slabs follow panel q - 1's
+  x += (size_t)blockIdx.y * 256;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)((uint64_t)n * (uint64_t)ldx * 4u - (uint64_t)blockIdx.y * 1024u), 0x00020000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)dh, (short)0, (int)((uint64_t)n * (uint64_t)lddh * 4u), 0x00020000);
   const unsigned ldx4 = (unsigned)ldx * 4u, ldd4 = (unsigned)lddh * 4u;
   // staging: thread -> row (tid >> 6) + 8 j (j = 0..3), columns 4 (tid & 63) .. + 3
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 #undef DW_ISSUE
 #undef DW_WRITE
   // C[row = o within tile (lane >> 4) * 4 + reg][col = i within tile (lane & 15)]: a lane holds dW[i][o .. o + 3]
-  float* slab = out + (size_t)blockIdx.x * 65536;
+  float* slab = out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 65536;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -611,6 +614,60 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 
 // Slabs [nslices][256 * 256] in `slabs` (caller reduces them in slice order); returns the number of slices, 0 when
 // the shape is not one this kernel is built for.
+// Slab reduction of the panel form: dw[p * 65536 + e] = sum over the slices, in slice order, of slabs[(p * nslices + s)][e].
+__global__ __launch_bounds__(256) void dw_panel_reduce_kernel(const float* __restrict__ slabs, int nslices, float* __restrict__ dw) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const float* p = slabs + (size_t)blockIdx.y * nslices * 65536 + e;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 4 <= nslices; s += 4) {                       // four slabs in flight per thread, added in slice order
+    const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)(s + 0) * 65536), v1 = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * 65536);
+    const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(s + 2) * 65536), v3 = *reinterpret_cast<const float4*>(p + (size_t)(s + 3) * 65536);
+    acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+    acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+    acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+  }
+  for (; s < nslices; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * 65536);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dw + (size_t)blockIdx.y * 65536 + e) = acc;
+}
+
+// dW[fi, 256] = X^T dH for fi = 256 p (p <= 8) at mid-size batches (GeneralGNN: n = 22 576): the streaming kernel over
+// (row slices) x (256-column panels of x), one workgroup per CU in all, then one reduction launch.  Returns 1 when it
+// ran, 0 when the shape is not served (the caller takes gcnx_gemm_dw's tiled path), < 0 on a launch error.
+int gcnx_gemm_dw_panels(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* dw, int64_t n,
+                        int32_t fi, int32_t fo, int prec) {
+  if (ctx->knob_gemm_stream == 0 || fo != 256 || fi % 256 != 0 || fi < 256 || fi > 2048 || n < 2048 || prec == GCNX_PREC_F32) return 0;
+  if (ldx % 4 || lddh % 4 || !sal16(x) || !sal16(dh) || !sal16(dw) || (uint64_t)n * (uint64_t)ldx * 4u >= 0xFFFFFF00ull ||
+      (uint64_t)n * (uint64_t)lddh * 4u >= 0xFFFFFF00ull)
+    return 0;
+  const int panels = fi / 256;
+  const int64_t steps = (n + 31) / 32;
+  int slices = ctx->num_cus / panels;                       // one workgroup per CU over all panels ...
+  if (slices > steps / 6) slices = (int)(steps / 6);        // ... but no slice shorter than 6 steps (fill / drain of the pipeline)
+  if (slices < 1) slices = 1;
+  const int64_t rows_per = ((steps + slices - 1) / slices) * 32;
+  slices = (int)((n + rows_per - 1) / rows_per);
+  if (gcnx_ws_reserve(ctx, (size_t)panels * slices * 65536 * sizeof(float))) return -1;
+  const int np = prec == GCNX_PREC_BF16X3 ? 2 : 1;
+  const dim3 grid(slices, panels);
+  if (np == 2) {
+    static bool set2 = false;
+    if (!set2) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dw_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DwLds<2>::total) != hipSuccess) return -1; set2 = true; }
+    hipLaunchKernelGGL((gemm_dw_stream_kernel<2>), grid, dim3(512), DwLds<2>::total, ctx->stream, x, ldx, dh, lddh, (float*)ctx->ws, n, rows_per);
+  } else {
+    static bool set1 = false;
+    if (!set1) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dw_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DwLds<1>::total) != hipSuccess) return -1; set1 = true; }
+    hipLaunchKernelGGL((gemm_dw_stream_kernel<1>), grid, dim3(512), DwLds<1>::total, ctx->stream, x, ldx, dh, lddh, (float*)ctx->ws, n, rows_per);
+  }
+  if (hipGetLastError() != hipSuccess) return -1;
+  hipLaunchKernelGGL(dw_panel_reduce_kernel, dim3(65536 / 4 / 256, panels), dim3(256), 0, ctx->stream, (const float*)ctx->ws, slices, dw);
+  return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+
 int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* slabs, int64_t n,
                         int32_t fi, int32_t fo, int prec, int max_slices) {
   if (ctx->knob_gemm_stream == 0 || fi != 256 || fo != 256 || n < 32 * 1024 || prec == GCNX_PREC_F32) return 0;

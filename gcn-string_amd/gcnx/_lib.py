@@ -77,6 +77,11 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _i64, _vp, _int],
     "gcnx_act_bias_grad": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _int, _vp, _vp, _vp],
     "gcnx_gemm_dw": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int],
+    "gcnx_wimage_elems": [_i32, _i32, _int, _int],
+    "gcnx_wimage_prepare": [_vp, _i32, _vp],
+    "gcnx_gemm_wimage": [_vp, _vp, _i64, _vp, _i32, _i32, _int, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp],
+    "gcnx_gemm_wimage_parts": [_vp, _i64],
+    "gcnx_bn_finalize_parts": [_vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp],
     "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],
     "gcnx_gemm_relu_bits": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp],
     "gcnx_gemm_dx_bits": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp, _vp],
@@ -116,7 +121,13 @@ SIGNATURES = {
     "gcnx_allreduce_f32": [_vp, _vp, _vp, _i64, _int],
 }
 _RESTYPE = {"gcnx_last_error": C.c_char_p, "gcnx_dense_bwd_scratch_floats": C.c_int64,
-            "gcnx_gcn_conv_bwd_scratch_floats": C.c_int64}
+            "gcnx_gcn_conv_bwd_scratch_floats": C.c_int64, "gcnx_wimage_elems": C.c_int64, "gcnx_gemm_wimage_parts": C.c_int64}
+
+
+class WimageJob(C.Structure):
+    """gcnx_wimage_job (include/gcnx.h): one matrix of a gcnx_wimage_prepare launch."""
+    _fields_ = [("w", C.c_void_p), ("img", C.c_void_p), ("fi", C.c_int32), ("fo", C.c_int32), ("transpose", C.c_int32),
+                ("prec", C.c_int32)]
 
 
 class PendingReduce(C.Structure):

@@ -725,6 +725,46 @@ def bn_moments(ctx, z, sums, mean, inv, moving_mean=None, moving_var=None, momen
                                     _p(moving_var)))
 
 
+def wimage_elems(ctx, fi, fo, transpose, prec):
+    """bf16 elements of the weight image of W [fi, fo] (or of W^T) for gemm_wimage; 0 for prec "f32"."""
+    return int(ctx.lib.gcnx_wimage_elems(int(fi), int(fo), 1 if transpose else 0, L.PRECS[prec]))
+
+
+def wimage_prepare(ctx, jobs):
+    """ONE launch writes the images of several matrices: jobs = [(w, img, transpose, prec), ...] (gcnx_wimage_prepare)."""
+    if not jobs:
+        return
+    arr = (L.WimageJob * len(jobs))()
+    for k, (w, img, transpose, prec) in enumerate(jobs):
+        fi, fo = w.shape
+        arr[k] = L.WimageJob(w.ptr, img.ptr, fi, fo, 1 if transpose else 0, L.PRECS[prec])
+    ctx._ck(ctx.lib.gcnx_wimage_prepare(ctx.h, len(jobs), C.cast(arr, C.c_void_p)))
+
+
+def gemm_wimage(ctx, x, img, fi, fo, out, transpose=False, bias=None, prec="bf16x3", accumulate=False, bn_parts=None):
+    """out = x W + bias (transpose False) / out (+)= x W^T (True) with W read from its image (gcnx_gemm_wimage).  Returns
+    None when the kernel does not serve the shape (nothing launched), else the number of batch-norm parts written to
+    ``bn_parts`` (0 without)."""
+    n = x.shape[0]
+    nparts = C.c_int32(0)
+    rc = ctx.lib.gcnx_gemm_wimage(ctx.h, _p(x), x.ld, img.ptr, int(fi), int(fo), 1 if transpose else 0, _p(bias), _p(out), out.ld, n,
+                                  L.PRECS[prec], 1 if accumulate else 0, _p(bn_parts), C.byref(nparts) if bn_parts is not None else None)
+    if rc == L.ERR_UNSUPPORTED:
+        return None
+    ctx._ck(rc)
+    return nparts.value
+
+
+def gemm_wimage_parts(ctx, n):
+    return int(ctx.lib.gcnx_gemm_wimage_parts(ctx.h, int(n)))
+
+
+def bn_finalize_parts(ctx, parts, nparts, mean, inv, moving_mean=None, moving_var=None, momentum=BN_MOMENTUM, eps=BN_EPS):
+    """mean / inv (and the moving statistics) from the (rows, mean, M2) parts gemm_wimage left (gcnx_bn_finalize_parts)."""
+    ctx._ck(ctx.lib.gcnx_bn_finalize_parts(ctx.h, _p(parts), int(nparts), mean.size, momentum, eps, _p(mean), _p(inv),
+                                           _p(moving_mean), _p(moving_var)))
+
+
 def bn_act(ctx, z, mean, inv, gamma, beta, y, act=None, alpha=None):
     n, f = z.shape
     ctx._ck(ctx.lib.gcnx_bn_act(ctx.h, _p(z), z.ld, n, f, _p(mean), _p(inv), _p(gamma), _p(beta), L.ACTS[act], _p(alpha),

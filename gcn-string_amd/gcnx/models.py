@@ -616,6 +616,7 @@ class GeneralGNN(_GraphRunner):
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
+        self._images_fresh, self._img_jobs = False, []
 
     # ---- parameters ------------------------------------------------------------------------------
     def build(self, f_in):
@@ -656,6 +657,27 @@ class GeneralGNN(_GraphRunner):
             L["moving_var"].copy_from_host(np.ones(fo, np.float32))
             self.layers.append(L)
         self.f_in, self.built = f_in, True
+        self._alloc_images()
+
+    def _alloc_images(self):
+        """bf16 / bf16x3: weight images (MFMA-fragment order, csrc/gemm_panel.hip) of every Dense layer that runs on node
+        rows -- the operand of X W and, where the layer's input needs a gradient, of dH W^T.  One launch per step rewrites
+        them all (the weights change with every update)."""
+        self._img_jobs = []
+        self._img_prec = self.prec
+        if self.prec == "f32":
+            return
+        ctx = self.ctx
+        for i, L in enumerate(self.layers):
+            L.pop("img_fwd", None); L.pop("img_bwd", None)
+            if L["group"] == "post" or L["fo"] % 16 or L["fi"] % 4:
+                continue
+            ef = D.wimage_elems(ctx, L["fi"], L["fo"], False, self.prec)
+            L["img_fwd"] = ctx.empty(ef, np.uint16)
+            self._img_jobs.append((L["kernel"], L["img_fwd"], False, self.prec))
+            if i > 0 and L["fi"] % 16 == 0:
+                L["img_bwd"] = ctx.empty(D.wimage_elems(ctx, L["fi"], L["fo"], True, self.prec), np.uint16)
+                self._img_jobs.append((L["kernel"], L["img_bwd"], True, self.prec))
 
     WEIGHT_ORDER = ("kernel", "bias", "gamma", "beta", "moving_mean", "moving_var", "alpha")
     # Order of one layer's arrays in get_weights() / set_weights() (model.get_weights() at gcn.py:383 feeds the .npz dump;
@@ -722,7 +744,21 @@ class GeneralGNN(_GraphRunner):
 
     def _dense_bn(self, L, x, z, y, training):
         ctx = self.ctx
-        D.gemm(ctx, x, L["kernel"], L["bias"], z, prec=self.prec)
+        if "img_fwd" in L and self._images_fresh:
+            # split-bf16 panel GEMM (csrc/gemm_panel.hip); in single-device training its epilogue also leaves the batch-norm
+            # statistics of what it writes, as (rows, mean, M2) per workgroup: no pass over z for the moments
+            fused_bn = training and not self._multi() and L["fo"] <= 256
+            parts = self._bn_parts(x.shape[0], L["fo"]) if fused_bn else None
+            nparts = D.gemm_wimage(ctx, x, L["img_fwd"], L["fi"], L["fo"], z, bias=L["bias"], prec=self.prec, bn_parts=parts)
+            if nparts is not None:
+                if fused_bn:
+                    D.bn_finalize_parts(ctx, parts, nparts, L["mean"], L["inv"], L["moving_mean"], L["moving_var"])
+                    D.bn_act(ctx, z, L["mean"], L["inv"], L["gamma"], L["beta"], y, act=L["act"], alpha=L.get("alpha"))
+                    return
+            else:
+                D.gemm(ctx, x, L["kernel"], L["bias"], z, prec=self._prec_of(L))
+        else:
+            D.gemm(ctx, x, L["kernel"], L["bias"], z, prec=self._prec_of(L))
         if training and self._multi():
             # sync-BN: the two moment passes with their column sums all-reduced and the GLOBAL row count
             count = self._counts["b" if L["group"] == "post" else "n"]
@@ -779,14 +815,29 @@ class GeneralGNN(_GraphRunner):
             D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
                          alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
                          dalpha=L.get("g_alpha"))
-        D.act_bias_grad(ctx, dz, None, dz, None, db=L["g_bias"])
+        if training and "img_fwd" in L and self._images_fresh:
+            # The Dense bias under a training-mode BatchNorm has the gradient sum_rows dz = gamma inv (sum g - n mean(g) -
+            # mean(g xhat) sum xhat) = 0 identically (sum xhat = 0): TensorFlow evaluates that sum and returns rounding
+            # noise of order 1e-8; the fast path writes the exact value instead of passing over dz once more.
+            pass                                           # (loss_and_grads zeroes the whole flat gradient buffer once per step)
+        else:
+            D.act_bias_grad(ctx, dz, None, dz, None, db=L["g_bias"])
+        if "img_fwd" in L and self._images_fresh and (dx is None or "img_bwd" in L):
+            D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=self.prec)           # (fi = 256 p: panels of the streaming kernel)
+            if dx is None:
+                return
+            if D.gemm_wimage(ctx, dz, L["img_bwd"], L["fi"], L["fo"], dx, transpose=True, prec=self.prec, accumulate=accumulate) is not None:
+                return
+            D.gemm_dx(ctx, dz, L["kernel"], dx, prec=self.prec, accumulate=accumulate)
+            return
+        prec = self._prec_of(L)
         if dx is not None and not accumulate:
             # both products of the layer in one launch pair (gcnx_dense_bwd; falls back inside for ragged widths)
-            D.dense_bwd(ctx, x, dz, L["kernel"], dx, L["g_kernel"], prec=self.prec)
+            D.dense_bwd(ctx, x, dz, L["kernel"], dx, L["g_kernel"], prec=prec)
         else:
-            D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=self.prec)
+            D.gemm_dw(ctx, x, dz, L["g_kernel"], prec=prec)
             if dx is not None:
-                D.gemm_dx(ctx, dz, L["kernel"], dx, prec=self.prec, accumulate=accumulate)
+                D.gemm_dx(ctx, dz, L["kernel"], dx, prec=prec, accumulate=accumulate)
 
     def _backward(self, batch, bufs, training=True):
         h, mp = self.hidden, self.mp
@@ -819,6 +870,28 @@ class GeneralGNN(_GraphRunner):
             self._bwd_dense_bn(L, d, x, bufs[f"z{li}"], dx, training)
             d = dx; li -= 1
 
+    def _prec_of(self, L):
+        """Arithmetic of a layer's products outside the panel kernels: the post-MLP runs on B rows (32 graphs): a few MFLOP
+        for which the bf16 tile kernels' operand images cost more than the products (28 us per launch against the fp32
+        tiles' few) -- exact fp32 there."""
+        return "f32" if L["group"] == "post" else self.prec
+
+    def _bn_parts(self, rows, fo):
+        """Scratch for one layer's batch-norm parts [(rows, mean, M2) x workgroups x fo] (consumed before the next layer runs)."""
+        need = 3 * max(D.gemm_wimage_parts(self.ctx, rows), 1) * fo
+        cur = getattr(self, "_bn_parts_buf", None)
+        if cur is None or cur.size < need:
+            self._bn_parts_buf = self.ctx.empty(need)
+        return self._bn_parts_buf
+
+    def _prepare_images(self):
+        """The weight images of this step's forward and backward products, all in one launch."""
+        if getattr(self, "_img_prec", None) != self.prec:       # (the precision was switched after build)
+            self._alloc_images()
+        self._images_fresh = bool(self._img_jobs)
+        if self._img_jobs:
+            D.wimage_prepare(self.ctx, self._img_jobs)
+
     def _tmp(self, bufs, key, shape):
         if key not in bufs or bufs[key].shape != tuple(shape):
             if getattr(self, "_cap", None) is None:
@@ -840,6 +913,7 @@ class GeneralGNN(_GraphRunner):
     def __call__(self, inputs, training=False):
         batch = self._as_batch(inputs)
         bufs = self._ensure(batch)
+        self._prepare_images()
         logits = self._forward(batch, bufs, training)
         la = self._tmp(bufs, "la_scratch", (2,))
         la.fill_zero()
@@ -867,8 +941,12 @@ class GeneralGNN(_GraphRunner):
                       and not getattr(self, "_comm_capture_failed", False))
 
         def seq():
+            self._prepare_images()
             logits = self._forward(batch, bufs, True)
-            self.loss_acc.fill_zero()
+            if self._images_fresh:
+                self.flat_g.fill_zero()                    # loss / accuracy tail and the analytically zero bias gradients: one memset
+            else:
+                self.loss_acc.fill_zero()
             D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom, cce=self.cce_train)
             self._backward(batch, bufs, True)
             if fused_comm:
@@ -911,6 +989,7 @@ class GeneralGNN(_GraphRunner):
     def evaluate_batch(self, inputs, target):
         batch = self._as_batch(inputs, target)
         bufs = self._ensure(batch)
+        self._prepare_images()
         logits = self._forward(batch, bufs, False)
         self.loss_acc.fill_zero()
         D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, None, batch.n_graphs, cce=self.cce_eval)

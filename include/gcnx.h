@@ -175,6 +175,32 @@ GCNX_API int gcnx_csr_transpose(gcnx_ctx* ctx, const int32_t* rowptr, const int3
 GCNX_API int gcnx_gemm(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* w, const float* bias,
               float* out, int64_t ldo, int64_t n, int32_t fi, int32_t fo, int prec, int act,
               const float* alpha);
+/* Split-bf16 weight GEMMs for mid-size batches (r3; csrc/gemm_panel.hip): the Dense products of the reference's live
+ * model GeneralGNN (gcn.py:320; MatMul + BiasAdd and the MatMul grad wrt the input, gcn.py:334/337) with the weight
+ * operand read from a bf16 IMAGE in MFMA-fragment order.  gcnx_wimage_elems: bf16 elements of the image of W [fi, fo]
+ * (transpose = 0: the operand of X W) or of W^T (transpose = 1: the operand of dH W^T); 0 for GCNX_PREC_F32.
+ * gcnx_wimage_prepare: ONE launch writes the images of up to 16 matrices (per step: the weights change with every
+ * update).  gcnx_gemm_wimage: out[n, fo] = x[n, fi] W + bias (transpose = 0) or out[n, fi] (+)= x[n, fo] W^T
+ * (transpose = 1; accumulate: skip-connection gradients); GCNX_ERR_UNSUPPORTED without a message when the shape is
+ * not the kernel's (widths in multiples of 16 / 4 floats, 16-byte aligned operands): call gcnx_gemm / gcnx_gemm_dx.
+ * bn_parts (transpose = 0, fo <= 256): the batch-norm statistics of what is written, as (rows, mean, M2) per column
+ * and workgroup -- [*n_parts][3][fo] floats, room for gcnx_gemm_wimage_parts(n) parts -- which gcnx_bn_finalize_parts
+ * combines (Chan's formula, part order) into mean / inv and the Keras moving-statistics update: tf.nn.moments of the
+ * Dense output without a pass over it. */
+typedef struct gcnx_wimage_job {
+  const float* w;
+  void* img;
+  int32_t fi, fo;
+  int32_t transpose, prec;
+} gcnx_wimage_job;
+GCNX_API int64_t gcnx_wimage_elems(int32_t fi, int32_t fo, int transpose, int prec);
+GCNX_API int gcnx_wimage_prepare(gcnx_ctx* ctx, int32_t njobs, const gcnx_wimage_job* jobs);
+GCNX_API int gcnx_gemm_wimage(gcnx_ctx* ctx, const float* x, int64_t ldx, const void* img, int32_t fi, int32_t fo, int transpose,
+                     const float* bias, float* out, int64_t ldo, int64_t n, int prec, int accumulate, float* bn_parts,
+                     int32_t* n_parts);
+GCNX_API int64_t gcnx_gemm_wimage_parts(gcnx_ctx* ctx, int64_t n);
+GCNX_API int gcnx_bn_finalize_parts(gcnx_ctx* ctx, const float* parts, int32_t nparts, int32_t f, float momentum, float eps,
+                           float* mean, float* inv, float* moving_mean, float* moving_var);
 /* The block-diagonal structure of a DisjointLoader batch (sp.block_diag) as a
  * scheduling plan: block_ptr int32[nblocks+1] on the device (= graph_ptr) says that rows
  * [block_ptr[g], block_ptr[g+1]) reference only columns of that same range.  Built once per
