@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
                                                         const float* __restrict__ h, int64_t ldh,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int64_t ldo, int32_t n, int32_t f, int32_t col0, int act,
-                                                        int nchunks, const int2* __restrict__ chunk_list, FoldArgs fo) {
+                                                        int nchunks, const int2* __restrict__ chunk_list, FoldArgs fo, int hub_deg) {
+  // hub_deg > 0 (r3): rows with more entries are NOT this kernel's -- spmm_hub_seg_kernel / spmm_hub_combine_kernel walk them
+  // as 256-entry segments on workgroups of their own (a plan lists them); such a row is skipped here, store included.
   constexpr int G = 64 / LPR;  // neighbour groups per wave
   __shared__ int32_t s_g[FOLD ? RPC : 1];   // FOLD: graph of each row of the chunk, and its pool scale
   __shared__ float s_sc[FOLD ? RPC : 1];
@@ -247,8 +249,9 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
     const int rB = r + 4;                                          // second row of this trip (may be past the chunk)
     int aA = s_rp[r - r0] - e0, bA = s_rp[r - r0 + 1] - e0;        // chunk-relative entry ranges
     int aB = rB < r1 ? s_rp[rB - r0] - e0 : 0, bB = rB < r1 ? s_rp[rB - r0 + 1] - e0 : 0;
-    const bool longA = bA - aA > kLongRow, longB = bB - aB > kLongRow;   // hubs: done by all four waves below
-    saw_long |= longA | longB;
+    const bool hubA = hub_deg > 0 && bA - aA > hub_deg, hubB = hub_deg > 0 && bB - aB > hub_deg;   // another kernel's rows
+    const bool longA = bA - aA > kLongRow, longB = bB - aB > kLongRow;   // long rows: done by all four waves below
+    saw_long |= (longA & !hubA) | (longB & !hubB);
     if (longA) bA = aA;
     if (longB) bB = aB;
     float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
   const int nnz_all = rowptr[n];
   for (int r = r0; r < r1; ++r) {                // uniform over the workgroup
     const int a = s_rp[r - r0] - e0, b = s_rp[r - r0 + 1] - e0;
-    if (b - a <= kLongRow) continue;
+    if (b - a <= kLongRow || (hub_deg > 0 && b - a > hub_deg)) continue;
     const int per = (b - a + 3) / 4;
     const int wa = a + wave * per, wb = min(b, wa + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1048,6 +1051,105 @@ __global__ __launch_bounds__(1024, 4) void spmm_pipe_kernel(
 }
 #undef GCNX_PSTEP4
 
+// ----------------------------------------------------------------------------------------------
+// Hub rows (r3; power-law batches, BASELINE config 5: degrees up to 4096).  Inside spmm_rows_kernel a long row is walked
+// by the four waves of ONE workgroup: the 4096-entry row took 518 us of a 736 us launch, max / mean wave lifetime 15.6.
+// A plan now lists every row of more than kHubDeg entries as segments of kHubSeg entries; a workgroup of
+// spmm_hub_seg_kernel sums one segment (four waves, 64 entries each, 8 gathers in flight per lane, partial sums merged in
+// wave order) into a partial row, spmm_hub_combine_kernel adds a row's partials in segment order and applies the
+// epilogue.  Deterministic; the row gather skips these rows (hub_deg).
+// ----------------------------------------------------------------------------------------------
+constexpr int kHubDeg = 256;
+constexpr int kHubSeg = 256;
+struct HubSeg { int row, a, b, slot; };          // entries [a, b) of `row` -> partial row `slot`
+struct HubRow { int row, slot0, nseg, pad; };
+
+template <bool WEIGHTED, bool FOLD>
+__global__ __launch_bounds__(256) void spmm_hub_seg_kernel(const HubSeg* __restrict__ segs, const int32_t* __restrict__ colidx,
+                                                           const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh,
+                                                           float* __restrict__ part, int32_t n, int32_t f, int nnz) {
+  __shared__ float4 s_part[4][64];
+  const HubSeg sg = segs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (sg.b - sg.a + 3) / 4;
+  const int wa = sg.a + wave * per, wb = min(sg.b, wa + per);
+  const __amdgpu_buffer_rsrc_t cbuf = __builtin_amdgcn_make_buffer_rsrc((void*)colidx, (short)0, nnz * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vbuf =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(WEIGHTED ? (const void*)vals : (const void*)colidx), (short)0, nnz * 4, 0x00020000);
+  const bool use_buf = (uint64_t)n * (uint64_t)ldh * 4u < 0xFFFFFF00ull;
+  const __amdgpu_buffer_rsrc_t hbuf =
+      __builtin_amdgcn_make_buffer_rsrc((void*)h, (short)0, use_buf ? (int)((uint64_t)n * (uint64_t)ldh * 4u) : 0, 0x00020000);
+  const unsigned ld32 = (unsigned)ldh;
+  for (int c0 = 0; c0 < f; c0 += 256) {                   // 64 lanes x float4 per pass
+    const int c = c0 + lane * 4;
+    const bool col_ok = c < f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int HU = 8;
+    for (int e = wa; e < wb; e += HU) {                   // (uniform per wave)
+      int ci[HU];
+      float wv[HU];
+#pragma unroll
+      for (int u = 0; u < HU; ++u) {
+        const unsigned off = e + u < wb ? (unsigned)(e + u) * 4u : 0xFFFFFFF0u;
+        ci[u] = __builtin_amdgcn_raw_buffer_load_b32(cbuf, off, 0, 0);
+        wv[u] = WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f;
+      }
+      f32x4v hv[HU];
+#pragma unroll
+      for (int u = 0; u < HU; ++u) {
+        if (use_buf) {
+          const unsigned off = (e + u < wb && col_ok) ? ((unsigned)ci[u] * ld32 + (unsigned)c) * 4u : 0xFFFFFFF0u;
+          hv[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(hbuf, off, 0, 0));
+        } else {
+          hv[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          if (e + u < wb && col_ok) { const float4 t = *reinterpret_cast<const float4*>(h + (int64_t)ci[u] * ldh + c); hv[u] = f32x4v{t.x, t.y, t.z, t.w}; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < HU; ++u) {
+        float4 t = make_float4(hv[u].x, hv[u].y, hv[u].z, hv[u].w);
+        if (FOLD) t = f4_step(t);
+        if (e + u < wb) acc = WEIGHTED ? f4_fma(wv[u], t, acc) : f4_add(acc, t);
+      }
+    }
+    __syncthreads();                                      // (s_part free: the previous column pass was consumed)
+    s_part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col_ok) {
+      const float4 t = f4_add(f4_add(s_part[0][lane], s_part[1][lane]), f4_add(s_part[2][lane], s_part[3][lane]));
+      *reinterpret_cast<float4*>(part + (size_t)sg.slot * f + c) = t;
+    }
+  }
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __restrict__ rows, const float* __restrict__ part,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
+                                                              int32_t f, int act, FoldArgs fo) {
+  const HubRow hr = rows[blockIdx.x];
+  const int lane = threadIdx.x;
+  int g = 0;
+  float sc = 1.0f;
+  if (FOLD) {                                             // graph of the row: binary search in graph_ptr (a few hundred rows in all)
+    int lo = 0, hi = fo.b;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fo.gp[mid] <= hr.row) lo = mid; else hi = mid; }
+    g = lo;
+    if (fo.avg) sc = 1.0f / (float)(fo.gp[g + 1] - fo.gp[g]);
+  }
+  for (int c = lane * 4; c < f; c += 256) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < hr.nseg; ++k) t = f4_add(t, *reinterpret_cast<const float4*>(part + (size_t)(hr.slot0 + k) * f + c));
+    if (FOLD) {
+      const float4 d = *reinterpret_cast<const float4*>(fo.dp + (int64_t)g * fo.lddp + c);
+      t.x *= d.x * sc; t.y *= d.y * sc; t.z *= d.z * sc; t.w *= d.w * sc;
+    } else {
+      if (bias) { const float4 bv = *reinterpret_cast<const float4*>(bias + c); t = f4_add(t, bv); }
+      if (act == GCNX_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)hr.row * ldo + c) = t;
+  }
+}
+
 // Fallback for widths / strides that are not multiples of 4 floats: one lane per column.
 __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ colidx,
@@ -1074,7 +1176,8 @@ __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restr
 template <int LPR>
 void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                 const int2* chunk_list = nullptr, int list_len = 0, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk) {
+                 const int2* chunk_list = nullptr, int list_len = 0, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk,
+                 int hub_deg = 0) {
   const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
   const bool small = chunk_list ? list_rpc <= kRowsPerChunkSmall : n < 16 * 1024 * kRowsPerChunk / 4;   // < 128k rows
   const int nchunks = chunk_list ? list_len : gcnx_cdiv(n, small ? kRowsPerChunkSmall : kRowsPerChunk);
@@ -1082,7 +1185,7 @@ void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, co
   for (int col0 = 0; col0 < f; col0 += span) {
 #define GCNX_ROWS_F(W, R, F)                                                                                         \
     hipLaunchKernelGGL((spmm_rows_kernel<LPR, W, R, F>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx, vals, \
-                       h, ldh, bias, out, ldo, n, f, col0, act, nchunks, chunk_list, fo)
+                       h, ldh, bias, out, ldo, n, f, col0, act, nchunks, chunk_list, fo, hub_deg)
 #define GCNX_ROWS(W, R) do { if (fold) GCNX_ROWS_F(W, R, true); else GCNX_ROWS_F(W, R, false); } while (0)
     if (small) { if (vals) GCNX_ROWS(true, kRowsPerChunkSmall); else GCNX_ROWS(false, kRowsPerChunkSmall); }
     else { if (vals) GCNX_ROWS(true, kRowsPerChunk); else GCNX_ROWS(false, kRowsPerChunk); }
@@ -1095,16 +1198,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                    int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk) {
+                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk, int hub_deg = 0) {
   int lanes = f / 4;
   // Tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in floats
   // forces the lanes-per-row split of the rows kernel; results are identical.
   if (ctx->knob_spmm_slab >= 16 && ctx->knob_spmm_slab / 4 < lanes) lanes = ctx->knob_spmm_slab / 4;
-  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
-  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
-  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
-  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
-  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc);
+  if (lanes > 32) launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc, hub_deg);
+  else if (lanes > 16) launch_rows<32>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc, hub_deg);
+  else if (lanes > 8) launch_rows<16>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc, hub_deg);
+  else if (lanes > 4) launch_rows<8>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc, hub_deg);
+  else launch_rows<4>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc, hub_deg);
 }
 
 template <int THREADS, int FT, int LPR>
@@ -1177,6 +1280,11 @@ struct RowOrder {                       // the tile kernels' degree order of one
   const int32_t* rowptr = nullptr;
   RowRec* dev = nullptr;
   int n = 0;
+  // hub rows (more than kHubDeg entries), those of graphs too tall for a tile first: [0, nhubs_tall) / [0, nsegs_tall)
+  HubSeg* hub_segs = nullptr;
+  HubRow* hub_rows = nullptr;
+  int nhubs = 0, nsegs = 0, nhubs_tall = 0, nsegs_tall = 0;
+  int nnz = 0;
 };
 struct gcnx_spmm_plan {
   std::vector<int32_t> bp;              // host copy of block_ptr
@@ -1212,7 +1320,11 @@ static void plan_free(gcnx_spmm_plan* p) {
   if (p->gids) (void)hipFree(p->gids);
   if (p->items) (void)hipFree(p->items);
   if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
-  for (int i = 0; i < p->norders; ++i) if (p->orders[i].dev) (void)hipFree(p->orders[i].dev);
+  for (int i = 0; i < p->norders; ++i) {
+    if (p->orders[i].dev) (void)hipFree(p->orders[i].dev);
+    if (p->orders[i].hub_segs) (void)hipFree(p->orders[i].hub_segs);
+    if (p->orders[i].hub_rows) (void)hipFree(p->orders[i].hub_rows);
+  }
   delete p;
 }
 
@@ -1268,11 +1380,43 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
         }
       }
     }
+    // hub rows as segments: rows of graphs too tall for a tile first (the tile kernels walk their own long rows)
+    std::vector<HubSeg> segs;
+    std::vector<HubRow> hubs;
+    int nh_tall = 0, ns_tall = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int g = 0; g < p->nblocks; ++g) {
+        const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
+        if ((ng > p->cap2) != (pass == 0)) continue;
+        for (int i = 0; i < ng; ++i) {
+          const int a = rp[r0 + i], b = rp[r0 + i + 1];
+          if (b - a <= kHubDeg) continue;
+          const int ns = (b - a + kHubSeg - 1) / kHubSeg;
+          hubs.push_back(HubRow{r0 + i, (int)segs.size(), ns, 0});
+          for (int k = 0; k < ns; ++k) segs.push_back(HubSeg{r0 + i, a + k * kHubSeg, std::min(b, a + (k + 1) * kHubSeg), (int)segs.size()});
+        }
+      }
+      if (pass == 0) { nh_tall = (int)hubs.size(); ns_tall = (int)segs.size(); }
+    }
     RowRec* dev = nullptr;
+    HubSeg* dsegs = nullptr;
+    HubRow* dhubs = nullptr;
     e = plan_upload(ctx, &dev, rec);
-    if (e != hipSuccess) { if (dev) (void)hipFree(dev); return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_bind: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = plan_upload(ctx, &dsegs, segs);
+    if (e == hipSuccess) e = plan_upload(ctx, &dhubs, hubs);
+    if (e != hipSuccess) {
+      if (dev) (void)hipFree(dev);
+      if (dsegs) (void)hipFree(dsegs);
+      if (dhubs) (void)hipFree(dhubs);
+      return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_bind: %s", hipGetErrorString(e));
+    }
     if (slot->dev) (void)hipFree(slot->dev);
+    if (slot->hub_segs) (void)hipFree(slot->hub_segs);
+    if (slot->hub_rows) (void)hipFree(slot->hub_rows);
     slot->rowptr = rowptr; slot->dev = dev; slot->n = n;
+    slot->hub_segs = dsegs; slot->hub_rows = dhubs;
+    slot->nhubs = (int)hubs.size(); slot->nsegs = (int)segs.size(); slot->nhubs_tall = nh_tall; slot->nsegs_tall = ns_tall;
+    slot->nnz = rp[n];
   } catch (const std::bad_alloc&) {
     return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_bind: out of host memory");
   }
@@ -1280,12 +1424,13 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
 }
 
 // The order bound to `rowptr`, built on first use (outside stream capture).  force: rebuild (the CSR behind the pointer changed).
-static int plan_order(gcnx_ctx* ctx, const gcnx_spmm_plan* cplan, const int32_t* rowptr, int32_t n, bool force, const RowRec** out) {
+static int plan_order(gcnx_ctx* ctx, const gcnx_spmm_plan* cplan, const int32_t* rowptr, int32_t n, bool force, const RowRec** out,
+                      const RowOrder** order_out = nullptr) {
   gcnx_spmm_plan* p = const_cast<gcnx_spmm_plan*>(cplan);   // (a cache behind an opaque handle; a ctx is single-threaded by contract)
   RowOrder* slot = nullptr;
   for (int i = 0; i < p->norders; ++i)
     if (p->orders[i].rowptr == rowptr && p->orders[i].n == n) slot = &p->orders[i];
-  if (slot && !force) { *out = slot->dev; return GCNX_OK; }
+  if (slot && !force) { *out = slot->dev; if (order_out) *order_out = slot; return GCNX_OK; }
   if (ctx->capturing)
     return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: the plan has no row order for this rowptr yet and building one synchronises: "
                      "call gcnx_spmm_plan_bind (or run the call once) before capturing");
@@ -1296,6 +1441,28 @@ static int plan_order(gcnx_ctx* ctx, const gcnx_spmm_plan* cplan, const int32_t*
   const int rc = plan_build_order(ctx, p, rowptr, n, slot);
   if (rc) return rc;
   *out = slot->dev;
+  if (order_out) *order_out = slot;
+  return GCNX_OK;
+}
+
+// The hub rows of a bound plan (all of them, or only those of graphs too tall for a tile): segments -> partial rows in the
+// ctx workspace -> combine + epilogue.
+static int launch_hubs(gcnx_ctx* ctx, const RowOrder* od, bool tall_only, const int32_t* colidx, const float* vals, const float* h,
+                       int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act, const FoldArgs* fold) {
+  const int nsegs = tall_only ? od->nsegs_tall : od->nsegs, nhubs = tall_only ? od->nhubs_tall : od->nhubs;
+  if (nsegs == 0) return GCNX_OK;
+  int rc = gcnx_ws_reserve(ctx, (size_t)nsegs * f * sizeof(float));
+  if (rc) return rc;
+  float* part = (float*)ctx->ws;
+  const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
+#define GCNX_HUB_SEG(W, F) hipLaunchKernelGGL((spmm_hub_seg_kernel<W, F>), dim3(nsegs), dim3(256), 0, ctx->stream, od->hub_segs, colidx, vals, h, ldh, part, n, f, od->nnz)
+  if (vals) { if (fold) GCNX_HUB_SEG(true, true); else GCNX_HUB_SEG(true, false); }
+  else { if (fold) GCNX_HUB_SEG(false, true); else GCNX_HUB_SEG(false, false); }
+#undef GCNX_HUB_SEG
+  GCNX_LAUNCH_OK(ctx);
+  if (fold) hipLaunchKernelGGL((spmm_hub_combine_kernel<true>), dim3(nhubs), dim3(64), 0, ctx->stream, od->hub_rows, (const float*)part, bias, out, ldo, f, act, fo);
+  else hipLaunchKernelGGL((spmm_hub_combine_kernel<false>), dim3(nhubs), dim3(64), 0, ctx->stream, od->hub_rows, (const float*)part, bias, out, ldo, f, act, fo);
+  GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
 
@@ -1444,10 +1611,15 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   if (relu_bits && (!tiles || force == 3))
     return gcnx_fail(ctx, GCNX_ERR_UNSUPPORTED, "gcnx_spmm_csr_relu_bits: the bit image is written by the tile kernels only "
                      "(needs a plan with enough tile units and f %% 32 == 0): use gcnx_spmm_csr");
+  const RowRec* rowrec = nullptr;
+  const RowOrder* order = nullptr;
+  if (plan && force != 3) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
   if (!tiles) {
-    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0);
+    // (with a bound plan: the rows of more than kHubDeg entries go to the hub kernels)
+    const bool hubs = order && order->nsegs > 0;
+    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0, nullptr, kRowsPerChunk, hubs ? kHubDeg : 0);
     GCNX_LAUNCH_OK(ctx);
-    return GCNX_OK;
+    return hubs ? launch_hubs(ctx, order, false, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr) : GCNX_OK;
   }
   // The pipelined kernel: any graph size, one 1024-thread workgroup per CU with two source buffers.  Opt-in
   // (GCNX_SPMM_KERNEL=pipe / gcnx_set_tuning): correct on every case the tier kernels are tested on, but at config 3 it
@@ -1516,8 +1688,6 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
     return GCNX_OK;
   }
   // tier 1: two 512-thread workgroups per CU; tier 2: one 1024-thread workgroup with the whole LDS
-  const RowRec* rowrec = nullptr;
-  if (plan->n1 + plan->n2 > 0) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec); if (rb) return rb; }
   const DuoFold bo{nullptr, nullptr, 0, 0, relu_bits};     // (graphs taller than a tile get no bits: their rows are folded from out)
   const int dmode = relu_bits ? kDuoBitsOut : kDuoPlain;
   // The three launches write disjoint rows.  GCNX_SPMM_CONC: as concurrent branches (two auxiliary streams), so that
@@ -1538,9 +1708,11 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   }
   if (!rc && plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     if (conc) ctx->stream = aux[1];
+    const bool hubs = order && order->nsegs_tall > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks, nullptr, plan->chunk_rpc);
+                  plan->nchunks, nullptr, plan->chunk_rpc, hubs ? kHubDeg : 0);
     if (hipGetLastError() != hipSuccess) rc = gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_csr: row-chunk launch failed");
+    if (!rc && hubs) rc = launch_hubs(ctx, order, true, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr);
     ctx->stream = home;
   }
   if (conc) { const int rj = gcnx_aux_join(ctx); if (!rc) rc = rj; }
@@ -1569,15 +1741,17 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
   // with a plan (throughput regime): the tile kernels in their folded form, taller graphs' row chunks on the rows kernel
   const bool tiles = plan && plan->nblocks == b && f % kSlab == 0 && ctx->knob_spmm_kernel != 1 &&
                      ((long long)(plan->n1 + 2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus || ctx->knob_spmm_kernel >= 2);
+  const RowRec* rowrec = nullptr;
+  const RowOrder* order = nullptr;
+  if (plan && plan->nblocks == b) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
   if (!tiles) {
-    dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo);
+    const bool hubs = order && order->nsegs > 0;
+    dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo, kRowsPerChunk, hubs ? kHubDeg : 0);
     GCNX_LAUNCH_OK(ctx);
-    return GCNX_OK;
+    return hubs ? launch_hubs(ctx, order, false, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, &fo) : GCNX_OK;
   }
   // y_bits (the forward's gcnx_spmm_csr_relu_bits image of y): the tiers expand it instead of reading y
   const int dmode = y_bits ? kDuoFoldBits : kDuoFold;
-  const RowRec* rowrec = nullptr;
-  if (plan->n1 + plan->n2 > 0) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec); if (rb) return rb; }
   if (plan->n1 > 0) {
     const DuoFold df{plan->gids, dpooled, lddp, fo.avg, (uint32_t*)y_bits};
     int rc = launch_duo<512, 32, 4>(ctx, rowptr, rowrec, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev, plan->n1, &df,
@@ -1591,9 +1765,11 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
     if (rc) return rc;
   }
   if (plan->nchunks > 0) {
+    const bool hubs = order && order->nsegs_tall > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks, &fo, plan->chunk_rpc);
+                  plan->nchunks, &fo, plan->chunk_rpc, hubs ? kHubDeg : 0);
     GCNX_LAUNCH_OK(ctx);
+    if (hubs) return launch_hubs(ctx, order, true, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, &fo);
   }
   return GCNX_OK;
 }

@@ -279,7 +279,9 @@ class DeviceCSR:
             return None
         # The tile kernels need >= 4 (graph, 32-column slab) units per CU (gcnx_spmm_csr); below ~128 graphs no
         # width reaches that, and building a plan (a D2H copy, a host sort, an upload) per streamed batch is wasted.
-        if self.n_blocks < 128 and not getattr(self.ctx, "_force_plan", False):
+        # (r3: a large batch of FEW graphs -- config 5: 122 power-law graphs of 8 192 nodes -- gets a plan too: it lists the hub
+        # rows, which then run as segments on workgroups of their own)
+        if self.n_blocks < 128 and self.n < 131072 and not getattr(self.ctx, "_force_plan", False):
             return None
         holder = self.block_ptr
         p = getattr(holder, "_spmm_plan", None)

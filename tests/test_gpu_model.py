@@ -765,7 +765,7 @@ def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     from gcnx.models import DeviceBatch
     hb = _full_size_batch(workload)
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, hb.vals, hb.graph_ptr)
-    assert a.symmetric and (a.plan is not None) == (workload == "block1m")
+    assert a.symmetric and a.plan is not None        # (config 5 too since r3: its plan lists the hub rows)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
     m = GCN2(ctx, 2, hidden=256, seed=0)
     m.build(hb.f)
