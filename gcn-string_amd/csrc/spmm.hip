@@ -101,7 +101,7 @@ __device__ unsigned long long* g_wave_stamps = nullptr;
 #define GCNX_WSTAMP_END
 #endif
 
-template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false>
+template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false, bool HUBS = false>
 __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   // 8 waves per SIMD = at most 64 VGPRs (latency regime)
    const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx,
@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
                                                         const float* __restrict__ h, int64_t ldh,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int64_t ldo, int32_t n, int32_t f, int32_t col0, int act,
-                                                        int nchunks, const int2* __restrict__ chunk_list, FoldArgs fo, int hub_deg) {
+                                                        int nchunks, const int2* __restrict__ chunk_list, FoldArgs fo, int hub_deg_rt) {
+  // (a template flag: with the test in the row loop of every instance the 64-VGPR latency-regime instance -- config 2 -- ran
+  // 16.3 us instead of 11.9)
+  const int hub_deg = HUBS ? hub_deg_rt : 0;
   // hub_deg > 0 (r3): rows with more entries are NOT this kernel's -- spmm_hub_seg_kernel / spmm_hub_combine_kernel walk them
   // as 256-entry segments on workgroups of their own (a plan lists them); such a row is skipped here, store included.
   constexpr int G = 64 / LPR;  // neighbour groups per wave
@@ -534,6 +537,26 @@ __device__ __forceinline__ void tile_dma32(float* buf, const float* __restrict__
   }
 }
 
+// The same with the LDS-DMA as inline asm.  For the builtin hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every
+// later LDS read -- it cannot tell two LDS buffers apart -- which serialises a double-buffered loop; the asm form is
+// invisible to its wait-count pass, so the CALLER waits (s_waitcnt vmcnt(0) before the barrier that precedes the reads).
+// lds_byte: LDS byte address of the tile's first row.
+template <int PPR, int THREADS, int PIECES>
+__device__ __forceinline__ void tile_dma32_asm(unsigned lds_byte, const float* __restrict__ gbase, unsigned ld32, int ng) {
+  const int tid = threadIdx.x;
+  const int total = ng * PPR;
+#pragma unroll
+  for (int u = 0; u < (PIECES + THREADS - 1) / THREADS; ++u) {
+    const int i = tid + u * THREADS;
+    if (i < total) {
+      const unsigned off = (unsigned)(i / PPR) * ld32 + (unsigned)(i % PPR) * 4u;
+      const float* src = gbase + off;
+      const unsigned base = __builtin_amdgcn_readfirstlane(lds_byte + (unsigned)(u * THREADS + (tid & ~63)) * 16u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "memory");
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Tile kernel (default with a plan): independent workgroups, no pipeline inside a workgroup.  Per work unit
 // (graph, sg column slabs) one index burst -- row pointers and the first 16 entries of every row, kept in registers
@@ -652,7 +675,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
   // the opposite order (chunk j ^ 1 first): each group then has two quads on either chunk, 1.75 expected.
   const int csw = (CPL == 2) ? ((((lane >> 2) + 2) >> 2) & 1) : 0;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned tb0 = lds0 + (sub + LPR * csw) * 16;   // LDS address of this lane's FIRST chunk of tile row 0
+  const unsigned tbl = lds0 + (sub + LPR * csw) * 16;   // LDS address of this lane's FIRST chunk of tile row 0 (buffer 0)
   const unsigned tbd = csw ? (unsigned)-64 : 64u;       // ... and the distance to its second chunk
   // workgroup id folded per XCD (ids are dealt round-robin to the 8 XCDs): consecutive virtual ids share an L2
   const int G = gridDim.x;
@@ -663,12 +686,26 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
   if (tid < FT) lds[CAP * FT + tid] = 0.f;      // the all-zero row padding entries point at
   const EntryBufs ebufs = entry_bufs(colidx, vals, rowptr[n]);
 
+  // Double buffering (r3; the 1024-thread shape, DMA-fed modes): a graph of up to kDblCap rows leaves room for TWO tiles, so
+  // the tile of the next slab (or of the next unit's first slab) streams in while this one is reduced -- the DMA wait, a
+  // third of a slab step, disappears for such graphs (half of config 3's rows).  The DMA is inline asm throughout (see
+  // tile_dma32_asm); the wait for it is the explicit vmcnt(0) in front of the barrier that precedes the reduction.
+  constexpr int kDblCap = 624;
+  constexpr unsigned kDblBuf = (kDblCap + 1) * RB;          // tile + its zero row
+  constexpr bool kCanDbl = THREADS == 1024 && (MODE == kDuoPlain || MODE == kDuoBitsOut);
+  static_assert(!kCanDbl || 2 * kDblBuf <= (unsigned)(CAP + 1) * RB, "two small tiles must stay below the bias slice");
+  int cur = 0;                                   // buffer the current tile is in (double-buffered units)
+  bool prefetched = false, zero_rows_ok = false; // this step's tile already requested; the small tiles' zero rows written
+
   int2 g = graphs[u / upg];
   for (int round = 0;; ++round) {
     const int cbase = (u % upg) * sg * FT;
     const int un = unit_of(round + 1);
     const bool has_next = un < nunits;
     const int2 gn = has_next ? graphs[un / upg] : g;
+    const bool dbl = kCanDbl && g.y <= kDblCap && !(dbg_rt & 16);   // (bit 16 of the tuning word: single tiles only, for A/B runs)
+    const int pad = dbl ? kDblCap : CAP;           // tile row padding entries point at (all zeros)
+    if (!dbl) { cur = 0; zero_rows_ok = false; }
     // index burst of the unit: (local row, degree) and the first 16 entries of every row this quad owns -- 32 for the
     // first row group, where the degree order puts the long rows -- once for all sg slabs (they share rows and
     // entries).  In flight together with the first tile.
@@ -687,15 +724,15 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
 #pragma unroll
       for (int t = 0; t < NI; ++t) {
         int c4[4];
-        if (!(dbg & 8)) fetch_entries<WEIGHTED, 1>(ebufs, a[t], slot, a[t] + (int)(rw[t] >> 16), g.x, CAP, c4, mv[t]);
-        else { c4[0] = c4[1] = c4[2] = c4[3] = CAP; mv[t][0] = mv[t][1] = mv[t][2] = mv[t][3] = 0.f; }
+        if (!(dbg & 8)) fetch_entries<WEIGHTED, 1>(ebufs, a[t], slot, a[t] + (int)(rw[t] >> 16), g.x, pad, c4, mv[t]);
+        else { c4[0] = c4[1] = c4[2] = c4[3] = pad; mv[t][0] = mv[t][1] = mv[t][2] = mv[t][3] = 0.f; }
         pc[t][0] = (unsigned)c4[0] | ((unsigned)c4[1] << 16);
         pc[t][1] = (unsigned)c4[2] | ((unsigned)c4[3] << 16);
       }
       {
         int c4[4];
-        if (!(dbg & 8)) fetch_entries<WEIGHTED, 1>(ebufs, a[0] + 16, slot, a[0] + (int)(rw[0] >> 16), g.x, CAP, c4, mv2);
-        else { c4[0] = c4[1] = c4[2] = c4[3] = CAP; mv2[0] = mv2[1] = mv2[2] = mv2[3] = 0.f; }
+        if (!(dbg & 8)) fetch_entries<WEIGHTED, 1>(ebufs, a[0] + 16, slot, a[0] + (int)(rw[0] >> 16), g.x, pad, c4, mv2);
+        else { c4[0] = c4[1] = c4[2] = c4[3] = pad; mv2[0] = mv2[1] = mv2[2] = mv2[3] = 0.f; }
         pc2[0] = (unsigned)c4[0] | ((unsigned)c4[1] << 16);
         pc2[1] = (unsigned)c4[2] | ((unsigned)c4[3] << 16);
       }
@@ -716,13 +753,33 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           const unsigned nib = bw[i >> 3] >> ((i & 7) * 4);
           t4[i] = make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
         }
-      } else if (!(dbg & 1)) tile_dma32<FT / 4, THREADS, CAP * (FT / 4)>(lds, h + (int64_t)g.x * ldh + c0, ld32, g.y);
+      } else if (!(dbg & 1) && !prefetched)
+        tile_dma32_asm<FT / 4, THREADS, CAP * (FT / 4)>(lds0 + cur * kDblBuf, h + (int64_t)g.x * ldh + c0, ld32, g.y);
+      if (dbl && !zero_rows_ok) {               // (the two small tiles' zero rows: a single-tile unit may have overwritten them)
+        if (tid < 2 * FT) lds[(tid / FT) * (kDblBuf / 4) + kDblCap * FT + tid % FT] = 0.f;
+        zero_rows_ok = true;
+      }
       if (FOLD) {
         if (tid < FT) lbias[tid] = fo.dp[(int64_t)fo.gids[u / upg] * fo.lddp + c0 + tid] * (fo.avg ? 1.0f / (float)g.y : 1.0f);
       } else {
         if (tid < FT) lbias[tid] = bias ? bias[c0 + tid] : 0.f;
       }
-      __syncthreads();                          // the tile (and on s == 0 the index burst) has landed
+      // the tile has landed (asm DMA: hipcc does not count it), the bias slice is written.  (A counted wait that leaves the
+      // previous reduction's stores in flight -- range-checked buffer stores, a fixed number per wave -- measured no faster.)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      prefetched = false;
+      if (dbl && !(dbg & 1)) {                  // the next tile streams in under this reduction
+        if (s + 1 < sg) {
+          tile_dma32_asm<FT / 4, THREADS, kDblCap * (FT / 4)>(lds0 + (cur ^ 1) * kDblBuf, h + (int64_t)g.x * ldh + c0 + FT, ld32, g.y);
+          prefetched = true;
+        } else if (has_next && gn.y <= kDblCap) {
+          tile_dma32_asm<FT / 4, THREADS, kDblCap * (FT / 4)>(lds0 + (cur ^ 1) * kDblBuf, h + (int64_t)gn.x * ldh + (un % upg) * sg * FT, ld32, gn.y);
+          prefetched = true;
+        }
+      }
+      const unsigned tb0 = tbl + cur * kDblBuf;  // this lane's first chunk of tile row 0 in the current buffer
       if constexpr (MODE == kDuoFold) {         // Y -> [Y > 0], in place
         float4* t4 = reinterpret_cast<float4*>(lds);
         for (int i = tid; i < g.y * (FT / 4); i += THREADS) t4[i] = f4_step(t4[i]);
@@ -789,6 +846,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           if (sub == 0 && pos < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
         }
       }
+      if (dbl) cur ^= 1;                        // (the next slab's tile -- or the next unit's first -- is in the other buffer)
     }
     if (!has_next) break;
     g = gn;
@@ -1183,10 +1241,11 @@ void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, co
   const int nchunks = chunk_list ? list_len : gcnx_cdiv(n, small ? kRowsPerChunkSmall : kRowsPerChunk);
   const int span = LPR * 4;
   for (int col0 = 0; col0 < f; col0 += span) {
-#define GCNX_ROWS_F(W, R, F)                                                                                         \
-    hipLaunchKernelGGL((spmm_rows_kernel<LPR, W, R, F>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx, vals, \
+#define GCNX_ROWS_F(W, R, F, H)                                                                                      \
+    hipLaunchKernelGGL((spmm_rows_kernel<LPR, W, R, F, H>), dim3(nchunks), dim3(256), 0, ctx->stream, rowptr, colidx, vals, \
                        h, ldh, bias, out, ldo, n, f, col0, act, nchunks, chunk_list, fo, hub_deg)
-#define GCNX_ROWS(W, R) do { if (fold) GCNX_ROWS_F(W, R, true); else GCNX_ROWS_F(W, R, false); } while (0)
+#define GCNX_ROWS(W, R) do { if (hub_deg > 0) { if (fold) GCNX_ROWS_F(W, R, true, true); else GCNX_ROWS_F(W, R, false, true); }     \
+                             else { if (fold) GCNX_ROWS_F(W, R, true, false); else GCNX_ROWS_F(W, R, false, false); } } while (0)
     if (small) { if (vals) GCNX_ROWS(true, kRowsPerChunkSmall); else GCNX_ROWS(false, kRowsPerChunkSmall); }
     else { if (vals) GCNX_ROWS(true, kRowsPerChunk); else GCNX_ROWS(false, kRowsPerChunk); }
 #undef GCNX_ROWS_F
@@ -1226,7 +1285,7 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
     attr_set = true;
   }
   int dbg = 0;
-#ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set): only in a tuning build (make TUNING=1)
+#ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set, bit 16 excepted): only in a tuning build (make TUNING=1)
   if (const char* e = getenv("GCNX_SPMM_DBG")) dbg = atoi(e);
 #endif
   const int full = (THREADS == 512 ? 2 : 1) * ctx->num_cus;   // resident workgroups
