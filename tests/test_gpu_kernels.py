@@ -1355,3 +1355,122 @@ def test_gcn_conv_fused_edge_cases(ctx):
     out5 = ctx.empty((5, f))
     D.gcn_conv_fwd(ctx, a5, ctx.to_device(x[:5]), ctx.to_device(w), None, out5, act=None)
     assert rel_err(out5.numpy(), ax[:5] @ w.astype(np.float64)) < TIGHT
+
+
+# ---- round 3 ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", None)])
+@pytest.mark.parametrize("n,fi,fo", [(3000, 256, 256), (5000, 768, 256), (2100, 16, 256), (1000, 36, 48), (33, 128, 64)])
+def test_gemm_wimage_panel_kernel_and_batch_norm_parts(ctx, n, fi, fo, prec, tol):
+    """The split-bf16 panel GEMM of GeneralGNN's Dense layers (csrc/gemm_panel.hip; MatMul + BiasAdd under gcn.py:334): weight
+    image of several matrices from ONE launch, out = x W + b against fp64 (bf16x3: 2e-5; plain bf16: exact against the
+    bf16-rounded operands, loosely against fp64), ragged K (16, 36: zero-padded k steps), row counts that are not a
+    multiple of the tile, and the batch-norm statistics of the output out of the epilogue -- (rows, mean, M2) parts merged
+    by gcnx_bn_finalize_parts -- against numpy's two-pass moments and the Keras moving-statistics update."""
+    from gcnx import device as D
+    rng = np.random.default_rng(n + fi)
+    x = (rng.standard_normal((n, fi)) * 2 + 0.5).astype(np.float32)
+    w = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
+    w2 = (rng.standard_normal((fi, fo)) / np.sqrt(fi)).astype(np.float32)
+    b = rng.standard_normal(fo).astype(np.float32)
+    dx, dw, dw2, db = ctx.to_device(x), ctx.to_device(w), ctx.to_device(w2), ctx.to_device(b)
+    img = ctx.empty(D.wimage_elems(ctx, fi, fo, False, prec), np.uint16)
+    img2 = ctx.empty(D.wimage_elems(ctx, fi, fo, False, prec), np.uint16)
+    D.wimage_prepare(ctx, [(dw, img, False, prec), (dw2, img2, False, prec)])
+    out = ctx.zeros((n, fo))
+    parts = ctx.zeros(3 * max(D.gemm_wimage_parts(ctx, n), 1) * fo)
+    nparts = D.gemm_wimage(ctx, dx, img, fi, fo, out, bias=db, prec=prec, bn_parts=parts)
+    assert nparts is not None and nparts >= 1
+    ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    got = out.numpy()
+    if tol is not None:
+        assert rel_err(got, ref) < tol
+    else:
+        o = O()
+        rb = lambda v: o.bf16_from_bits(o.bf16_bits(v)).astype(np.float64)
+        assert rel_err(got, rb(x) @ rb(w) + b) < 1e-5 and rel_err(got, ref) < 2e-2
+    # the second matrix of the same prepare launch
+    out2 = ctx.zeros((n, fo))
+    assert D.gemm_wimage(ctx, dx, img2, fi, fo, out2, prec=prec) == 0
+    assert rel_err(out2.numpy(), x.astype(np.float64) @ w2.astype(np.float64)) < (tol or 2e-2)
+    # batch-norm moments of what was written
+    mean, inv = ctx.empty(fo), ctx.empty(fo)
+    mm, mv = ctx.to_device(np.full(fo, 0.25, np.float32)), ctx.to_device(np.full(fo, 2.0, np.float32))
+    D.bn_finalize_parts(ctx, parts, nparts, mean, inv, mm, mv)
+    g64 = got.astype(np.float64)
+    assert rel_err(mean.numpy(), g64.mean(0)) < TIGHT
+    assert rel_err(inv.numpy(), 1.0 / np.sqrt(g64.var(0) + 1e-3)) < TIGHT
+    assert rel_err(mm.numpy(), 0.99 * 0.25 + 0.01 * g64.mean(0)) < TIGHT and rel_err(mv.numpy(), 0.99 * 2.0 + 0.01 * g64.var(0)) < TIGHT
+    # shapes the kernel does not serve are refused without a launch (and without a message)
+    xm = ctx.zeros((n, fi + 4)).cols(1, fi + 1)                       # a 4-byte-aligned operand
+    assert D.gemm_wimage(ctx, xm, img, fi, fo, out, prec=prec) is None
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("n,fi", [(4097, 256), (5000, 512), (3001, 1024)])
+def test_gemm_wimage_transposed_accumulate_and_dw_panels(ctx, n, fi, prec, tol):
+    """The two backward products of a GeneralGNN Dense layer on the panel kernels: dX (+)= dH W^T through the transposed image
+    (A-resident wide kernel for fi > 256: the column panels walked inside the workgroup; accumulate = the skip
+    connections' gradient sum), and dW = X^T dH as 256-column panels of the streaming kernel with one reduction launch --
+    on column-slice views of wider buffers (the concat buffer of GeneralGNN.call), against fp64."""
+    from gcnx import device as D
+    rng = np.random.default_rng(fi + n)
+    fo = 256
+    w = (rng.standard_normal((fi, fo)) / 16).astype(np.float32)
+    dh = rng.standard_normal((n, fo)).astype(np.float32)
+    cat = rng.standard_normal((n, fi + 64)).astype(np.float32)            # x and dx are column slices [32, 32 + fi)
+    dcat0 = rng.standard_normal((n, fi + 64)).astype(np.float32)
+    dw_, ddh, dcat, ddcat = ctx.to_device(w), ctx.to_device(dh), ctx.to_device(cat), ctx.to_device(dcat0)
+    imgt = ctx.empty(D.wimage_elems(ctx, fi, fo, True, prec), np.uint16)
+    D.wimage_prepare(ctx, [(dw_, imgt, True, prec)])
+    xs, dxs = dcat.cols(32, 32 + fi), ddcat.cols(32, 32 + fi)
+    assert D.gemm_wimage(ctx, ddh, imgt, fi, fo, dxs, transpose=True, prec=prec, accumulate=True) == 0
+    want = dcat0.astype(np.float64)
+    want[:, 32:32 + fi] += dh.astype(np.float64) @ w.astype(np.float64).T
+    got = ddcat.numpy()
+    assert rel_err(got, want) < tol
+    assert np.array_equal(got[:, :32], dcat0[:, :32]) and np.array_equal(got[:, 32 + fi:], dcat0[:, 32 + fi:])   # neighbours untouched
+    assert D.gemm_wimage(ctx, ddh, imgt, fi, fo, dxs, transpose=True, prec=prec) == 0                              # overwrite form
+    assert rel_err(ddcat.numpy()[:, 32:32 + fi], dh.astype(np.float64) @ w.astype(np.float64).T) < tol
+    g = ctx.empty((fi, fo))
+    D.gemm_dw(ctx, xs, ddh, g, prec=prec)
+    assert rel_err(g.numpy(), cat[:, 32:32 + fi].astype(np.float64).T @ dh.astype(np.float64)) < tol
+    g2 = ctx.empty((fi, fo)); D.gemm_dw(ctx, xs, ddh, g2, prec=prec)
+    assert np.array_equal(g.numpy(), g2.numpy())                                                                    # deterministic
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_hub_rows_as_segments_on_their_own_workgroups(ctx, weighted):
+    """BASELINE config 5's shape in small: 16 power-law graphs of 8 192 nodes (degrees up to 4096), F = 64.  A batch of this
+    size gets a plan although it has few graphs; the plan lists the rows of more than 256 entries as 256-entry segments
+    (spmm_hub_seg_kernel -> spmm_hub_combine_kernel), the row gather skips them -- forward aggregation with bias + ReLU and
+    the folded pool backward against scipy in fp64, bit-reproducible."""
+    import scipy.sparse as sp
+    from gcnx import device as D, synth
+    from gcnx.device import Segments
+    hb = synth.power_law_batch(16, 8192, 64, seed=3)
+    deg = np.diff(hb.rowptr)
+    assert hb.n >= 131072 and deg.max() >= 2048 and (deg > 256).sum() >= 16
+    csr, vals = _csr(ctx, hb, weighted)
+    assert csr.plan is not None
+    rng = np.random.default_rng(5)
+    f = 64
+    a64 = sp.csr_matrix((np.ones(hb.nnz) if vals is None else vals.astype(np.float64), hb.colidx, hb.rowptr), shape=(hb.n, hb.n))
+    h = rng.standard_normal((hb.n, f), dtype=np.float32); bias = rng.standard_normal(f).astype(np.float32)
+    out = ctx.zeros((hb.n, f))
+    D.spmm(ctx, csr, ctx.to_device(h), ctx.to_device(bias), out, act="relu")
+    ref = np.maximum(a64 @ h.astype(np.float64) + bias, 0)
+    got = out.numpy()
+    assert rel_err(got, ref) < TIGHT
+    hubs = np.nonzero(deg > 256)[0]
+    assert rel_err(got[hubs], ref[hubs]) < TIGHT                      # the hub rows themselves
+    out2 = ctx.zeros((hb.n, f)); D.spmm(ctx, csr, ctx.to_device(h), ctx.to_device(bias), out2, act="relu")
+    assert np.array_equal(got, out2.numpy())
+    # folded pool backward (A symmetric here: the same operator)
+    y = np.maximum(rng.standard_normal((hb.n, f), dtype=np.float32), 0)
+    dp = rng.standard_normal((hb.n_graphs, f), dtype=np.float32)
+    seg = Segments(ctx, hb.graph_ptr)
+    o2 = ctx.zeros((hb.n, f))
+    D.spmm_pool_bwd(ctx, csr, ctx.to_device(y), seg, ctx.to_device(dp), o2, "avg")
+    sizes = np.diff(hb.graph_ptr)
+    dz = np.repeat(dp.astype(np.float64) / sizes[:, None], sizes, axis=0) * (y > 0)
+    assert rel_err(o2.numpy(), a64.T @ dz) < TIGHT
