@@ -1,11 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): bench lines, rocprofv3 kernel stats of the same command, and the
 # separate --pmc passes for HBM traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950).
-#   usage: bash scripts/profile_round.sh r01
+#   usage: bash scripts/profile_round.sh r01 [bench|pmc|gemm|all]   (stages, so that one gpurun call stays inside its limit)
 set -o pipefail
 R=${1:-r01}
+STAGE=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R; mkdir -p $O
+if [ $STAGE = all ] || [ $STAGE = bench ]; then
 python3 bench.py --steps 200 --warmup 20 > $O/bench_ecoli.json 2> $O/bench_ecoli.err || { tail -5 $O/bench_ecoli.err; exit 1; }
 python3 bench.py --prec bf16x3 --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 > $O/bench_ecoli_bf16x3.json 2> $O/bench_ecoli_bf16x3.err
 python3 scripts/loader_bench.py > $O/loader_bench.txt 2>&1
@@ -14,12 +16,20 @@ python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec
 python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 --prec bf16x3 > $O/bench_block1m_bf16x3.json 2> $O/bench_block1m_bf16x3.err
 python3 bench.py --workload powerlaw --steps 20 --warmup 3 --cpu-seconds 0 > $O/bench_powerlaw.json 2> $O/bench_powerlaw.err
 python3 bench.py --model generalgnn --steps 50 --warmup 5 > $O/bench_generalgnn.json 2> $O/bench_generalgnn.err
+python3 bench.py --model generalgnn --prec bf16x3 --steps 50 --warmup 5 --cpu-seconds 0 > $O/bench_generalgnn_bf16x3.json 2> $O/bench_generalgnn_bf16x3.err
+python3 bench.py --model generalgnn --prec bf16 --steps 50 --warmup 5 --cpu-seconds 0 > $O/bench_generalgnn_bf16.json 2> $O/bench_generalgnn_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ecoli -- python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 > $O/trace_ecoli.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_block1m -- python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > $O/trace_block1m.log 2>&1
-for w in ecoli block1m; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_powerlaw -- python3 bench.py --workload powerlaw --steps 20 --warmup 3 --cpu-seconds 0 > $O/trace_powerlaw.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_generalgnn -- python3 bench.py --model generalgnn --prec bf16x3 --steps 50 --warmup 5 --cpu-seconds 0 > $O/trace_generalgnn.log 2>&1
+fi
+if [ $STAGE = all ] || [ $STAGE = pmc ]; then
+for w in ecoli block1m powerlaw; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$w -- python3 scripts/spmm_bench.py --workload $w --rounds 1 --iters 5 --slabs 0 > $O/pmc_fetch_$w.log 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_write_$w -- python3 scripts/spmm_bench.py --workload $w --rounds 1 --iters 5 --slabs 0 > $O/pmc_write_$w.log 2>&1
 done
+fi
+if [ $STAGE = all ] || [ $STAGE = gemm ]; then
 # MFMA utilisation of the weight GEMMs (north_star: "MFMA utilisation on the GEMM against gfx950 peak"): SQ counters in two
 # passes (8 SQ slots per pass), config-3 shapes (N = 1M, 256 x 256), every precision
 for p in f32 bf16x3 bf16; do
@@ -29,6 +39,7 @@ for p in f32 bf16x3 bf16; do
   python3 scripts/gemm_bench.py --n 1000000 --shapes 256x256 --prec $p --iters 10 > $O/gemm_bench_$p.txt 2>&1
 done
 python3 scripts/mfma_util.py $O > $O/gemm_mfma_util.txt 2>&1
+fi
 # keep the summaries, drop the per-dispatch traces (large)
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -size +3M -delete

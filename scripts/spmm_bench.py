@@ -16,6 +16,9 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--slabs", default="0")
 ap.add_argument("--unweighted", action="store_true")
 ap.add_argument("--shard", default="", help="r,w: rank r's shard of w (block1m; the cut bench.py makes)")
+ap.add_argument("--pads", default="", help="comma list of MiB: re-time with h and out re-allocated that far apart (HBM channel phase of the two streams)")
+ap.add_argument("--hog", type=int, default=0, help="GiB allocated (and kept) before anything else: does where the arrays land matter?")
+ap.add_argument("--hog-after-csr", type=int, default=0)
 ap.add_argument("--conc", type=int, default=-1, help="1 / 0: the plan path's launches as concurrent branches or not (spmm_conc)")
 args = ap.parse_args()
 if args.workload == "block1m":       # the batches bench.py times (per-graph-seeded generators)
@@ -33,8 +36,10 @@ else:
     hb = synth.power_law_batch(122, 8192, 256, seed=3, with_x=False, first_graph=0); f = 256
 vals = None if args.unweighted else synth.gcn_norm_host(hb.rowptr, hb.colidx)
 ctx = gcnx.Context(0)
+_hog = [ctx.empty((1 << 28,)) for _ in range(args.hog)]
 if args.conc >= 0: ctx.set_tuning("spmm_conc", args.conc)
 a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+_hog2 = [ctx.empty((1 << 28,)) for _ in range(args.hog_after_csr)]
 h = ctx.to_device(np.random.default_rng(0).standard_normal((hb.n, f), dtype=np.float32))
 out = ctx.empty((hb.n, f)); bias = ctx.zeros(f)
 alg = synth.spmm_algorithmic_bytes(hb.n, hb.nnz, f, vals is not None)
@@ -65,4 +70,16 @@ for rnd in range(args.rounds):
         ms = e1.elapsed_ms_since(e0) / args.iters
         chk = float(np.abs(out.numpy()[::1009]).sum())
         print(f"round {rnd} slab {slab:>8}: {ms*1e3:9.1f} us  {alg/ms/1e6:8.1f} GB/s  frac {alg/ms/1e6/8000:.3f}  chk {chk:.6g}", flush=True)
+if args.pads:
+    hh = h.numpy(); del h, out
+    for pad in args.pads.split(","):
+        keep = [ctx.empty((int(float(pad) * 262144),)) ] if float(pad) > 0 else []
+        h2 = ctx.to_device(hh); keep2 = [ctx.empty((int(float(pad) * 262144),))] if float(pad) > 0 else []; o2 = ctx.empty((hb.n, f))
+        ctx.set_tuning("spmm_kernel", "auto"); ctx.set_tuning("spmm_slab", 0)
+        for _ in range(3): D.spmm(ctx, a, h2, bias, o2, act="relu")
+        e0 = ctx.event().record()
+        for _ in range(args.iters): D.spmm(ctx, a, h2, bias, o2, act="relu")
+        ms = ctx.event().record().elapsed_ms_since(e0) / args.iters
+        print(f"pad {pad:>8} MiB  h @{h2.ptr:#x} out @{o2.ptr:#x} diff {(o2.ptr - h2.ptr) / 2**20:10.3f} MiB: {ms*1e3:9.1f} us  frac {alg/ms/1e6/8000:.3f}", flush=True)
+        del h2, o2, keep, keep2
 ctx.close()

@@ -3,14 +3,19 @@
 import collections, csv, glob, json, os, shutil, sys
 d = sys.argv[1]
 pmc_json = {}
-for w in ("ecoli", "block1m"):
+for w in ("ecoli", "block1m", "powerlaw", "generalgnn"):
     p = os.path.join(d, f"bench_{w}.json")
     if os.path.exists(p):
         for line in open(p):
             if line.startswith("{"):
                 r = json.loads(line)
-                print(f"[bench {w}] {r['value']:.0f} graphs/s  {r['ms_per_step']:.3f} ms/step  SpMM {r['roofline']['avg_launch_us']:.1f} us "
-                      f"{r['roofline']['achieved']:.0f} GB/s frac {r['roofline']['frac']:.3f}")
+                rf = r.get("roofline")
+                if rf is None:
+                    print(f"[bench {w}] {r['value']:.0f} graphs/s  {r['ms_per_step']:.3f} ms/step  ({r['config']['workload'][:80]})"); continue
+                print(f"[bench {w}] {r['value']:.0f} graphs/s  {r['ms_per_step']:.3f} ms/step  {rf.get('kernel', 'SpMM')[:40]} {rf.get('avg_launch_us', 0):.1f} us "
+                      f"{rf['achieved']:.0f} {rf['unit']} frac {rf['frac']:.3f}")
+                if "cold" in r: print(f"        cold (right after warm-up) {r['cold']}")
+                if "generalgnn" in r: print(f"        generalgnn {r['generalgnn']}")
                 if "roofline_config3" in r:
                     b = r["roofline_config3"]; print(f"        config3 SpMM {b['avg_launch_us']:.1f} us {b['achieved']:.0f} GB/s frac {b['frac']:.3f}")
                 if "cpu_baseline" in r:
