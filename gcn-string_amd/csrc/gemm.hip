@@ -1010,6 +1010,56 @@ int gcnx_gemm_dx_bits(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float*
   return rc;                                   // (UNSUPPORTED without a message, as above)
 }
 
+// bf16 STORAGE between bf16-operand weight GEMMs (r3).  GCNX_PREC_BF16 rounds both operands of every product to bf16 when
+// it loads them; an activation that only such products read can therefore be STORED as bf16 (round to nearest even at the
+// producer) without changing a single bit of any result, and every kernel on the chain moves half the bytes.  These are
+// the three products with the streamed operand(s) read as bf16 (uint16 rows, leading dimensions in elements) and, for the
+// first two, the result written as bf16 (out_bf16) or fp32.  Streaming kernels only: GCNX_ERR_UNSUPPORTED, without a
+// message and with nothing launched, for any other shape (fi = fo = 256, n >= 32768, 16-byte aligned rows).
+int gcnx_gemm_fwd_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const float* w, const float* bias, void* out, int64_t ldo,
+                       int out_bf16, int64_t n, int32_t fi, int32_t fo, int act, void* relu_bits) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (X W)");
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_fwd_bf16: negative size");
+  GCNX_REQUIRE(ctx, x16 && w && out, "gcnx_gemm_fwd_bf16: NULL pointer");
+  GCNX_REQUIRE(ctx, ldx >= fi && ldo >= fo, "gcnx_gemm_fwd_bf16: leading dimension too small");
+  GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_gemm_fwd_bf16: activation %d not supported here", act);
+  GCNX_REQUIRE(ctx, !relu_bits || act == GCNX_ACT_RELU, "gcnx_gemm_fwd_bf16: the bit image is that of a ReLU output");
+  if (fi != 256 || fo != 256 || (bias && !al16(bias))) return GCNX_ERR_UNSUPPORTED;
+  return gcnx_gemm_stream_bf16(ctx, x16, ldx, w, fi, fo, 1, out, ldo, out_bf16, n, bias, act, nullptr, nullptr, relu_bits);
+}
+
+int gcnx_gemm_dx_bf16(gcnx_ctx* ctx, const void* dh16, int64_t lddh, const float* w, void* dx, int64_t lddx, int dx_bf16, int64_t n,
+                      int32_t fi, int32_t fo, const void* mask_bits, float* db) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (dX)");
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dx_bf16: negative size");
+  GCNX_REQUIRE(ctx, dh16 && w && dx, "gcnx_gemm_dx_bf16: NULL pointer");
+  GCNX_REQUIRE(ctx, lddh >= fo && lddx >= fi, "gcnx_gemm_dx_bf16: leading dimension too small");
+  if (fi != 256 || fo != 256) return GCNX_ERR_UNSUPPORTED;
+  return gcnx_gemm_stream_bf16(ctx, dh16, lddh, w, fi, fo, 0, dx, lddx, dx_bf16, n, nullptr, GCNX_ACT_NONE, db, mask_bits, nullptr);
+}
+
+int gcnx_gemm_dw_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const void* dh16, int64_t lddh, float* dw, int64_t n,
+                      int32_t fi, int32_t fo) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "weight GEMM (dW)");
+  GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dw_bf16: negative size");
+  GCNX_REQUIRE(ctx, x16 && dh16 && dw, "gcnx_gemm_dw_bf16: NULL pointer");
+  GCNX_REQUIRE(ctx, ldx >= fi && lddh >= fo, "gcnx_gemm_dw_bf16: leading dimension too small");
+  if (fi != 256 || fo != 256 || n < 32 * 1024 || !ctx->knob_gemm_stream || !al16(dw)) return GCNX_ERR_UNSUPPORTED;
+  const int max_slices = ctx->num_cus;
+  int rc = gcnx_ws_reserve(ctx, (size_t)max_slices * 65536 * sizeof(float));
+  if (rc) return rc;
+  const int ns = gcnx_gemm_dw_stream16(ctx, x16, ldx, dh16, lddh, (float*)ctx->ws, n, fi, fo, max_slices);
+  if (ns < 0) return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_gemm_dw_bf16: streaming kernel launch failed");
+  if (ns == 0) return GCNX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(gcnx_cdiv(65536, 256)), dim3(256), 0, ctx->stream, (const float*)ctx->ws, (int64_t)65536,
+                     ns, dw, (int64_t)65536);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
 int gcnx_gemm_dx(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float* w, float* dx, int64_t lddx, int64_t n,
                  int32_t fi, int32_t fo, int prec, int accumulate, const float* y_mask, int64_t ldy, float* db) {
   GCNX_CHECK_CTX(ctx);

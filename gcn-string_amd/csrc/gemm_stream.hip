@@ -103,11 +103,18 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, sbf16x8
 // hipcc from re-serialising it): the weight fragments of block b + 1 are read from LDS and a quarter of the NEXT K
 // step's activations is converted fp32 -> bf16 (hi, lo) while the MFMAs of block b issue; the activation loads that
 // replace the converted ring slot go out at the end of the step.
-template <int NP, int CW, int RT, int KSTEPS, int MASK>
+// IN16 / OUT16 (r3, plain bf16 only): the streamed operand is already stored as bf16 (`a` points at uint16 rows, lda in
+// elements) / the result is stored as bf16 (round to nearest even -- exactly the rounding the NEXT weight GEMM would apply
+// to an fp32 copy, so a chain of bf16-operand GEMMs computes the same bits with half the traffic).  A bf16 row piece of
+// 8 k is ONE 16-byte load that is the MFMA fragment as it stands: no conversion, and the ring is eight K steps deep
+// (the same 32 registers, 64 KiB in flight per CU).
+template <int NP, int CW, int RT, int KSTEPS, int MASK, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __restrict__ a, int64_t lda, const __bf16* __restrict__ wimg,
                                                              float* __restrict__ c, int64_t ldc, int64_t M, int ncol, StreamEpi ep,
                                                              int n_rb, int halves) {
-  constexpr int kSDepth = StreamDepth<MASK>::value;
+  static_assert(!IN16 || (NP == 1 && MASK != 1), "bf16 input: plain bf16 products, bit-image masks");
+  constexpr int kSDepth = IN16 ? 8 : StreamDepth<MASK>::value;
+  constexpr unsigned AB = IN16 ? 2u : 4u, CB = OUT16 ? 2u : 4u;       // bytes per streamed / stored element
   constexpr int CT = CW / 16;                            // column tiles per workgroup
   constexpr int NB = CT / 2;                             // blocks of two column tiles per K step
   constexpr int NF = 2 * RT;                             // float4 loads per lane and K step
@@ -157,13 +164,13 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   const int nunits = pair < n_rb ? (n_rb - pair + npairs - 1) / npairs : 0;
   const int total = nunits * KSTEPS;
   const __amdgpu_buffer_rsrc_t ars =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a, (short)0, (GCNX_STREAM_ABL & 1) ? 0 : (int)((uint64_t)M * (uint64_t)lda * 4u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)a, (short)0, (GCNX_STREAM_ABL & 1) ? 0 : (int)((uint64_t)M * (uint64_t)lda * AB), 0x00020000);
   const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(MASK == 1 ? (const void*)ep.mask : MASK == 2 ? (const void*)ep.mbits_in : (const void*)a), (short)0,
       MASK == 1 ? (int)((uint64_t)M * (uint64_t)ep.ldmask * 4u) : MASK == 2 ? (int)((uint64_t)M * (uint64_t)halves * 32u) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)c, (short)0, (GCNX_STREAM_ABL & 2) ? 0 : (int)((uint64_t)M * (uint64_t)ldc * 4u), 0x00020000);
-  const unsigned lda4 = (unsigned)lda * 4u, ldm4 = (unsigned)ep.ldmask * 4u, ldc4 = (unsigned)ldc * 4u;
+      __builtin_amdgcn_make_buffer_rsrc((void*)c, (short)0, (GCNX_STREAM_ABL & 2) ? 0 : (int)((uint64_t)M * (uint64_t)ldc * CB), 0x00020000);
+  const unsigned lda4 = (unsigned)lda * AB, ldm4 = (unsigned)ep.ldmask * 4u, ldc4 = (unsigned)ldc * CB;     // row strides in bytes
   const int wrow = wave * ROWS + rl;                     // this lane's row inside a block (tile 0; tile t = + 16 t)
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(ep.bits_out ? (void*)ep.bits_out : (void*)c), (short)0, ep.bits_out ? (int)((uint64_t)M * (uint64_t)halves * 32u) : 0, 0x00020000);
@@ -179,7 +186,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
     return (unsigned long long)w_[0] | ((unsigned long long)w_[1] << 32);
   };
 
-  float4 pf[kSDepth][NF];                                // activation ring: [step % depth][tile * 2 + (0: k 0..3, 1: k 4..7)]
+  float4 pf[IN16 ? 1 : kSDepth][NF];                     // activation ring: [step % depth][tile * 2 + (0: k 0..3, 1: k 4..7)]
+  si32x4 pq[IN16 ? kSDepth : 1][RT];                     // IN16: [step % depth][tile] = the 8 bf16 of the lane's row piece
   float4 mk[kSDepth][2];                                 // MASK: the mask pieces that ride with the same step
 
   // Loads of flat step t (unit t / KSTEPS, K step t % KSTEPS).  Range-checked: steps past the end and rows past M
@@ -192,9 +200,13 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
     const bool live_ = t_ < total;                                                                                 \
     _Pragma("unroll") for (int tt = 0; tt < RT; ++tt) {                                                            \
       const int64_t row_ = r0_ + tt * 16;                                                                          \
-      const unsigned off_ = (live_ && row_ < M) ? (unsigned)row_ * lda4 + (unsigned)(ks_ * 32 + q * 8) * 4u : 0xFFFFFFE0u; \
-      pf[SLOT][tt * 2] = sbuf4(ars, off_);                                                                         \
-      pf[SLOT][tt * 2 + 1] = sbuf4(ars, off_ + 16u);                                                               \
+      const unsigned off_ = (live_ && row_ < M) ? (unsigned)row_ * lda4 + (unsigned)(ks_ * 32 + q * 8) * AB : 0xFFFFFFE0u; \
+      if constexpr (IN16) {                                                                                        \
+        pq[SLOT][tt] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, off_, 0, GCNX_STREAM_LOAD_AUX)); \
+      } else {                                                                                                     \
+        pf[SLOT][tt * 2] = sbuf4(ars, off_);                                                                       \
+        pf[SLOT][tt * 2 + 1] = sbuf4(ars, off_ + 16u);                                                             \
+      }                                                                                                            \
     }                                                                                                              \
     if (MASK == 1) {                                                                                               \
       _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                              \
@@ -209,7 +221,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
   }
   // One float4 (4 consecutive k) of ring slot SLOT -> elements 4 (F & 1) .. + 3 of the bf16 fragments of tile F / 2.
 #define GS_CONVERT(SLOT, F, XH, XL)                                                                               \
-  {                                                                                                                \
+  if constexpr (IN16) {                                                                                            \
+    if (((F) & 1) == 0) XH[(F) / 2] = __builtin_bit_cast(sbf16x8, pq[SLOT][(F) / 2]);                              \
+  } else {                                                                                                         \
     const float4 v_ = pf[SLOT][F];                                                                                 \
     const float f_[4] = {v_.x, v_.y, v_.z, v_.w};                                                                  \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
@@ -338,8 +352,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
         }
         // range-checked store: rows past M / columns past ncol get an out-of-range offset and are dropped -- no branch
         // (a load or store inside a branch makes hipcc drain the whole prefetch ring with vmcnt(0))
-        const unsigned off = (row < M && col < ncol) ? (unsigned)row * ldc4 + (unsigned)col * 4u : 0xFFFFFFE0u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(si32x4, sf32x4{v.x, v.y, v.z, v.w}), crs, off, 0, GCNX_STREAM_STORE_AUX);
+        const unsigned off = (row < M && col < ncol) ? (unsigned)row * ldc4 + (unsigned)col * CB : 0xFFFFFFE0u;
+        if constexpr (OUT16) {
+          typedef __bf16 sbf16x4 __attribute__((ext_vector_type(4)));
+          typedef int si32x2 __attribute__((ext_vector_type(2)));
+          const sbf16x4 o16 = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(si32x2, o16), crs, off, 0, GCNX_STREAM_STORE_AUX);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(si32x4, sf32x4{v.x, v.y, v.z, v.w}), crs, off, 0, GCNX_STREAM_STORE_AUX);
+        }
         if (MASK == 0)
           obits |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << ((tt * CT + ct) * 4);
         if (ep.colpart) {
@@ -471,6 +492,64 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
   return gcnx_colsum_partials(ctx, prow, ncol, colsum_out);
 }
 
+namespace {
+// the bf16-storage forms: <1, 256, 1, 8> with a bf16 streamed operand, fp32 or bf16 result; masks as bit images only
+template <bool OUT16>
+int launch_stream16(gcnx_ctx* ctx, const void* a, int64_t lda, const __bf16* img, void* c, int64_t ldc, int64_t m, int ncol,
+                    const StreamEpi& ep) {
+  constexpr size_t lds_bytes = (size_t)8 * 256 * 32 * 2 + 2 * 256 * 4 + (size_t)kSWaves * 256 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<1, 256, 1, 8, 0, true, OUT16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<1, 256, 1, 8, 2, true, OUT16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  const int n_rb = gcnx_cdiv(m, 16 * kSWaves);
+  int grid = ctx->num_cus;
+  if (grid > n_rb) grid = n_rb;
+  if (ep.mbits_in)
+    hipLaunchKernelGGL((gemm_stream_kernel<1, 256, 1, 8, 2, true, OUT16>), dim3(grid), dim3(512), lds_bytes, ctx->stream,
+                       (const float*)a, lda, img, (float*)c, ldc, m, ncol, ep, n_rb, 1);
+  else
+    hipLaunchKernelGGL((gemm_stream_kernel<1, 256, 1, 8, 0, true, OUT16>), dim3(grid), dim3(512), lds_bytes, ctx->stream,
+                       (const float*)a, lda, img, (float*)c, ldc, m, ncol, ep, n_rb, 1);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+}  // namespace
+
+// X W (transpose = 1) / dH W^T (transpose = 0) with the streamed operand stored as bf16 and the result stored as bf16
+// (c_bf16) or fp32: plain bf16 products, K = 256, 256 output columns, tall inputs.  The entry point checks the arguments;
+// this returns GCNX_ERR_UNSUPPORTED without a message for shapes outside the kernel.
+int gcnx_gemm_stream_bf16(gcnx_ctx* ctx, const void* a16, int64_t lda, const float* w, int fi, int fo, int transpose, void* c,
+                          int64_t ldc, int c_bf16, int64_t m, const float* bias, int act, float* colsum_out, const void* mask_bits,
+                          void* bits_out) {
+  const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
+  if (ctx->knob_gemm_stream == 0 || K != 256 || ncol != 256 || m < 32 * 1024) return GCNX_ERR_UNSUPPORTED;
+  if (lda % 8 || ldc % 4 || !sal16(a16) || !sal16(c) || (uint64_t)m * (uint64_t)lda * 2u >= 0xFFFFFF00ull ||
+      (uint64_t)m * (uint64_t)ldc * (c_bf16 ? 2u : 4u) >= 0xFFFFFF00ull || (uint64_t)m * 64u >= 0xFFFFFF00ull ||
+      (reinterpret_cast<uintptr_t>(mask_bits) & 7) || (reinterpret_cast<uintptr_t>(bits_out) & 7))
+    return GCNX_ERR_UNSUPPORTED;
+  if (colsum_out && !sal16(colsum_out)) return GCNX_ERR_UNSUPPORTED;
+  const size_t img_elems = (size_t)8 * 256 * 32;
+  const int64_t prow = colsum_out ? ctx->num_cus : 0;
+  const size_t part_bytes = colsum_out ? ((gcnx_colsum_partials_ws(prow, ncol) + 255) & ~(size_t)255) : 0;
+  int rc = gcnx_ws_reserve(ctx, part_bytes + img_elems * sizeof(__bf16) + 256);
+  if (rc) return rc;
+  __bf16* img = (__bf16*)((char*)ctx->ws + part_bytes);
+  hipLaunchKernelGGL(stream_wprep_kernel, dim3(gcnx_cdiv((long long)img_elems, 256)), dim3(256), 0, ctx->stream, w, fi, fo, transpose,
+                     1, 256, 8, ncol, img);
+  GCNX_LAUNCH_OK(ctx);
+  const StreamEpi ep{bias, nullptr, nullptr, 0, act, 0, colsum_out ? (float*)ctx->ws : nullptr,
+                     (const unsigned long long*)mask_bits, (unsigned long long*)bits_out};
+  if (colsum_out) GCNX_HIP(ctx, hipMemsetAsync(ctx->ws, 0, (size_t)prow * ncol * sizeof(float), ctx->stream));
+  rc = c_bf16 ? launch_stream16<true>(ctx, a16, lda, img, c, ldc, m, ncol, ep) : launch_stream16<false>(ctx, a16, lda, img, c, ldc, m, ncol, ep);
+  if (rc || !colsum_out) return rc;
+  return gcnx_colsum_partials(ctx, prow, ncol, colsum_out);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // dW[Fi, Fo] = X^T[Fi, N] dH[N, Fo]  (MatMul grad wrt the kernel, gcn.py:337): the reduction runs over the N rows
 // (10^6 at config 3), both operands are streamed once and BOTH need the row index as the MFMA k index, i.e. a
@@ -516,10 +595,14 @@ __device__ __forceinline__ void dw_store4(char* dst, const float4& v, bool lo_to
 }
 
 // x [N, ldx] (columns 0..255), dh [N, lddh] (columns 0..255); out: slab + blockIdx.x * 65536 floats = dW[i][o].
-template <int NP>
+// IN16 (r3, plain bf16): both operands are stored as bf16 -- a thread stages 8 columns of two rows per matrix with one
+// 16-byte load each and writes them to the LDS rows as they are (no conversion; half the bytes of the fp32 form).
+template <int NP, bool IN16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ dh, int64_t lddh,
                                                                 float* __restrict__ out, int64_t n, int64_t rows_per_wg) {
+  static_assert(!IN16 || NP == 1, "bf16 operands: plain bf16 products");
+  constexpr unsigned EB = IN16 ? 2u : 4u;
   extern __shared__ __attribute__((aligned(16))) char dlds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg;
@@ -528,15 +611,25 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 
   // blockIdx.y (r3): a 256-column panel of a wider x -- dW of a Dense layer with fi = 256 p inputs (GeneralGNN's concat
   // skips) as p products over the same row slices; panel q's slabs follow panel q - 1's
-  x += (size_t)blockIdx.y * 256;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)((uint64_t)n * (uint64_t)ldx * 4u - (uint64_t)blockIdx.y * 1024u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)dh, (short)0, (int)((uint64_t)n * (uint64_t)lddh * 4u), 0x00020000);
-  const unsigned ldx4 = (unsigned)ldx * 4u, ldd4 = (unsigned)lddh * 4u;
-  // staging: thread -> row (tid >> 6) + 8 j (j = 0..3), columns 4 (tid & 63) .. + 3
-  const int srow = tid >> 6, scol4 = (tid & 63) * 4;
+  x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)blockIdx.y * 256 * EB);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, (int)((uint64_t)n * (uint64_t)ldx * EB - (uint64_t)blockIdx.y * 256u * EB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)dh, (short)0, (int)((uint64_t)n * (uint64_t)lddh * EB), 0x00020000);
+  const unsigned ldx4 = (unsigned)ldx * EB, ldd4 = (unsigned)lddh * EB;              // row strides in bytes
+  // staging: thread -> row (tid >> 6) + 8 j (j = 0..3), columns 4 (tid & 63) .. + 3;  IN16: row (tid >> 5) + 16 j (j = 0, 1),
+  // columns 8 (tid & 31) .. + 7
+  const int srow = IN16 ? tid >> 5 : tid >> 6, scol4 = IN16 ? (tid & 31) * 8 : (tid & 63) * 4;
   float4 sx[4], sd[4];
+  si32x4 qx[2], qd[2];
 #define DW_ISSUE(STEP)                                                                                            \
-  {                                                                                                                \
+  if constexpr (IN16) {                                                                                            \
+    const int64_t rb_ = r_begin + (int64_t)(STEP) * 32 + srow;                                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+      const int64_t r_ = rb_ + 16 * j;                                                                             \
+      const bool ok_ = (STEP) < nsteps && r_ < r_end;                                                              \
+      qx[j] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)r_ * ldx4 + (unsigned)scol4 * 2u : 0xFFFFFFE0u, 0, GCNX_STREAM_LOAD_AUX)); \
+      qd[j] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, ok_ ? (unsigned)r_ * ldd4 + (unsigned)scol4 * 2u : 0xFFFFFFE0u, 0, GCNX_STREAM_LOAD_AUX)); \
+    }                                                                                                              \
+  } else {                                                                                                         \
     const int64_t rb_ = r_begin + (int64_t)(STEP) * 32 + srow;                                                     \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
       const int64_t r_ = rb_ + 8 * j;                                                                              \
@@ -546,7 +639,13 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
     }                                                                                                              \
   }
 #define DW_WRITE(STAGE)                                                                                            \
-  {                                                                                                                \
+  if constexpr (IN16) {                                                                                            \
+    char* sb_ = dlds + (STAGE) * DwLds<NP>::stage + srow * kDwRowB + scol4 * 2;                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+      *reinterpret_cast<si32x4*>(sb_ + j * 16 * kDwRowB) = qx[j];                                                  \
+      *reinterpret_cast<si32x4*>(sb_ + NP * kDwPlane + j * 16 * kDwRowB) = qd[j];                                  \
+    }                                                                                                              \
+  } else {                                                                                                         \
     char* sb_ = dlds + (STAGE) * DwLds<NP>::stage + srow * kDwRowB + scol4 * 2;                                    \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
       dw_store4(sb_ + j * 8 * kDwRowB, sx[j], NP == 2);                                                            \
@@ -594,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 #pragma unroll
       for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
     }
-    if (s + 1 < nsteps) DW_WRITE(st ^ 1)                  // (the other stage was last read before the previous barrier)
+    if (s + 1 < nsteps) { DW_WRITE(st ^ 1) }              // (the other stage was last read before the previous barrier)
     __syncthreads();
   }
 #undef DW_ISSUE
@@ -666,6 +765,25 @@ int gcnx_gemm_dw_panels(gcnx_ctx* ctx, const float* x, int64_t ldx, const float*
   if (hipGetLastError() != hipSuccess) return -1;
   hipLaunchKernelGGL(dw_panel_reduce_kernel, dim3(65536 / 4 / 256, panels), dim3(256), 0, ctx->stream, (const float*)ctx->ws, slices, dw);
   return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+
+// The same with both operands stored as bf16 (uint16 rows, leading dimensions in elements): plain bf16 products.
+int gcnx_gemm_dw_stream16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const void* dh16, int64_t lddh, float* slabs, int64_t n,
+                          int32_t fi, int32_t fo, int max_slices) {
+  if (ctx->knob_gemm_stream == 0 || fi != 256 || fo != 256 || n < 32 * 1024) return 0;
+  if (ldx % 8 || lddh % 8 || !sal16(x16) || !sal16(dh16) || (uint64_t)n * (uint64_t)ldx * 2u >= 0xFFFFFF00ull ||
+      (uint64_t)n * (uint64_t)lddh * 2u >= 0xFFFFFF00ull)
+    return 0;
+  int slices = ctx->num_cus < max_slices ? ctx->num_cus : max_slices;
+  const int64_t steps = (n + 31) / 32;
+  if (slices > steps) slices = (int)steps;
+  const int64_t rows_per = ((steps + slices - 1) / slices) * 32;
+  slices = (int)((n + rows_per - 1) / rows_per);
+  static bool set16 = false;
+  if (!set16) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dw_stream_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DwLds<1>::total) != hipSuccess) return 0; set16 = true; }
+  hipLaunchKernelGGL((gemm_dw_stream_kernel<1, true>), dim3(slices), dim3(512), DwLds<1>::total, ctx->stream, (const float*)x16, ldx,
+                     (const float*)dh16, lddh, slabs, n, rows_per);
+  return hipGetLastError() == hipSuccess ? slices : -1;
 }
 
 int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* slabs, int64_t n,

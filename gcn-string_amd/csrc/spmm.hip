@@ -101,7 +101,16 @@ __device__ unsigned long long* g_wave_stamps = nullptr;
 #define GCNX_WSTAMP_END
 #endif
 
-template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false, bool HUBS = false>
+// OUT16 forms (r3): the result row is stored as bf16, round to nearest even -- for outputs that only bf16-operand weight
+// GEMMs read, which would round an fp32 copy in exactly this way (gcnx_spmm_csr_bf16out).  `out` then points at uint16 rows
+// and ldo counts elements.
+__device__ __forceinline__ void store4_bf16(float* out, int64_t elem, const float4& v) {
+  typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+  const b16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<b16x4*>(reinterpret_cast<unsigned short*>(out) + elem) = o;
+}
+
+template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false, bool HUBS = false, bool OUT16 = false>
 __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   // 8 waves per SIMD = at most 64 VGPRs (latency regime)
    const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ colidx,
@@ -228,7 +237,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
           acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         }
       }
-      *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
+      if constexpr (OUT16) store4_bf16(out, (int64_t)r * ldo + c, acc);
+      else *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
     }
   };
   constexpr int kLongRow = RPC <= 8 ? kLongRowSmall : kLongRowLarge;
@@ -428,7 +438,8 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
         t = f4_add(t, bv);
         if (act == GCNX_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
       }
-      *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = t;
+      if constexpr (OUT16) store4_bf16(out, (int64_t)r * ldo + c, t);
+      else *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = t;
     }
   }
   GCNX_WSTAMP_END
@@ -642,7 +653,7 @@ struct DuoFold {
 };
 enum { kDuoPlain = 0, kDuoFold = 1, kDuoBitsOut = 2, kDuoFoldBits = 3 };
 
-template <int THREADS, int FT, int LPR, bool WEIGHTED, int MODE = kDuoPlain>
+template <int THREADS, int FT, int LPR, bool WEIGHTED, int MODE = kDuoPlain, bool OUT16 = false>
 __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
     const int32_t* __restrict__ rowptr, const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
     const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh, const float* __restrict__ bias,
@@ -834,7 +845,8 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
             if (!FOLD && act == GCNX_ACT_RELU) {
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
+            if constexpr (OUT16) store4_bf16(out, (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4, o);
+            else *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
             if constexpr (MODE == kDuoBitsOut)
               bword |= ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u))
                        << (4 * (sub + LPR * (j ^ csw)));
@@ -1235,8 +1247,21 @@ template <int LPR>
 void launch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                  int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
                  const int2* chunk_list = nullptr, int list_len = 0, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk,
-                 int hub_deg = 0) {
+                 int hub_deg = 0, int out16 = 0) {
   const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
+  if (out16) {   // (bf16 result rows: the one shape the bf16-storage path of large batches needs -- the caller has checked it)
+    if constexpr (LPR == 64) {
+      for (int col0 = 0; col0 < f; col0 += LPR * 4) {
+        if (fold)
+          hipLaunchKernelGGL((spmm_rows_kernel<64, true, kRowsPerChunkSmall, true, false, true>), dim3(list_len), dim3(256), 0, ctx->stream, rowptr,
+                             colidx, vals, h, ldh, bias, out, ldo, n, f, col0, act, list_len, chunk_list, fo, 0);
+        else
+          hipLaunchKernelGGL((spmm_rows_kernel<64, true, kRowsPerChunkSmall, false, false, true>), dim3(list_len), dim3(256), 0, ctx->stream, rowptr,
+                             colidx, vals, h, ldh, bias, out, ldo, n, f, col0, act, list_len, chunk_list, fo, 0);
+      }
+    }
+    return;
+  }
   const bool small = chunk_list ? list_rpc <= kRowsPerChunkSmall : n < 16 * 1024 * kRowsPerChunk / 4;   // < 128k rows
   const int nchunks = chunk_list ? list_len : gcnx_cdiv(n, small ? kRowsPerChunkSmall : kRowsPerChunk);
   const int span = LPR * 4;
@@ -1257,7 +1282,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                    int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk, int hub_deg = 0) {
+                   const int2* chunk_list, int list_len, const FoldArgs* fold = nullptr, int list_rpc = kRowsPerChunk, int hub_deg = 0,
+                   int out16 = 0) {
+  if (out16) { launch_rows<64>(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, chunk_list, list_len, fold, list_rpc, 0, 1); return; }
   int lanes = f / 4;
   // Tuning knob (not part of the ABI contract): GCNX_SPMM_SLAB = column-slab width in floats
   // forces the lanes-per-row split of the rows kernel; results are identical.
@@ -1272,7 +1299,7 @@ void dispatch_rows(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, 
 template <int THREADS, int FT, int LPR>
 int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const int32_t* colidx, const float* vals, const float* h,
                int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-               const int2* graphs, int ngraphs, const DuoFold* fold = nullptr, int mode = kDuoPlain) {
+               const int2* graphs, int ngraphs, const DuoFold* fold = nullptr, int mode = kDuoPlain, int out16 = 0) {
   constexpr int lds_bytes = DuoShape<THREADS, FT>::LDSF * 4;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1282,6 +1309,12 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
     GCNX_DUO_ATTR(true, kDuoPlain); GCNX_DUO_ATTR(false, kDuoPlain); GCNX_DUO_ATTR(true, kDuoFold); GCNX_DUO_ATTR(false, kDuoFold);
     GCNX_DUO_ATTR(true, kDuoBitsOut); GCNX_DUO_ATTR(false, kDuoBitsOut); GCNX_DUO_ATTR(true, kDuoFoldBits); GCNX_DUO_ATTR(false, kDuoFoldBits);
 #undef GCNX_DUO_ATTR
+    if constexpr (THREADS == 1024) {     // the bf16-result forms (weighted, plain / folded from the bit image)
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true, kDuoPlain, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true, kDuoFoldBits, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    }
     attr_set = true;
   }
   int dbg = 0;
@@ -1310,7 +1343,16 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
 #define GCNX_DUO_LAUNCH(W, M)                                                                                                \
   hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, W, M>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, rowrec, \
                      colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo)
-  if (vals) {
+  if (out16) {
+    if constexpr (THREADS == 1024) {
+      if (mode == kDuoFoldBits)
+        hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true, kDuoFoldBits, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
+                           rowrec, colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo);
+      else
+        hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true, kDuoPlain, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
+                           rowrec, colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo);
+    }
+  } else if (vals) {
     switch (mode) {
       case kDuoFold: GCNX_DUO_LAUNCH(true, kDuoFold); break;
       case kDuoBitsOut: GCNX_DUO_LAUNCH(true, kDuoBitsOut); break;
@@ -1626,7 +1668,24 @@ int gcnx_spmm_plan_bind(gcnx_ctx* ctx, gcnx_spmm_plan* plan, const int32_t* rowp
 
 static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                          int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                         const gcnx_spmm_plan* plan, uint32_t* relu_bits);
+                         const gcnx_spmm_plan* plan, uint32_t* relu_bits, int out16 = 0);
+
+// The conditions of the bf16-result forms (gcnx_spmm_csr_bf16out / _pool_bwd_bf16out): weighted operator, every tile
+// graph on the 1024-thread shape, taller graphs as 8-row chunks, no hub rows.
+static bool out16_shape_ok(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const float* vals, int32_t f, int64_t ldo, const void* out) {
+  return plan && vals && f % kSlab == 0 && f > 128 && ldo % 4 == 0 && aligned16(out) && plan->n1 == 0 && plan->n2 > 0 &&
+         (plan->nchunks == 0 || plan->chunk_rpc == kRowsPerChunkSmall) && ctx->knob_spmm_kernel != 1 && ctx->knob_spmm_kernel != 3 &&
+         (long long)(2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
+}
+
+int gcnx_spmm_csr_bf16out(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                          int64_t ldh, const float* bias, void* out16, int64_t ldo, int32_t n, int32_t f, int act,
+                          const gcnx_spmm_plan* plan) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, out16 != nullptr || n == 0 || f == 0, "gcnx_spmm_csr_bf16out: NULL output");
+  if (!out16_shape_ok(ctx, plan, vals, f, ldo, out16)) return GCNX_ERR_UNSUPPORTED;       // (an answer, not a failure: no message)
+  return spmm_csr_impl(ctx, rowptr, colidx, vals, h, ldh, bias, (float*)out16, ldo, n, f, act, plan, nullptr, 1);
+}
 
 int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                   int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
@@ -1644,7 +1703,7 @@ int gcnx_spmm_csr_relu_bits(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t*
 
 static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
                          int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
-                         const gcnx_spmm_plan* plan, uint32_t* relu_bits) {
+                         const gcnx_spmm_plan* plan, uint32_t* relu_bits, int out16) {
   GCNX_CHECK_CTX(ctx);
   GCNX_RANGE(ctx, "aggregation (GCNConv / GeneralConv SpMM)");
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr: negative size");
@@ -1655,6 +1714,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   GCNX_REQUIRE(ctx, h != out, "gcnx_spmm_csr: in-place aggregation is not possible");
   const bool vec = (f % 4 == 0) && (ldh % 4 == 0) && (ldo % 4 == 0) && aligned16(h) && aligned16(out) &&
                    (!bias || aligned16(bias));
+  if (out16 && !vec) return GCNX_ERR_UNSUPPORTED;
   if (!vec) {
     hipLaunchKernelGGL(spmm_scalar_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, rowptr, colidx, vals,
                        h, ldh, bias, out, ldo, n, f, act);
@@ -1673,6 +1733,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   const RowRec* rowrec = nullptr;
   const RowOrder* order = nullptr;
   if (plan && force != 3) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
+  if (out16 && (!tiles || (order && order->nsegs_tall > 0))) return GCNX_ERR_UNSUPPORTED;     // (checked by the caller; hub rows: fp32 only)
   if (!tiles) {
     // (with a bound plan: the rows of more than kHubDeg entries go to the hub kernels)
     const bool hubs = order && order->nsegs > 0;
@@ -1758,7 +1819,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   int rc = GCNX_OK;
   if (plan->n2 > 0) {        // (the 1024-thread tier first: its workgroups are the hardest to place)
     rc = launch_duo<1024, 32, 4>(ctx, rowptr, rowrec, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1,
-                                 plan->n2, &bo, dmode);
+                                 plan->n2, &bo, dmode, out16);
   }
   if (!rc && plan->n1 > 0) {
     if (conc) ctx->stream = aux[0];
@@ -1769,7 +1830,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
     if (conc) ctx->stream = aux[1];
     const bool hubs = order && order->nsegs_tall > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks, nullptr, plan->chunk_rpc, hubs ? kHubDeg : 0);
+                  plan->nchunks, nullptr, plan->chunk_rpc, hubs ? kHubDeg : 0, out16);
     if (hipGetLastError() != hipSuccess) rc = gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_csr: row-chunk launch failed");
     if (!rc && hubs) rc = launch_hubs(ctx, order, true, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr);
     ctx->stream = home;
@@ -1778,10 +1839,32 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   return rc;
 }
 
+static int spmm_csr_pool_bwd_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                                  const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
+                                  int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode,
+                                  const gcnx_spmm_plan* plan, const void* y_bits, int out16);
+
 int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                            const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
                            int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode,
                            const gcnx_spmm_plan* plan, const void* y_bits) {
+  return spmm_csr_pool_bwd_impl(ctx, rowptr, colidx, vals, y, ldy, graph_ptr, b, dpooled, lddp, out, ldo, n, f, mode, plan, y_bits, 0);
+}
+
+int gcnx_spmm_csr_pool_bwd_bf16out(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                                   const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
+                                   int64_t lddp, void* out16, int64_t ldo, int32_t n, int32_t f, int mode,
+                                   const gcnx_spmm_plan* plan, const void* y_bits) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, out16 != nullptr || n == 0 || f == 0, "gcnx_spmm_csr_pool_bwd_bf16out: NULL output");
+  if (!y_bits || !plan || plan->nblocks != b || !out16_shape_ok(ctx, plan, vals, f, ldo, out16)) return GCNX_ERR_UNSUPPORTED;
+  return spmm_csr_pool_bwd_impl(ctx, rowptr, colidx, vals, y, ldy, graph_ptr, b, dpooled, lddp, (float*)out16, ldo, n, f, mode, plan, y_bits, 1);
+}
+
+static int spmm_csr_pool_bwd_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                                  const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled,
+                                  int64_t lddp, float* out, int64_t ldo, int32_t n, int32_t f, int mode,
+                                  const gcnx_spmm_plan* plan, const void* y_bits, int out16) {
   GCNX_CHECK_CTX(ctx);
   GCNX_RANGE(ctx, "aggregation bwd (pool' folded)");
   GCNX_REQUIRE(ctx, n >= 0 && f >= 0 && b >= 0, "gcnx_spmm_csr_pool_bwd: negative size");
@@ -1803,6 +1886,7 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
   const RowRec* rowrec = nullptr;
   const RowOrder* order = nullptr;
   if (plan && plan->nblocks == b) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
+  if (out16 && (!tiles || (order && order->nsegs_tall > 0))) return GCNX_ERR_UNSUPPORTED;
   if (!tiles) {
     const bool hubs = order && order->nsegs > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo, kRowsPerChunk, hubs ? kHubDeg : 0);
@@ -1820,13 +1904,13 @@ int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* 
   if (plan->n2 > 0) {
     const DuoFold df{plan->gids + plan->n1, dpooled, lddp, fo.avg, (uint32_t*)y_bits};
     int rc = launch_duo<1024, 32, 4>(ctx, rowptr, rowrec, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1,
-                                     plan->n2, &df, dmode);
+                                     plan->n2, &df, dmode, out16);
     if (rc) return rc;
   }
   if (plan->nchunks > 0) {
     const bool hubs = order && order->nsegs_tall > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks, &fo, plan->chunk_rpc, hubs ? kHubDeg : 0);
+                  plan->nchunks, &fo, plan->chunk_rpc, hubs ? kHubDeg : 0, out16);
     GCNX_LAUNCH_OK(ctx);
     if (hubs) return launch_hubs(ctx, order, true, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, &fo);
   }

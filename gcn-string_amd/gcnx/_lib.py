@@ -85,6 +85,11 @@ SIGNATURES = {
     "gcnx_gemm_dx": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _int, _vp, _i64, _vp],
     "gcnx_gemm_relu_bits": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp],
     "gcnx_gemm_dx_bits": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp, _vp],
+    "gcnx_spmm_csr_bf16out": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp],
+    "gcnx_spmm_csr_pool_bwd_bf16out": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],
+    "gcnx_gemm_fwd_bf16": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _int, _i64, _i32, _i32, _int, _vp],
+    "gcnx_gemm_dx_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _int, _i64, _i32, _i32, _vp, _vp],
+    "gcnx_gemm_dw_bf16": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32],
     "gcnx_dense_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp],
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
     "gcnx_spmm_csr_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],

@@ -442,6 +442,78 @@ def gemm_relu_bits(ctx, x, w, bias, out, bits, prec="bf16"):
     return True
 
 
+# ---- bf16 STORAGE between bf16-operand weight GEMMs (include/gcnx.h: "bf16 STORAGE ...").  Arrays of dtype uint16 hold
+# bfloat16 bit patterns.  Each wrapper returns False -- nothing launched -- when the library answers GCNX_ERR_UNSUPPORTED.
+def _is16(a):
+    return a.dtype == np.uint16
+
+
+def spmm_bf16out(ctx, a, h, bias, out16, act=None):
+    """out16 = bf16(act(A h + bias)) (gcnx_spmm_csr_bf16out): the aggregation with its result stored as bfloat16."""
+    n, f = h.shape
+    assert a.n == n and out16.shape == (n, f) and _is16(out16)
+    rc = ctx.lib.gcnx_spmm_csr_bf16out(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(h), h.ld, _p(bias), out16.ptr, out16.ld,
+                                       n, f, L.ACTS[act], a.plan)
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
+def spmm_pool_bwd_bf16out(ctx, at, y, seg, dpooled, out16, mode="sum", y_bits=None):
+    """out16 = bf16(A^T (pool'(dpooled) * [y > 0])) from the bit image of y (gcnx_spmm_csr_pool_bwd_bf16out)."""
+    n, f = y.shape
+    assert at.n == n and out16.shape == (n, f) and _is16(out16) and dpooled.shape == (seg.n_graphs, f)
+    if y_bits is None or at.n_blocks != seg.n_graphs:
+        return False
+    rc = ctx.lib.gcnx_spmm_csr_pool_bwd_bf16out(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(at.vals), _p(y), y.ld, seg.dev.ptr,
+                                                seg.n_graphs, _p(dpooled), dpooled.ld, out16.ptr, out16.ld, n, f, L.POOLS[mode],
+                                                at.plan, _p(y_bits))
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
+def gemm_fwd_bf16(ctx, x16, w, bias, out, act=None, bits=None):
+    """out = act(x16 w + bias) with x16 stored as bfloat16; out is stored as bfloat16 when it is a uint16 array
+    (gcnx_gemm_fwd_bf16); bits (optional, act = "relu"): the bit image of [out > 0] for gemm_dx_bf16."""
+    n, fi = x16.shape
+    fo = w.shape[1]
+    assert _is16(x16) and w.shape[0] == fi and out.shape == (n, fo) and (bits is None or bits.nbytes >= n * 64)
+    rc = ctx.lib.gcnx_gemm_fwd_bf16(ctx.h, x16.ptr, x16.ld, _p(w), _p(bias), out.ptr, out.ld, int(_is16(out)), n, fi, fo, L.ACTS[act],
+                                    _p(bits))
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
+def gemm_dx_bf16(ctx, dh16, w, dx, mask_bits=None, db=None):
+    """dx = dh16 w^T (* the ReLU mask in mask_bits), db = column sums of dx; dh16 stored as bfloat16, dx as bfloat16 when it
+    is a uint16 array (gcnx_gemm_dx_bf16)."""
+    n, fo = dh16.shape
+    fi = w.shape[0]
+    assert _is16(dh16) and w.shape[1] == fo and dx.shape == (n, fi)
+    rc = ctx.lib.gcnx_gemm_dx_bf16(ctx.h, dh16.ptr, dh16.ld, _p(w), dx.ptr, dx.ld, int(_is16(dx)), n, fi, fo, _p(mask_bits), _p(db))
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
+def gemm_dw_bf16(ctx, x16, dh16, dw):
+    """dw = x16^T dh16, both stored as bfloat16 (gcnx_gemm_dw_bf16)."""
+    n, fi = x16.shape
+    fo = dh16.shape[1]
+    assert _is16(x16) and _is16(dh16) and dh16.shape[0] == n and dw.shape == (fi, fo)
+    rc = ctx.lib.gcnx_gemm_dw_bf16(ctx.h, x16.ptr, x16.ld, dh16.ptr, dh16.ld, _p(dw), n, fi, fo)
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
+
+
 def spmm(ctx, a, h, bias, out, act=None):
     n, f = h.shape
     assert a.n == n and out.shape == (n, f)
@@ -532,6 +604,13 @@ def to_bf16(ctx, x):
     y = ctx.empty(x.shape, np.uint16)
     ctx._ck(ctx.lib.gcnx_f32_to_bf16(ctx.h, x.ptr, y.ptr, x.size))
     return y
+
+
+def to_bf16_into(ctx, x, y16):
+    """y16 <- bf16(x), round to nearest even (gcnx_f32_to_bf16), into an existing uint16 array of the same shape."""
+    assert x.contiguous and y16.contiguous and x.dtype == np.float32 and y16.dtype == np.uint16 and x.shape == y16.shape
+    ctx._ck(ctx.lib.gcnx_f32_to_bf16(ctx.h, x.ptr, y16.ptr, x.size))
+    return y16
 
 
 def from_bf16(ctx, x):

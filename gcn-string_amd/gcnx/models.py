@@ -162,7 +162,8 @@ class GCN2(_GraphRunner):
                       "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1")),
                       "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0",
                       "s_order": os.environ.get("GCNX_S_ORDER", "1") != "0",
-                      "buckets": os.environ.get("GCNX_COMM_BUCKETS", "1") != "0"}
+                      "buckets": os.environ.get("GCNX_COMM_BUCKETS", "1") != "0",
+                      "act16": os.environ.get("GCNX_ACT16", "1") != "0"}
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
@@ -255,7 +256,23 @@ class GCN2(_GraphRunner):
                            wt=bufs["w2t"] if keep else None, prec=prec,
                            pool=(batch.seg, bufs["tp_part"], bufs["tp_cnt"]) if late else None)
         else:
-            if self._s_order():
+            bufs["act16"] = False
+            if self._s_order() and self._act16_try(batch, with_loss):
+                # bf16 STORAGE of what only bf16-operand weight GEMMs read (r3): with prec = "bf16" every weight GEMM rounds its
+                # operands to bfloat16 as it loads them, so S1 = A X and Y1 (read by the two products of layer 2's kernel and
+                # by the two weight-gradient products) are stored rounded -- the same bits in every result, half the bytes in
+                # the aggregation's output, in both operands of dW1 / dW2 and in the input of three of the five GEMMs.
+                s16 = self._cap.view("s1_16", batch.n, self.f_in, np.uint16)
+                if D.spmm_bf16out(ctx, batch.a, batch.x, None, s16):          # (False: the tile kernels do not serve this batch)
+                    y16 = self._cap.view("y1_16", batch.n, self.hidden, np.uint16)
+                    bufs["y1bits"] = self._cap.view("y1bits", batch.n, 16, np.int32)
+                    if not (D.gemm_fwd_bf16(ctx, s16, p["w1"], p["b1"], y16, act="relu", bits=bufs["y1bits"])
+                            and D.gemm_fwd_bf16(ctx, y16, p["w2"], None, bufs["h"])):
+                        raise RuntimeError("gcnx: the streaming bf16 GEMM refused a shape the bf16-storage path was chosen for")
+                    bufs["act16"], bufs["y1bits_ok"], bufs["s1_16"], bufs["y1_16"] = True, True, s16, y16
+            if bufs["act16"]:
+                pass
+            elif self._s_order():
                 # layer 1 as (A X) W1: the same product as GCNConv's A (X W1), two launches either way -- but the layer's
                 # input needs no gradient, so with S1 = A X kept dW1 = S1^T dZ1 and the backward pass has no aggregation
                 # for this layer (one of the step's four, 575 us of 4.7 ms at config 3)
@@ -272,7 +289,8 @@ class GCN2(_GraphRunner):
             else:
                 D.gemm(ctx, batch.x, p["w1"], None, bufs["h"], prec=prec)
                 D.spmm(ctx, batch.a, bufs["h"], p["b1"], bufs["y1"], act="relu")
-            D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
+            if not bufs["act16"]:
+                D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
             # pooled layer on the tile kernels with a backward pass to follow: its launch also writes [Y2 > 0] as a bit
             # image, which the folded backward aggregation expands instead of reading Y2 again (1 GB -> 32 MB at config 3)
             bufs["y2bits_ok"] = False
@@ -336,7 +354,14 @@ class GCN2(_GraphRunner):
             D.gemm_dw2(ctx, bufs["s1"], bufs["dz2"], g["w1"], bufs["s2"], bufs["dz"], g["w2"], prec="f32", params=self.flat_p,
                        grads=self.flat_g.flat(0, self.n_params), lr=lr, pending=pend, leaf=ha)
             return True
-        if fold:
+        act16 = bool(bufs.get("act16"))
+        dh16 = self._cap.view("dh2_16", batch.n, self.hidden, np.uint16) if act16 else None
+        dh16_done = False
+        if fold and act16 and bufs.get("y2bits_ok"):
+            dh16_done = D.spmm_pool_bwd_bf16out(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], dh16, self.pool, y_bits=bufs["y2bits"])
+        if dh16_done:
+            pass                                                                # dH2 = A^T dZ2, stored as bf16
+        elif fold:
             D.spmm_pool_bwd(ctx, at, bufs["y2"], batch.seg, bufs["dpooled"], bufs["h"], self.pool,
                             y_bits=bufs["y2bits"] if bufs.get("y2bits_ok") else None)                # dH2 = A^T dZ2
         else:
@@ -368,11 +393,16 @@ class GCN2(_GraphRunner):
         # the fp32 MFMA) with dW2: on one stream the step measured 1-3 % faster at config 3 in every precision (4.12
         # against 4.21-4.25 ms in bf16), the same at config 5.
         import contextlib
+        if act16 and not dh16_done:
+            D.to_bf16_into(ctx, bufs["h"], dh16)                                # (dH2 came from an fp32 path: the same rounding)
         with (contextlib.nullcontext() if "s1" in bufs else ctx.side()):
             if not fold:
                 D.act_bias_grad(ctx, bufs["dz"], None, bufs["dz"], None, db=g["b2"])     # db2 = colsum(dZ2)
             # (folded: db2 came out of the head -- from the pool's own count of positive entries)
-            D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)          # dW2 = Y1^T dH2
+            if act16:
+                self._must(D.gemm_dw_bf16(ctx, bufs["y1_16"], dh16, g["w2"]))   # dW2 = Y1^T dH2
+            else:
+                D.gemm_dw(ctx, bufs["y1"], bufs["h"], g["w2"], prec=prec)      # dW2 = Y1^T dH2
         if buckets:
             # Multi-GPU ("enqueue behind the layer-1 dW GEMM"): the gradients of layers 2 and 3
             # and the metric tail -- {dW2, db2, dW3, db3, loss, #correct}, the contiguous tail of the flat buffer -- are
@@ -382,13 +412,30 @@ class GCN2(_GraphRunner):
             # communicator reduces through the host) issues the same two buckets in line.
             ctx.join()
             self._allreduce_tail_bucket()
-        D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"],
-                  mask_bits=bufs["y1bits"] if bufs.get("y1bits_ok") else None)                       # dZ1, db1
-        xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
-        D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                            # dW1 = X^T (A^T dZ1) or S1^T dZ1
+        if act16:
+            dz16 = self._cap.view("dz1_16", batch.n, self.hidden, np.uint16)
+            self._must(D.gemm_dx_bf16(ctx, dh16, p["w2"], dz16, mask_bits=bufs["y1bits"], db=g["b1"]))   # dZ1 (bf16), db1
+            self._must(D.gemm_dw_bf16(ctx, bufs["s1_16"], dz16, g["w1"]))      # dW1 = S1^T dZ1
+        else:
+            D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"],
+                      mask_bits=bufs["y1bits"] if bufs.get("y1bits_ok") else None)                   # dZ1, db1
+            xs, dh1 = self._layer1_dw_operands(batch, bufs, at)
+            D.gemm_dw(ctx, xs, dh1, g["w1"], prec=prec)                        # dW1 = X^T (A^T dZ1) or S1^T dZ1
         ctx.join()
         if buckets:
             self._allreduce_head_bucket()
+
+    @staticmethod
+    def _must(ok):
+        if not ok:
+            raise RuntimeError("gcnx: a bf16-storage kernel refused a shape its producer had accepted")
+
+    def _act16_try(self, batch, with_loss):
+        """bf16 storage of S1, Y1, dH2, dZ1 (the tensors only weight GEMMs read): a training step with plain bf16 GEMM operands
+        at the streaming kernels' shape, the aggregation on a tile plan.  The first producer (gcnx_spmm_csr_bf16out) has the
+        last word.  GCNX_ACT16=0 keeps fp32 storage (same results, bit for bit: tested)."""
+        return (with_loss == "grads" and self.prec == "bf16" and self._knob["act16"] and self.hidden == 256 and self.f_in == 256
+                and batch.n >= 32768 and batch.a.plan is not None and batch.a.vals is not None and self._knob["side"] == 1)
 
     def _allreduce_tail_bucket(self):
         """{dW2, db2, dW3, db3, loss, #correct}: on the side stream (a second branch of a captured step) when the transport

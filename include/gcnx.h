@@ -276,6 +276,32 @@ GCNX_API int gcnx_act_bias_grad(gcnx_ctx* ctx, const float* dy, int64_t lddy, co
 /* dW[Fi,Fo] = X^T[Fi,N] * dH[N,Fo]: deterministic two-stage split-K (no atomics). */
 GCNX_API int gcnx_gemm_dw(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh,
                  float* dw, int64_t n, int32_t fi, int32_t fo, int prec);
+/* ---- bf16 STORAGE of activations that only bf16-operand weight GEMMs read (r3; large batches, GCNX_PREC_BF16) ----------
+ * GCNX_PREC_BF16 rounds both operands of a product to bfloat16 (nearest even) as it loads them (tf.cast(x, tf.bfloat16)
+ * in front of every MatMul / MatMul grad of the Dense and GCNConv kernels, gcn.py:334, :337).  A tensor that only such
+ * products read -- S1 = A X, Y1, dH2 = A^T dZ2, dZ1 of the two-layer model -- can be STORED rounded: every result stays
+ * bit-identical and the producer and the consumers move half its bytes.  `x16` / `dh16` / `out16` are uint16 rows
+ * (bfloat16 bit patterns), leading dimensions in ELEMENTS.
+ *   gcnx_spmm_csr_bf16out           = gcnx_spmm_csr with the result stored as bf16 (tile kernels + 8-row chunks only).
+ *   gcnx_spmm_csr_pool_bwd_bf16out  = gcnx_spmm_csr_pool_bwd(plan, y_bits) with the result stored as bf16.
+ *   gcnx_gemm_fwd_bf16              = gcnx_gemm / gcnx_gemm_relu_bits on a bf16 input; out as bf16 (out_bf16) or fp32.
+ *   gcnx_gemm_dx_bf16               = gcnx_gemm_dx / gcnx_gemm_dx_bits on a bf16 dH (mask_bits and db may be NULL).
+ *   gcnx_gemm_dw_bf16               = gcnx_gemm_dw with both operands stored as bf16.
+ * All five return GCNX_ERR_UNSUPPORTED -- nothing launched, gcnx_last_error untouched -- for shapes outside the streaming /
+ * tile kernels (GEMMs: fi = fo = 256, n >= 32768; SpMM: weighted operator, a plan whose tile graphs all take the
+ * 1024-thread shape, f a multiple of 32 above 128, no hub rows): keep fp32 storage then. */
+GCNX_API int gcnx_spmm_csr_bf16out(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                          int64_t ldh, const float* bias, void* out16, int64_t ldo, int32_t n, int32_t f, int act,
+                          const gcnx_spmm_plan* plan);
+GCNX_API int gcnx_spmm_csr_pool_bwd_bf16out(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
+                          const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled, int64_t lddp,
+                          void* out16, int64_t ldo, int32_t n, int32_t f, int mode, const gcnx_spmm_plan* plan, const void* y_bits);
+GCNX_API int gcnx_gemm_fwd_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const float* w, const float* bias, void* out, int64_t ldo,
+                          int out_bf16, int64_t n, int32_t fi, int32_t fo, int act, void* relu_bits);
+GCNX_API int gcnx_gemm_dx_bf16(gcnx_ctx* ctx, const void* dh16, int64_t lddh, const float* w, void* dx, int64_t lddx, int dx_bf16,
+                          int64_t n, int32_t fi, int32_t fo, const void* mask_bits, float* db);
+GCNX_API int gcnx_gemm_dw_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const void* dh16, int64_t lddh, float* dw, int64_t n,
+                          int32_t fi, int32_t fo);
 /* The ReLU mask of a Dense / GCNConv kernel product as a bit image between the forward and the backward product of
  * large batches: gcnx_gemm_relu_bits = gcnx_gemm(act = GCNX_ACT_RELU) that also writes [out > 0] to `bits` (n * 64
  * bytes reserved, 8-byte aligned; layout private to the pair, which must use the same precision), gcnx_gemm_dx_bits = gcnx_gemm_dx masked by that image instead of

@@ -1474,3 +1474,98 @@ def test_spmm_hub_rows_as_segments_on_their_own_workgroups(ctx, weighted):
     sizes = np.diff(hb.graph_ptr)
     dz = np.repeat(dp.astype(np.float64) / sizes[:, None], sizes, axis=0) * (y > 0)
     assert rel_err(o2.numpy(), a64.T @ dz) < TIGHT
+
+
+def test_bf16_storage_between_bf16_operand_gemms_changes_no_bit(ctx):
+    """bf16 STORAGE (r3, include/gcnx.h): gcnx_gemm_fwd_bf16 / gcnx_gemm_dx_bf16 / gcnx_gemm_dw_bf16 read their streamed
+    operands as bfloat16 and (the first two) store the result rounded to bfloat16.  Against the fp32-storage entry points
+    with GCNX_PREC_BF16 on the SAME values: every product, bias gradient and bit image identical bit for bit, stored results
+    equal to the RNE rounding (oracle.bf16_bits) of the fp32 ones.  Ragged row count, zero rows past the end."""
+    from gcnx import device as D
+    o = O()
+    rng = np.random.default_rng(21)
+    n = 40_003
+    x32 = o.bf16_from_bits(o.bf16_bits(rng.standard_normal((n, 256), dtype=np.float32)))      # values bf16 holds exactly
+    w = (rng.standard_normal((256, 256)) / 16).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32)
+    dx, dw_, dbias = ctx.to_device(x32), ctx.to_device(w), ctx.to_device(b)
+    x16 = D.to_bf16(ctx, dx)
+    assert np.array_equal(x16.numpy(), o.bf16_bits(x32))
+    # forward with ReLU + bit image: fp32 storage (gcnx_gemm_relu_bits) against bf16 in / bf16 out
+    y32 = ctx.empty((n, 256)); bits32 = ctx.zeros(n * 16, np.int32)
+    assert D.gemm_relu_bits(ctx, dx, dw_, dbias, y32, bits32, prec="bf16")
+    y16 = ctx.empty((n, 256), np.uint16); bits16 = ctx.zeros(n * 16, np.int32)
+    assert D.gemm_fwd_bf16(ctx, x16, dw_, dbias, y16, act="relu", bits=bits16)
+    assert np.array_equal(y16.numpy(), o.bf16_bits(y32.numpy()))
+    assert np.array_equal(bits16.numpy(), bits32.numpy())
+    # ... against the oracle's bf16-operand product (fp64 accumulation of the rounded operands)
+    ref = np.maximum(x32.astype(np.float64) @ o.bf16_from_bits(o.bf16_bits(w)).astype(np.float64) + b, 0)
+    assert rel_err(o.bf16_from_bits(y16.numpy()), ref) < 2.0 ** -8
+    # forward without activation, fp32 result (layer 2's kernel product: the aggregation reads it in fp32)
+    h32 = ctx.empty((n, 256)); h32b = ctx.empty((n, 256))
+    D.gemm(ctx, dx, dw_, None, h32, prec="bf16")
+    assert D.gemm_fwd_bf16(ctx, x16, dw_, None, h32b)
+    assert np.array_equal(h32.numpy(), h32b.numpy())
+    # dX with the bit image and the bias gradient of the layer below
+    dz32 = ctx.empty((n, 256)); db32 = ctx.zeros(256)
+    D.gemm_dx(ctx, dx, dw_, dz32, prec="bf16", y_mask=y32, db=db32, mask_bits=bits32)
+    dz16 = ctx.empty((n, 256), np.uint16); db16 = ctx.zeros(256)
+    assert D.gemm_dx_bf16(ctx, x16, dw_, dz16, mask_bits=bits16, db=db16)
+    assert np.array_equal(dz16.numpy(), o.bf16_bits(dz32.numpy()))
+    assert np.array_equal(db16.numpy(), db32.numpy())
+    # dW from two bf16-stored operands
+    g32 = ctx.empty((256, 256)); g16 = ctx.empty((256, 256))
+    dzr = ctx.to_device(o.bf16_from_bits(dz16.numpy()))
+    D.gemm_dw(ctx, dx, dzr, g32, prec="bf16")
+    assert D.gemm_dw_bf16(ctx, x16, dz16, g16)
+    assert np.array_equal(g16.numpy(), g32.numpy())
+    # shapes outside the streaming kernels: an answer, nothing launched
+    small = ctx.zeros((1000, 256), np.uint16)
+    assert not D.gemm_fwd_bf16(ctx, small, dw_, None, ctx.empty((1000, 256)))
+    assert not D.gemm_dw_bf16(ctx, small, small, g16)
+
+
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+def test_spmm_bf16_result_rows_on_the_tile_kernels(ctx, mode):
+    """gcnx_spmm_csr_bf16out / gcnx_spmm_csr_pool_bwd_bf16out: the tile kernel (double-buffered and single tiles) and the
+    8-row chunks of taller graphs store the rounded row -- equal to oracle.bf16_bits of the fp32 entry point's result, which
+    the tile tests hold to the oracle -- and the forms refuse what they do not serve."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    o = O()
+    hb = synth.block_diag_batch(150_000, 1_500_000, 256, seed=6, with_x=False)
+    sizes = np.diff(hb.graph_ptr)
+    assert len(sizes) >= 128 and (sizes <= 624).any() and ((sizes > 624) & (sizes <= 1276)).any() and (sizes > 1276).any()
+    n, f, b = hb.n, 256, len(sizes)
+    rng = np.random.default_rng(9)
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    assert a.plan is not None
+    x = ctx.to_device(rng.standard_normal((n, f), dtype=np.float32)); bias = ctx.to_device(rng.standard_normal(f).astype(np.float32))
+    out32 = ctx.empty((n, f)); out16 = ctx.zeros((n, f), np.uint16)
+    for act, bb in ((None, None), ("relu", bias)):
+        D.spmm(ctx, a, x, bb, out32, act=act)
+        assert D.spmm_bf16out(ctx, a, x, bb, out16, act=act)
+        assert np.array_equal(out16.numpy(), o.bf16_bits(out32.numpy())), act
+    # ... independently: within one bf16 rounding of the fp64 aggregation
+    ref = _ref_spmm(hb, vals, x.numpy(), None, False)
+    D.spmm_bf16out(ctx, a, x, None, out16)
+    assert rel_err(o.bf16_from_bits(out16.numpy()), ref) < 2.0 ** -8
+    # the folded backward aggregation from the bit image
+    seg = Segments(ctx, hb.graph_ptr)
+    y2 = ctx.empty((n, f)); bits = ctx.zeros((f // 32) * n, np.int32)
+    assert D.spmm_relu_bits(ctx, a, x, bias, y2, bits)
+    dp = ctx.to_device(rng.standard_normal((b, f), dtype=np.float32))
+    at = a.transpose()
+    D.spmm_pool_bwd(ctx, at, y2, seg, dp, out32, mode, y_bits=bits)
+    assert D.spmm_pool_bwd_bf16out(ctx, at, y2, seg, dp, out16, mode, y_bits=bits)
+    assert np.array_equal(out16.numpy(), o.bf16_bits(out32.numpy()))
+    # refusals: no bit image; an unweighted operator; the row gather forced
+    assert not D.spmm_pool_bwd_bf16out(ctx, at, y2, seg, dp, out16, mode, y_bits=None)
+    au = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
+    assert not D.spmm_bf16out(ctx, au, x, None, out16)
+    try:
+        ctx.set_tuning("spmm_kernel", "rows")
+        assert not D.spmm_bf16out(ctx, a, x, None, out16)
+    finally:
+        ctx.set_tuning("spmm_kernel", "auto")

@@ -750,6 +750,41 @@ def _full_size_batch(workload):
     return hb
 
 
+def test_gcn2_bf16_storage_of_gemm_only_activations_changes_no_bit(ctx):
+    """prec = "bf16" on a tile-plan batch (r3): S1 = A X, Y1, dH2 and dZ1 -- read by weight GEMMs only, which round their
+    operands to bfloat16 anyway -- are stored as bfloat16 (gcnx_spmm_csr_bf16out, gcnx_gemm_fwd_bf16, ...).  Against the same
+    model with fp32 storage (the knob GCNX_ACT16=0 sets): loss, accuracy, every gradient and the updated weights bit for
+    bit, eagerly, captured and replayed; tall graphs (row chunks) and double-buffered tiles in the batch."""
+    from gcnx import synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch
+    hb = synth.block_diag_batch(100_000, 1_000_000, 256, seed=12)
+    sizes = np.diff(hb.graph_ptr)
+    assert len(sizes) >= 128 and (sizes > 1276).any() and (sizes <= 624).any()
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    assert a.plan is not None
+    y = np.zeros((len(sizes), 2), np.float32); y[np.arange(len(sizes)), np.arange(len(sizes)) % 2] = 1
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(y))
+    res = {}
+    for store16 in (True, False):
+        m = GCN2(ctx, 2, hidden=256, seed=3, prec="bf16")
+        m._knob["act16"] = store16
+        out = []
+        for step in range(3):                              # eager, captured, replayed
+            loss, acc = m.train_step(batch, None, lr=0.01)
+            out.append((loss, acc, {k: v.copy() for k, v in m.gradients().items()}, [w.copy() for w in m.get_weights()]))
+        assert bool(m._bufs.get("act16")) == store16
+        res[store16] = out
+    for (l1, a1, g1, w1), (l0, a0, g0, w0) in zip(res[True], res[False]):
+        assert l1 == l0 and a1 == a0
+        for k in g1:
+            assert np.array_equal(g1[k], g0[k]), k
+        for u, v in zip(w1, w0):
+            assert np.array_equal(u, v)
+    assert np.isfinite(res[True][-1][0]) and any(np.abs(v).max() > 0 for v in res[True][0][2].values())
+
+
 @pytest.mark.parametrize("workload", ["block1m", "powerlaw"])
 def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     """BASELINE config 3 (1M nodes / 10M entries / F=256, 1 667 graphs) and config 5 (122 power-law graphs of 8 192
@@ -874,7 +909,12 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
         m.prec = prec; m._drop_graphs(); m.set_weights(w0)
         loss, _ = m.train_step(batch, None, lr=0.0)
         got = m.gradients()
-        m1, m2 = m._bufs["y1"].numpy() > 0, m._bufs["y2"].numpy() > 0
+        if m._bufs.get("act16"):        # (r3: with plain bf16 operands Y1 is stored as bfloat16 -- the fp32 buffer is not written)
+            from gcnx import device as _D
+            m1 = _D.from_bf16(ctx, m._bufs["y1_16"]).numpy() > 0
+        else:
+            m1 = m._bufs["y1"].numpy() > 0
+        m2 = m._bufs["y2"].numpy() > 0
         if prec != "bf16":
             assert abs(loss - loss64) < TOL * abs(loss64), (prec, loss, loss64)
             f1, f2 = m1 != own1, m2 != own2
