@@ -534,7 +534,9 @@ def main():
                        "global_graphs": global_graphs, "nodes_per_gpu": hb.n, "nnz_per_gpu": hb.nnz, "features": hb.f,
                        "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32"
                                                         f"{' inside the step graph' if world > 1 and model._comm_in_graph() else ''})",
-                       "hip_graph": not args.no_graph, "gemm_precision": args.prec, "cce": model.cce_train},
+                       "hip_graph": not args.no_graph, "gemm_precision": args.prec, "cce": model.cce_train,
+                       "activation_storage": ("bf16 for the tensors only bf16-operand weight GEMMs read (S1, Y1, dH2, dZ1: results "
+                                              "bit-identical to fp32 storage), fp32 elsewhere" if (model._bufs or {}).get("act16") else "fp32")},
             "burn_in": {"steps": burn_steps, "ms": args.burn_in_ms,
                         "what": "untimed repetitions of the same step after the W warm-up steps and before the timed region (clock / "
                                 "cache steady state; the timed region is exactly `steps` full steps)"},
