@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03i; mkdir -p $O
+O=gpurun_out/r03j; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard8 -- python3 bench.py --workload block1m --steps 30 --warmup 3 --cpu-seconds 0 --no-config3 --spmm-iters 2 --emulate-rank 0 --of 8 > $O/shard8.json 2> $O/shard8.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -- python3 bench.py --workload block1m --steps 30 --warmup 3 --cpu-seconds 0 --no-config3 --spmm-iters 2 > $O/full.json 2> $O/full.err
 python3 - <<PY
