@@ -244,6 +244,13 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
     }                                                                                                              \
   }
 
+  // Column sums of what is written (ep.colpart).  One-plane kernels with bit-image masks have the registers to keep them
+  // per LANE over the workgroup's whole walk (CT float4s) and to combine lanes, waves and workgroups once at the end; the
+  // others (fp32 mask pieces in the ring, two planes: at the register limit) combine the 16 lanes of a tile per unit.
+  constexpr bool CSREG = NP == 1 && MASK != 1;
+  float4 cs[CSREG ? CT : 1];
+#pragma unroll
+  for (int j = 0; j < (CSREG ? CT : 1); ++j) cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   sf32x4 acc[RT][CT];
 #pragma unroll
   for (int t = 0; t < RT; ++t)
@@ -368,15 +375,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
           // lanes rl = 0 .. 15 (fixed tree), lane rl = 0 adds the result to its wave's LDS row -- the same lane in
           // the same order every time (units, tiles ascending): deterministic.  LDS only: nothing here waits on vmcnt.
           float4 sv = row < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (CSREG) {
+            cs[ct].x += sv.x; cs[ct].y += sv.y; cs[ct].z += sv.z; cs[ct].w += sv.w;     // (units, tiles ascending: a fixed order)
+          } else {
 #pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1) {
-            sv.x += __shfl_xor(sv.x, sh); sv.y += __shfl_xor(sv.y, sh); sv.z += __shfl_xor(sv.z, sh); sv.w += __shfl_xor(sv.w, sh);
-          }
-          if (rl == 0) {
-            float4* ws4 = reinterpret_cast<float4*>(wsum + wave * CW + ct * 16 + q * 4);
-            float4 o = *ws4;
-            o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
-            *ws4 = o;
+            for (int sh = 1; sh < 16; sh <<= 1) {
+              sv.x += __shfl_xor(sv.x, sh); sv.y += __shfl_xor(sv.y, sh); sv.z += __shfl_xor(sv.z, sh); sv.w += __shfl_xor(sv.w, sh);
+            }
+            if (rl == 0) {
+              float4* ws4 = reinterpret_cast<float4*>(wsum + wave * CW + ct * 16 + q * 4);
+              float4 o = *ws4;
+              o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
+              *ws4 = o;
+            }
           }
         }
       }
@@ -391,6 +402,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const float* __rest
     if (MASK == 2) mbits = mnext64;
     else mbits = mnext;                                  // the first two mask pieces of the next unit are already in
     mnext = 0;
+  }
+  if constexpr (CSREG) {
+    if (ep.colpart) {                                    // the 16 lanes that share a column group (fixed tree), once per launch
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        float4 sv = cs[ct];
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) {
+          sv.x += __shfl_xor(sv.x, sh); sv.y += __shfl_xor(sv.y, sh); sv.z += __shfl_xor(sv.z, sh); sv.w += __shfl_xor(sv.w, sh);
+        }
+        if (rl == 0) *reinterpret_cast<float4*>(wsum + wave * CW + ct * 16 + q * 4) = sv;
+      }
+    }
   }
   if (ep.colpart) {                                      // the workgroup's column sums: its 8 waves in a fixed order
     __syncthreads();
@@ -619,15 +643,16 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
   // columns 8 (tid & 31) .. + 7
   const int srow = IN16 ? tid >> 5 : tid >> 6, scol4 = IN16 ? (tid & 31) * 8 : (tid & 63) * 4;
   float4 sx[4], sd[4];
-  si32x4 qx[2], qd[2];
-#define DW_ISSUE(STEP)                                                                                            \
+  si32x4 qx[2][2], qd[2][2];             // IN16: two register sets -- the loads run TWO steps ahead (64 KiB in flight per CU, as in
+                                         // the fp32 form; with one step, 32 KiB, the kernel was latency-bound at 4.1 TB/s)
+#define DW_ISSUE(STEP, SET)                                                                                       \
   if constexpr (IN16) {                                                                                            \
     const int64_t rb_ = r_begin + (int64_t)(STEP) * 32 + srow;                                                     \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
       const int64_t r_ = rb_ + 16 * j;                                                                             \
       const bool ok_ = (STEP) < nsteps && r_ < r_end;                                                              \
-      qx[j] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)r_ * ldx4 + (unsigned)scol4 * 2u : 0xFFFFFFE0u, 0, GCNX_STREAM_LOAD_AUX)); \
-      qd[j] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, ok_ ? (unsigned)r_ * ldd4 + (unsigned)scol4 * 2u : 0xFFFFFFE0u, 0, GCNX_STREAM_LOAD_AUX)); \
+      qx[SET][j] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)r_ * ldx4 + (unsigned)scol4 * 2u : 0xFFFFFFE0u, 0, GCNX_STREAM_LOAD_AUX)); \
+      qd[SET][j] = __builtin_bit_cast(si32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, ok_ ? (unsigned)r_ * ldd4 + (unsigned)scol4 * 2u : 0xFFFFFFE0u, 0, GCNX_STREAM_LOAD_AUX)); \
     }                                                                                                              \
   } else {                                                                                                         \
     const int64_t rb_ = r_begin + (int64_t)(STEP) * 32 + srow;                                                     \
@@ -638,12 +663,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
       sd[j] = sbuf4(drs, ok_ ? (unsigned)r_ * ldd4 + (unsigned)scol4 * 4u : 0xFFFFFFE0u);                          \
     }                                                                                                              \
   }
-#define DW_WRITE(STAGE)                                                                                            \
+#define DW_WRITE(STAGE, SET)                                                                                       \
   if constexpr (IN16) {                                                                                            \
     char* sb_ = dlds + (STAGE) * DwLds<NP>::stage + srow * kDwRowB + scol4 * 2;                                    \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
-      *reinterpret_cast<si32x4*>(sb_ + j * 16 * kDwRowB) = qx[j];                                                  \
-      *reinterpret_cast<si32x4*>(sb_ + NP * kDwPlane + j * 16 * kDwRowB) = qd[j];                                  \
+      *reinterpret_cast<si32x4*>(sb_ + j * 16 * kDwRowB) = qx[SET][j];                                             \
+      *reinterpret_cast<si32x4*>(sb_ + NP * kDwPlane + j * 16 * kDwRowB) = qd[SET][j];                             \
     }                                                                                                              \
   } else {                                                                                                         \
     char* sb_ = dlds + (STAGE) * DwLds<NP>::stage + srow * kDwRowB + scol4 * 2;                                    \
@@ -665,12 +690,20 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = sf32x4{0.f, 0.f, 0.f, 0.f};
 
-  DW_ISSUE(0)
-  DW_WRITE(0)
+  DW_ISSUE(0, 0)
+  DW_WRITE(0, 0)
+  if constexpr (IN16) { DW_ISSUE(1, 1) }
   __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    const int st = s & 1;
-    DW_ISSUE(s + 1)                                       // in flight under this step's MFMAs
+  // One K step (32 rows) on LDS stage ST: the loads that replace a free register set go out first, the other stage is
+  // written behind the MFMAs.  fp32 operands: one set, one step ahead.  bf16 operands: set (step & 1), two steps ahead.
+#define DW_STEP(S, ST)                                                                                            \
+  {                                                                                                                \
+    if constexpr (IN16) { DW_ISSUE((S) + 2, (ST)) } else { DW_ISSUE((S) + 1, 0) }                                  \
+    dw_mfma_step((ST));                                                                                            \
+    if ((S) + 1 < nsteps) { if constexpr (IN16) { DW_WRITE((ST) ^ 1, (ST) ^ 1) } else { DW_WRITE((ST) ^ 1, 0) } }  \
+    __syncthreads();                                                                                               \
+  }
+  auto dw_mfma_step = [&](int st) {
     const char* xb = dlds + st * DwLds<NP>::stage + lane_off;           // X planes (hi, lo)
     const char* db = xb + NP * kDwPlane;                                // dH planes
     sbf16x8 ah[4], al[4];
@@ -693,9 +726,16 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 #pragma unroll
       for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
     }
-    if (s + 1 < nsteps) { DW_WRITE(st ^ 1) }              // (the other stage was last read before the previous barrier)
-    __syncthreads();
+  };
+  if constexpr (IN16) {
+    for (int s = 0; s < nsteps; s += 2) {                 // (the other stage was last read before the previous barrier)
+      DW_STEP(s, 0)
+      if (s + 1 < nsteps) DW_STEP(s + 1, 1)
+    }
+  } else {
+    for (int s = 0; s < nsteps; ++s) DW_STEP(s, s & 1)    // (fp32 operands: the loop as it was -- one register set, a run-time stage)
   }
+#undef DW_STEP
 #undef DW_ISSUE
 #undef DW_WRITE
   // C[row = o within tile (lane >> 4) * 4 + reg][col = i within tile (lane & 15)]: a lane holds dW[i][o .. o + 3]

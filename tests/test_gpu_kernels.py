@@ -696,7 +696,12 @@ def test_gemm_relu_bit_image_between_forward_and_dx(ctx, n, prec):
     dx_ref, dx_bits, db_ref, db_bits = ctx.empty((n, 256)), ctx.empty((n, 256)), ctx.empty(256), ctx.empty(256)
     D.gemm_dx(ctx, dh, w2, dx_ref, prec=prec, y_mask=y_ref, db=db_ref)
     D.gemm_dx(ctx, dh, w2, dx_bits, prec=prec, db=db_bits, mask_bits=bits)
-    assert np.array_equal(dx_ref.numpy(), dx_bits.numpy()) and np.array_equal(db_ref.numpy(), db_bits.numpy())
+    assert np.array_equal(dx_ref.numpy(), dx_bits.numpy())
+    # db: the same numbers; the one-plane bit-image form adds them per lane over the whole walk (registers) and combines lanes
+    # once, the other forms combine the 16 lanes of a tile per row block -- a different association, not a different sum
+    if prec == "bf16x3":
+        assert np.array_equal(db_ref.numpy(), db_bits.numpy())
+    assert rel_err(db_bits.numpy(), dx_ref.numpy().astype(np.float64).sum(0)) < 2e-6 and rel_err(db_ref.numpy(), db_bits.numpy()) < 2e-6
     assert np.array_equal(dx_bits.numpy() != 0, (y_ref.numpy() > 0) & (dx_bits.numpy() != 0))      # zero wherever the mask is
     # not served: fp32 products, short inputs -- refused without a launch
     assert not D.gemm_relu_bits(ctx, x, w1, b1, y_bits, bits, prec="f32")
