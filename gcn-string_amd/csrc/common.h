@@ -87,7 +87,8 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
 // `slabs` (room for max_slices of them) and returns the number of slices; 0 = shape not handled, < 0 = launch error.
 int gcnx_gemm_stream_bf16(gcnx_ctx* ctx, const void* a16, int64_t lda, const float* w, int fi, int fo, int transpose, void* c,
                           int64_t ldc, int c_bf16, int64_t m, const float* bias, int act, float* colsum_out, const void* mask_bits,
-                          void* bits_out);
+                          void* bits_out, const void* wimg);
+int gcnx_gemm_stream_images_impl(gcnx_ctx* ctx, int njobs, const float* const* w, const int* transpose, void* const* img);
 int gcnx_gemm_dw_stream16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const void* dh16, int64_t lddh, float* slabs, int64_t n,
                           int32_t fi, int32_t fo, int max_slices);
 int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh, int64_t lddh, float* slabs, int64_t n,

@@ -1016,8 +1016,23 @@ int gcnx_gemm_dx_bits(gcnx_ctx* ctx, const float* dh, int64_t lddh, const float*
 // the three products with the streamed operand(s) read as bf16 (uint16 rows, leading dimensions in elements) and, for the
 // first two, the result written as bf16 (out_bf16) or fp32.  Streaming kernels only: GCNX_ERR_UNSUPPORTED, without a
 // message and with nothing launched, for any other shape (fi = fo = 256, n >= 32768, 16-byte aligned rows).
+int gcnx_gemm_stream_images(gcnx_ctx* ctx, int32_t njobs, const gcnx_stream_image_job* jobs) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, njobs >= 0 && njobs <= 4 && (njobs == 0 || jobs), "gcnx_gemm_stream_images: 0 .. 4 jobs");
+  if (njobs == 0) return GCNX_OK;
+  const float* w[4]; int tr[4]; void* img[4];
+  for (int j = 0; j < njobs; ++j) {
+    GCNX_REQUIRE(ctx, jobs[j].w && jobs[j].img && (reinterpret_cast<uintptr_t>(jobs[j].img) & 15) == 0,
+                 "gcnx_gemm_stream_images: job %d: NULL weight / image, or an image that is not 16-byte aligned", j);
+    GCNX_REQUIRE(ctx, jobs[j].fi == 256 && jobs[j].fo == 256, "gcnx_gemm_stream_images: job %d: the streaming bf16 kernels take 256 x 256 "
+                 "operands (got %d x %d)", j, jobs[j].fi, jobs[j].fo);
+    w[j] = jobs[j].w; tr[j] = jobs[j].transpose ? 1 : 0; img[j] = jobs[j].img;
+  }
+  return gcnx_gemm_stream_images_impl(ctx, njobs, w, tr, img);
+}
+
 int gcnx_gemm_fwd_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const float* w, const float* bias, void* out, int64_t ldo,
-                       int out_bf16, int64_t n, int32_t fi, int32_t fo, int act, void* relu_bits) {
+                       int out_bf16, int64_t n, int32_t fi, int32_t fo, int act, void* relu_bits, const void* wimg) {
   GCNX_CHECK_CTX(ctx);
   GCNX_RANGE(ctx, "weight GEMM (X W)");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_fwd_bf16: negative size");
@@ -1026,18 +1041,18 @@ int gcnx_gemm_fwd_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const float*
   GCNX_REQUIRE(ctx, act == GCNX_ACT_NONE || act == GCNX_ACT_RELU, "gcnx_gemm_fwd_bf16: activation %d not supported here", act);
   GCNX_REQUIRE(ctx, !relu_bits || act == GCNX_ACT_RELU, "gcnx_gemm_fwd_bf16: the bit image is that of a ReLU output");
   if (fi != 256 || fo != 256 || (bias && !al16(bias))) return GCNX_ERR_UNSUPPORTED;
-  return gcnx_gemm_stream_bf16(ctx, x16, ldx, w, fi, fo, 1, out, ldo, out_bf16, n, bias, act, nullptr, nullptr, relu_bits);
+  return gcnx_gemm_stream_bf16(ctx, x16, ldx, w, fi, fo, 1, out, ldo, out_bf16, n, bias, act, nullptr, nullptr, relu_bits, wimg);
 }
 
 int gcnx_gemm_dx_bf16(gcnx_ctx* ctx, const void* dh16, int64_t lddh, const float* w, void* dx, int64_t lddx, int dx_bf16, int64_t n,
-                      int32_t fi, int32_t fo, const void* mask_bits, float* db) {
+                      int32_t fi, int32_t fo, const void* mask_bits, float* db, const void* wimg) {
   GCNX_CHECK_CTX(ctx);
   GCNX_RANGE(ctx, "weight GEMM (dX)");
   GCNX_REQUIRE(ctx, n >= 0 && fi >= 0 && fo >= 0, "gcnx_gemm_dx_bf16: negative size");
   GCNX_REQUIRE(ctx, dh16 && w && dx, "gcnx_gemm_dx_bf16: NULL pointer");
   GCNX_REQUIRE(ctx, lddh >= fo && lddx >= fi, "gcnx_gemm_dx_bf16: leading dimension too small");
   if (fi != 256 || fo != 256) return GCNX_ERR_UNSUPPORTED;
-  return gcnx_gemm_stream_bf16(ctx, dh16, lddh, w, fi, fo, 0, dx, lddx, dx_bf16, n, nullptr, GCNX_ACT_NONE, db, mask_bits, nullptr);
+  return gcnx_gemm_stream_bf16(ctx, dh16, lddh, w, fi, fo, 0, dx, lddx, dx_bf16, n, nullptr, GCNX_ACT_NONE, db, mask_bits, nullptr, wimg);
 }
 
 int gcnx_gemm_dw_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const void* dh16, int64_t lddh, float* dw, int64_t n,

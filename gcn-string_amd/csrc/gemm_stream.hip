@@ -83,6 +83,23 @@ __global__ __launch_bounds__(256) void stream_wprep_kernel(const float* __restri
   img[idx] = p == 0 ? hi : (__bf16)(v - (float)hi);
 }
 
+// The one-plane 256 x 256 images of several weight operands in ONE launch (gcnx_gemm_stream_images): blockIdx.y = job.
+struct StreamImageJobs { const float* w[4]; __bf16* img[4]; int transpose[4]; };
+__global__ __launch_bounds__(256) void stream_wprep_multi_kernel(StreamImageJobs jobs) {
+  const int j = blockIdx.y;
+  const float* __restrict__ w = jobs.w[j];
+  __bf16* __restrict__ img = jobs.img[j];
+  const int transpose = jobs.transpose[j];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // < 8 * 256 * 32: the layout of stream_wprep_kernel, np = 1
+  int64_t r = idx;
+  const int ks = (int)(r / (256 * 32)); r %= 256 * 32;
+  const int ct = (int)(r / 512); r %= 512;
+  const int q = (int)(r / 128); r %= 128;
+  const int c = (int)(r / 8), jj = (int)(r % 8);
+  const int col = ct * 16 + c, k = ks * 32 + q * 8 + jj;
+  img[idx] = (__bf16)(transpose ? w[(int64_t)k * 256 + col] : w[(int64_t)col * 256 + k]);
+}
+
 __device__ __forceinline__ float4 sbuf4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
   const sf32x4 r = __builtin_bit_cast(sf32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, GCNX_STREAM_LOAD_AUX));
   return make_float4(r.x, r.y, r.z, r.w);
@@ -497,7 +514,10 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
   // START of the workspace (where gcnx_colsum_partials looks for them), the weight image behind them
   int grid_wgs = ctx->num_cus;
   if (halves == 2) grid_wgs &= ~1;
-  const int64_t prow = colsum_out ? grid_wgs / halves : 0;
+  // (one partial row per workgroup PAIR that runs: the launch caps the grid at the row blocks there are, and every
+  // workgroup of it writes its row -- no rows to clear)
+  const int64_t n_rb_ = gcnx_cdiv(m, (np == 2 ? 32 : 16) * kSWaves);
+  const int64_t prow = colsum_out ? std::min<int64_t>(grid_wgs / halves, n_rb_) : 0;
   if (colsum_out && (ncol % 4 != 0 || !sal16(colsum_out))) return GCNX_ERR_UNSUPPORTED;
   const size_t part_bytes = colsum_out ? ((gcnx_colsum_partials_ws(prow, ncol) + 255) & ~(size_t)255) : 0;
   int rc = gcnx_ws_reserve(ctx, part_bytes + img_elems * sizeof(__bf16) + 256);
@@ -508,8 +528,6 @@ int gcnx_gemm_stream_nn(gcnx_ctx* ctx, const float* a, int64_t lda, const float*
   GCNX_LAUNCH_OK(ctx);
   const StreamEpi ep{bias, alpha, mask_bits ? nullptr : mask, ldmask, act, accumulate, colsum_out ? (float*)ctx->ws : nullptr,
                      (const unsigned long long*)mask_bits, (unsigned long long*)bits_out};
-  if (colsum_out)   // workgroups without row blocks (short inputs) do not run: their partial rows must read as zero
-    GCNX_HIP(ctx, hipMemsetAsync(ctx->ws, 0, (size_t)prow * ncol * sizeof(float), ctx->stream));
   rc = np == 2 ? launch_stream<2, 128, 2, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves)
                : launch_stream<1, 256, 1, 8>(ctx, a, lda, img, c, ldc, m, ncol, ep, halves);
   if (rc || !colsum_out) return rc;
@@ -549,7 +567,7 @@ int launch_stream16(gcnx_ctx* ctx, const void* a, int64_t lda, const __bf16* img
 // this returns GCNX_ERR_UNSUPPORTED without a message for shapes outside the kernel.
 int gcnx_gemm_stream_bf16(gcnx_ctx* ctx, const void* a16, int64_t lda, const float* w, int fi, int fo, int transpose, void* c,
                           int64_t ldc, int c_bf16, int64_t m, const float* bias, int act, float* colsum_out, const void* mask_bits,
-                          void* bits_out) {
+                          void* bits_out, const void* wimg) {
   const int ncol = transpose ? fo : fi, K = transpose ? fi : fo;
   if (ctx->knob_gemm_stream == 0 || K != 256 || ncol != 256 || m < 32 * 1024) return GCNX_ERR_UNSUPPORTED;
   if (lda % 8 || ldc % 4 || !sal16(a16) || !sal16(c) || (uint64_t)m * (uint64_t)lda * 2u >= 0xFFFFFF00ull ||
@@ -558,17 +576,20 @@ int gcnx_gemm_stream_bf16(gcnx_ctx* ctx, const void* a16, int64_t lda, const flo
     return GCNX_ERR_UNSUPPORTED;
   if (colsum_out && !sal16(colsum_out)) return GCNX_ERR_UNSUPPORTED;
   const size_t img_elems = (size_t)8 * 256 * 32;
-  const int64_t prow = colsum_out ? ctx->num_cus : 0;
+  const int64_t prow = colsum_out ? std::min<int64_t>(ctx->num_cus, gcnx_cdiv(m, 16 * kSWaves)) : 0;   // (= the grid: every workgroup writes its row)
   const size_t part_bytes = colsum_out ? ((gcnx_colsum_partials_ws(prow, ncol) + 255) & ~(size_t)255) : 0;
   int rc = gcnx_ws_reserve(ctx, part_bytes + img_elems * sizeof(__bf16) + 256);
   if (rc) return rc;
-  __bf16* img = (__bf16*)((char*)ctx->ws + part_bytes);
-  hipLaunchKernelGGL(stream_wprep_kernel, dim3(gcnx_cdiv((long long)img_elems, 256)), dim3(256), 0, ctx->stream, w, fi, fo, transpose,
-                     1, 256, 8, ncol, img);
-  GCNX_LAUNCH_OK(ctx);
+  const __bf16* img = (const __bf16*)wimg;            // the caller's image of this operand (gcnx_gemm_stream_images) ...
+  if (!img) {                                         // ... or one built here
+    __bf16* own = (__bf16*)((char*)ctx->ws + part_bytes);
+    hipLaunchKernelGGL(stream_wprep_kernel, dim3(gcnx_cdiv((long long)img_elems, 256)), dim3(256), 0, ctx->stream, w, fi, fo, transpose,
+                       1, 256, 8, ncol, own);
+    GCNX_LAUNCH_OK(ctx);
+    img = own;
+  }
   const StreamEpi ep{bias, nullptr, nullptr, 0, act, 0, colsum_out ? (float*)ctx->ws : nullptr,
                      (const unsigned long long*)mask_bits, (unsigned long long*)bits_out};
-  if (colsum_out) GCNX_HIP(ctx, hipMemsetAsync(ctx->ws, 0, (size_t)prow * ncol * sizeof(float), ctx->stream));
   rc = c_bf16 ? launch_stream16<true>(ctx, a16, lda, img, c, ldc, m, ncol, ep) : launch_stream16<false>(ctx, a16, lda, img, c, ldc, m, ncol, ep);
   if (rc || !colsum_out) return rc;
   return gcnx_colsum_partials(ctx, prow, ncol, colsum_out);
@@ -848,4 +869,14 @@ int gcnx_gemm_dw_stream(gcnx_ctx* ctx, const float* x, int64_t ldx, const float*
     hipLaunchKernelGGL((gemm_dw_stream_kernel<1>), dim3(slices), dim3(512), DwLds<1>::total, ctx->stream, x, ldx, dh, lddh, slabs, n, rows_per);
   }
   return hipGetLastError() == hipSuccess ? slices : -1;
+}
+
+// The images of up to four 256 x 256 weight operands for gcnx_gemm_fwd_bf16 (transpose = 1: X W) / gcnx_gemm_dx_bf16
+// (transpose = 0: dH W^T), 128 KiB each, in one launch.
+int gcnx_gemm_stream_images_impl(gcnx_ctx* ctx, int njobs, const float* const* w, const int* transpose, void* const* img) {
+  StreamImageJobs jobs{};
+  for (int j = 0; j < njobs; ++j) { jobs.w[j] = w[j]; jobs.img[j] = (__bf16*)img[j]; jobs.transpose[j] = transpose[j]; }
+  hipLaunchKernelGGL(stream_wprep_multi_kernel, dim3(8 * 256 * 32 / 256, njobs), dim3(256), 0, ctx->stream, jobs);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
 }

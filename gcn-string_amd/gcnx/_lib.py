@@ -87,8 +87,9 @@ SIGNATURES = {
     "gcnx_gemm_dx_bits": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _int, _vp, _vp],
     "gcnx_spmm_csr_bf16out": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _int, _vp],
     "gcnx_spmm_csr_pool_bwd_bf16out": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],
-    "gcnx_gemm_fwd_bf16": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _int, _i64, _i32, _i32, _int, _vp],
-    "gcnx_gemm_dx_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _int, _i64, _i32, _i32, _vp, _vp],
+    "gcnx_gemm_fwd_bf16": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _int, _i64, _i32, _i32, _int, _vp, _vp],
+    "gcnx_gemm_dx_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _int, _i64, _i32, _i32, _vp, _vp, _vp],
+    "gcnx_gemm_stream_images": [_vp, _i32, _vp],
     "gcnx_gemm_dw_bf16": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32],
     "gcnx_dense_bwd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp],
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
@@ -133,6 +134,14 @@ class WimageJob(C.Structure):
     """gcnx_wimage_job (include/gcnx.h): one matrix of a gcnx_wimage_prepare launch."""
     _fields_ = [("w", C.c_void_p), ("img", C.c_void_p), ("fi", C.c_int32), ("fo", C.c_int32), ("transpose", C.c_int32),
                 ("prec", C.c_int32)]
+
+
+class StreamImageJob(C.Structure):
+    """gcnx_stream_image_job (include/gcnx.h): one weight operand of a gcnx_gemm_stream_images launch."""
+    _fields_ = [("w", C.c_void_p), ("fi", C.c_int32), ("fo", C.c_int32), ("transpose", C.c_int32), ("img", C.c_void_p)]
+
+
+STREAM_IMAGE_BYTES = 131072
 
 
 class PendingReduce(C.Structure):

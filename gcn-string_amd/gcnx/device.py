@@ -475,27 +475,42 @@ def spmm_pool_bwd_bf16out(ctx, at, y, seg, dpooled, out16, mode="sum", y_bits=No
     return True
 
 
-def gemm_fwd_bf16(ctx, x16, w, bias, out, act=None, bits=None):
+def stream_images(ctx, jobs, storage):
+    """The bf16 images of up to four 256 x 256 weight operands in one launch (gcnx_gemm_stream_images).  jobs: (w, transpose)
+    pairs -- transpose = True: the operand of gemm_fwd_bf16 (x w), False: of gemm_dx_bf16 (dh w^T); storage: a uint16 array
+    of at least len(jobs) * 65536 elements.  Returns the device pointers, to be passed as ``wimg``."""
+    assert storage.dtype == np.uint16 and storage.size >= len(jobs) * (L.STREAM_IMAGE_BYTES // 2) and len(jobs) <= 4
+    arr = (L.StreamImageJob * len(jobs))()
+    ptrs = []
+    for i, (w, tr) in enumerate(jobs):
+        assert w.shape == (256, 256) and w.contiguous
+        ptrs.append(storage.ptr + i * L.STREAM_IMAGE_BYTES)
+        arr[i] = L.StreamImageJob(w.ptr, 256, 256, 1 if tr else 0, ptrs[-1])
+    ctx._ck(ctx.lib.gcnx_gemm_stream_images(ctx.h, len(jobs), C.cast(arr, C.c_void_p)))
+    return ptrs
+
+
+def gemm_fwd_bf16(ctx, x16, w, bias, out, act=None, bits=None, wimg=None):
     """out = act(x16 w + bias) with x16 stored as bfloat16; out is stored as bfloat16 when it is a uint16 array
     (gcnx_gemm_fwd_bf16); bits (optional, act = "relu"): the bit image of [out > 0] for gemm_dx_bf16."""
     n, fi = x16.shape
     fo = w.shape[1]
     assert _is16(x16) and w.shape[0] == fi and out.shape == (n, fo) and (bits is None or bits.nbytes >= n * 64)
     rc = ctx.lib.gcnx_gemm_fwd_bf16(ctx.h, x16.ptr, x16.ld, _p(w), _p(bias), out.ptr, out.ld, int(_is16(out)), n, fi, fo, L.ACTS[act],
-                                    _p(bits))
+                                    _p(bits), wimg)
     if rc == L.ERR_UNSUPPORTED:
         return False
     ctx._ck(rc)
     return True
 
 
-def gemm_dx_bf16(ctx, dh16, w, dx, mask_bits=None, db=None):
+def gemm_dx_bf16(ctx, dh16, w, dx, mask_bits=None, db=None, wimg=None):
     """dx = dh16 w^T (* the ReLU mask in mask_bits), db = column sums of dx; dh16 stored as bfloat16, dx as bfloat16 when it
     is a uint16 array (gcnx_gemm_dx_bf16)."""
     n, fo = dh16.shape
     fi = w.shape[0]
     assert _is16(dh16) and w.shape[1] == fo and dx.shape == (n, fi)
-    rc = ctx.lib.gcnx_gemm_dx_bf16(ctx.h, dh16.ptr, dh16.ld, _p(w), dx.ptr, dx.ld, int(_is16(dx)), n, fi, fo, _p(mask_bits), _p(db))
+    rc = ctx.lib.gcnx_gemm_dx_bf16(ctx.h, dh16.ptr, dh16.ld, _p(w), dx.ptr, dx.ld, int(_is16(dx)), n, fi, fo, _p(mask_bits), _p(db), wimg)
     if rc == L.ERR_UNSUPPORTED:
         return False
     ctx._ck(rc)

@@ -266,8 +266,11 @@ class GCN2(_GraphRunner):
                 if D.spmm_bf16out(ctx, batch.a, batch.x, None, s16):          # (False: the tile kernels do not serve this batch)
                     y16 = self._cap.view("y1_16", batch.n, self.hidden, np.uint16)
                     bufs["y1bits"] = self._cap.view("y1bits", batch.n, 16, np.int32)
-                    if not (D.gemm_fwd_bf16(ctx, s16, p["w1"], p["b1"], y16, act="relu", bits=bufs["y1bits"])
-                            and D.gemm_fwd_bf16(ctx, y16, p["w2"], None, bufs["h"])):
+                    # the bf16 images of the step's three weight operands (W1 and W2 forward, W2 for dX) in one launch
+                    bufs["wimg"] = D.stream_images(ctx, [(p["w1"], True), (p["w2"], True), (p["w2"], False)],
+                                                   self._cap.view("wimg", 3, 65536, np.uint16))
+                    if not (D.gemm_fwd_bf16(ctx, s16, p["w1"], p["b1"], y16, act="relu", bits=bufs["y1bits"], wimg=bufs["wimg"][0])
+                            and D.gemm_fwd_bf16(ctx, y16, p["w2"], None, bufs["h"], wimg=bufs["wimg"][1])):
                         raise RuntimeError("gcnx: the streaming bf16 GEMM refused a shape the bf16-storage path was chosen for")
                     bufs["act16"], bufs["y1bits_ok"], bufs["s1_16"], bufs["y1_16"] = True, True, s16, y16
             if bufs["act16"]:
@@ -414,7 +417,7 @@ class GCN2(_GraphRunner):
             self._allreduce_tail_bucket()
         if act16:
             dz16 = self._cap.view("dz1_16", batch.n, self.hidden, np.uint16)
-            self._must(D.gemm_dx_bf16(ctx, dh16, p["w2"], dz16, mask_bits=bufs["y1bits"], db=g["b1"]))   # dZ1 (bf16), db1
+            self._must(D.gemm_dx_bf16(ctx, dh16, p["w2"], dz16, mask_bits=bufs["y1bits"], db=g["b1"], wimg=bufs["wimg"][2]))   # dZ1 (bf16), db1
             self._must(D.gemm_dw_bf16(ctx, bufs["s1_16"], dz16, g["w1"]))      # dW1 = S1^T dZ1
         else:
             D.gemm_dx(ctx, bufs["h"], p["w2"], bufs["dz2"], prec=prec, y_mask=bufs["y1"], db=g["b1"],

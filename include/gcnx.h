@@ -297,9 +297,20 @@ GCNX_API int gcnx_spmm_csr_pool_bwd_bf16out(gcnx_ctx* ctx, const int32_t* rowptr
                           const float* y, int64_t ldy, const int32_t* graph_ptr, int32_t b, const float* dpooled, int64_t lddp,
                           void* out16, int64_t ldo, int32_t n, int32_t f, int mode, const gcnx_spmm_plan* plan, const void* y_bits);
 GCNX_API int gcnx_gemm_fwd_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const float* w, const float* bias, void* out, int64_t ldo,
-                          int out_bf16, int64_t n, int32_t fi, int32_t fo, int act, void* relu_bits);
+                          int out_bf16, int64_t n, int32_t fi, int32_t fo, int act, void* relu_bits, const void* wimg);
 GCNX_API int gcnx_gemm_dx_bf16(gcnx_ctx* ctx, const void* dh16, int64_t lddh, const float* w, void* dx, int64_t lddx, int dx_bf16,
-                          int64_t n, int32_t fi, int32_t fo, const void* mask_bits, float* db);
+                          int64_t n, int32_t fi, int32_t fo, const void* mask_bits, float* db, const void* wimg);
+/* `wimg` (may be NULL: the call builds it, one small launch): the bf16 image of the weight operand in MFMA-fragment order,
+ * GCNX_STREAM_IMAGE_BYTES bytes, written by gcnx_gemm_stream_images -- the images of up to four operands in ONE launch, once
+ * per step after the optimizer update (transpose = 1: the operand of gcnx_gemm_fwd_bf16, X W; 0: of gcnx_gemm_dx_bf16,
+ * dH W^T).  A 1/8 shard of config 3 is a 0.5 ms step: three 5-us preparation launches are 3 % of it. */
+#define GCNX_STREAM_IMAGE_BYTES 131072
+typedef struct gcnx_stream_image_job {
+  const float* w; int32_t fi, fo;   /* W [fi, fo], 256 x 256 */
+  int32_t transpose;
+  void* img;                        /* GCNX_STREAM_IMAGE_BYTES bytes, 16-byte aligned */
+} gcnx_stream_image_job;
+GCNX_API int gcnx_gemm_stream_images(gcnx_ctx* ctx, int32_t njobs, const gcnx_stream_image_job* jobs);
 GCNX_API int gcnx_gemm_dw_bf16(gcnx_ctx* ctx, const void* x16, int64_t ldx, const void* dh16, int64_t lddh, float* dw, int64_t n,
                           int32_t fi, int32_t fo);
 /* The ReLU mask of a Dense / GCNConv kernel product as a bit image between the forward and the backward product of

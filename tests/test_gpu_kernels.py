@@ -1524,6 +1524,13 @@ def test_bf16_storage_between_bf16_operand_gemms_changes_no_bit(ctx):
     D.gemm_dw(ctx, dx, dzr, g32, prec="bf16")
     assert D.gemm_dw_bf16(ctx, x16, dz16, g16)
     assert np.array_equal(g16.numpy(), g32.numpy())
+    # the weight images of a whole step from ONE launch (gcnx_gemm_stream_images) instead of one small launch per product
+    img_store = ctx.empty(2 * 65536, np.uint16)                # (the caller owns the images: they must outlive the products)
+    imgs = D.stream_images(ctx, [(dw_, True), (dw_, False)], img_store)
+    y16b = ctx.zeros((n, 256), np.uint16); dz16b = ctx.zeros((n, 256), np.uint16); db16b = ctx.zeros(256)
+    assert D.gemm_fwd_bf16(ctx, x16, dw_, dbias, y16b, act="relu", wimg=imgs[0])
+    assert D.gemm_dx_bf16(ctx, x16, dw_, dz16b, mask_bits=bits16, db=db16b, wimg=imgs[1])
+    assert np.array_equal(y16b.numpy(), y16.numpy()) and np.array_equal(dz16b.numpy(), dz16.numpy()) and np.array_equal(db16b.numpy(), db16.numpy())
     # shapes outside the streaming kernels: an answer, nothing launched
     small = ctx.zeros((1000, 256), np.uint16)
     assert not D.gemm_fwd_bf16(ctx, small, dw_, None, ctx.empty((1000, 256)))
