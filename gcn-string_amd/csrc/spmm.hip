@@ -790,6 +790,18 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           prefetched = true;
         }
       }
+      [[maybe_unused]] unsigned touch = 0;
+      if constexpr (MODE == kDuoFoldBits) {
+        // The next step's words of the bit image, touched now (one lane per 64-byte piece: at most one load per thread): the
+        // expansion at the top of the next step then starts from L2 instead of HBM -- every word is read once per launch, so
+        // it is never there by itself.  The value is only kept until the end of this step (a register-held prefetch of the
+        // whole slab, 10 words per thread, spilled 26 registers of this 128-VGPR kernel).
+        const bool same = s + 1 < sg;
+        const int nrow0 = same ? g.x : gn.x, nrows = (same || has_next) ? (same ? g.y : gn.y) : 0;
+        const int nc0 = same ? c0 + FT : (un % upg) * sg * FT;
+        const uint32_t* bwn = fo.bits + (size_t)(nc0 / FT) * (size_t)n + nrow0;
+        if (tid * 16 < nrows && !(dbg_rt & 32)) touch = bwn[tid * 16];
+      }
       const unsigned tb0 = tbl + cur * kDblBuf;  // this lane's first chunk of tile row 0 in the current buffer
       if constexpr (MODE == kDuoFold) {         // Y -> [Y > 0], in place
         float4* t4 = reinterpret_cast<float4*>(lds);
@@ -858,6 +870,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           if (sub == 0 && pos < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
         }
       }
+      if constexpr (MODE == kDuoFoldBits) asm volatile("" ::"v"(touch));   // (the touch load has landed; nothing reads it)
       if (dbl) cur ^= 1;                        // (the next slab's tile -- or the next unit's first -- is in the other buffer)
     }
     if (!has_next) break;
