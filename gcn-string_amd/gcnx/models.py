@@ -865,10 +865,11 @@ class GeneralGNN(_GraphRunner):
             D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
                          alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
                          dalpha=L.get("g_alpha"))
-        if training and "img_fwd" in L and self._images_fresh:
+        if training:
             # The Dense bias under a training-mode BatchNorm has the gradient sum_rows dz = gamma inv (sum g - n mean(g) -
-            # mean(g xhat) sum xhat) = 0 identically (sum xhat = 0): TensorFlow evaluates that sum and returns rounding
-            # noise of order 1e-8; the fast path writes the exact value instead of passing over dz once more.
+            # mean(g xhat) sum xhat) = 0 identically (sum xhat = 0; with sync-BN the sums are the global ones): TensorFlow
+            # evaluates that sum and returns rounding noise of order 1e-8; every training path here writes the exact value
+            # instead of passing over dz once more (14 column-sum launches per step in the fp32 configuration).
             pass                                           # (loss_and_grads zeroes the whole flat gradient buffer once per step)
         else:
             D.act_bias_grad(ctx, dz, None, dz, None, db=L["g_bias"])
@@ -993,10 +994,7 @@ class GeneralGNN(_GraphRunner):
         def seq():
             self._prepare_images()
             logits = self._forward(batch, bufs, True)
-            if self._images_fresh:
-                self.flat_g.fill_zero()                    # loss / accuracy tail and the analytically zero bias gradients: one memset
-            else:
-                self.loss_acc.fill_zero()
+            self.flat_g.fill_zero()                        # loss / accuracy tail and the analytically zero bias gradients: one memset
             D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, bufs["dlogits"], denom, cce=self.cce_train)
             self._backward(batch, bufs, True)
             if fused_comm:
