@@ -328,14 +328,15 @@ def test_rccl_path_single_rank(ctx):
     assert np.array_equal(d.numpy(), x) and float(c1.allreduce_host([3.5], "max")[0]) == 3.5
 
 
-@pytest.mark.parametrize("hidden", [128, 256])
-def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx, hidden):
+@pytest.mark.parametrize("hidden,f_in,prec", [(128, 128, "f32"), (256, 128, "f32"), (256, 256, "bf16")])
+def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx, hidden, f_in, prec):
     """The code path a rank of an N-GPU run takes -- gradients (fold-only reductions), ncclAllReduce and SGD recorded into
     ONE HIP graph -- with a real RCCL communicator.  One GPU is all there is here, so the communicator has one rank and
     the wrapper only CLAIMS a world of two: the collective is then the identity and the step must equal the plain
     single-process step bit for bit (same kernels, same order), through capture and replay.  hidden = 128: the one-launch
     layers with one flat all-reduce; hidden = 256: the two-launch layers, the all-reduce in two buckets -- the first on the
-    side stream (a second branch of the captured graph) beside layer 1's backward."""
+    side stream (a second branch of the captured graph) beside layer 1's backward; (256, 256, "bf16"): the same with the
+    streaming bf16 GEMMs and bf16 storage of S1, Y1, dH2, dZ1 (r3) inside the captured, bucketed step."""
     import ctypes as C
     from gcnx import _lib as L, synth
     from gcnx.comm import Communicator
@@ -352,14 +353,15 @@ def test_gcn2_multi_gpu_step_graph_with_a_real_rccl_collective(ctx, hidden):
             self.h, self._scratch, self._path = h, ctx.zeros(4), None
 
     # (hidden = 256: 130 graphs, so that the batch has a tile plan and takes the large-batch sequence the buckets live in)
-    hb = synth.ecoli_batch(6 if hidden == 128 else 130, 128, seed=21)
+    hb = synth.ecoli_batch(6 if hidden == 128 else 130, f_in, seed=21)
     vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
 
     def run(comm):
         a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
         batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
-        m = GCN2(ctx, 2, hidden=hidden, seed=5, comm=comm)
+        m = GCN2(ctx, 2, hidden=hidden, seed=5, comm=comm, prec=prec)
         out = [m.train_step(batch, None, lr=0.05, global_batch=hb.n_graphs) for _ in range(4)]   # eager, capture, replay x2
+        assert bool(m._bufs.get("act16")) == (prec == "bf16")
         return m, out
 
     comm = OneRankPosingAsTwo(ctx)
