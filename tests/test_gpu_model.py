@@ -429,6 +429,52 @@ def test_gcn2_world_size_2_on_one_gpu_equals_single_rank(hidden, n_calls):
         assert np.array_equal(a, b)                        # both ranks hold the same weights, bit for bit
 
 
+def test_gcn2_world_size_2_large_batch_with_bf16_storage_equals_single_rank():
+    """The same at the large-batch sequence with plain bf16 operands (r3): each rank's shard (~150 graphs, > 32 768 rows, a tile
+    plan) stores S1, Y1, dH2, dZ1 as bfloat16 and reduces its gradients in two buckets; the two ranks' summed gradients
+    equal the single-rank step on the whole batch up to fp32 reduction order -- the bf16 roundings are the same numbers
+    on either side (per row: no rounding depends on which rank holds the row)."""
+    import gcnx
+    from gcnx import synth, shard
+    from gcnx.models import DeviceBatch, GCN2
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from thread_comm import ThreadWorld
+    hb = synth.ecoli_batch(300, 256, seed=9)          # (~150 graphs per rank: a tile plan needs 128)
+    hb.vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+
+    def make_batch(ctx, part):
+        a = gcnx.DeviceCSR.from_host_csr(ctx, part.rowptr, part.colidx, part.vals, part.graph_ptr)
+        return DeviceBatch(ctx, ctx.to_device(part.x), a, gcnx.Segments(ctx, part.graph_ptr), ctx.to_device(part.y, np.float32))
+
+    ctx0 = gcnx.Context(0)
+    ref = GCN2(ctx0, 2, hidden=256, seed=5, use_graph=False, prec="bf16")
+    ref_loss, ref_acc = ref.train_step(make_batch(ctx0, hb), None, lr=0.05)
+    assert ref._bufs.get("act16")
+    ref_g, ref_w = ref.gradients(), ref.get_weights()
+    ctx0.close()
+
+    def rank_fn(rank, make_comm):
+        ctx = gcnx.Context(0)
+        part, global_b = shard.shard_batch(hb, rank, 2)
+        m = GCN2(ctx, 2, hidden=256, seed=5, use_graph=False, comm=make_comm(ctx), prec="bf16")
+        loss, acc = m.train_step(make_batch(ctx, part), None, lr=0.05, global_batch=global_b)
+        out = (loss, acc, m.gradients(), m.get_weights(), m.comm.calls, bool(m._bufs.get("act16")))
+        ctx.close()
+        return out
+
+    res = ThreadWorld(2).run(rank_fn)
+    for loss, acc, g, w, calls, act16 in res:
+        assert calls == 2 and act16
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)) and acc == pytest.approx(ref_acc)
+        for k in g:
+            assert rel_err(g[k], ref_g[k]) < 5e-5, k
+        for a, b in zip(w, ref_w):
+            assert rel_err(a, b) < 5e-5
+    for a, b in zip(res[0][3], res[1][3]):
+        assert np.array_equal(a, b)
+
+
 def test_general_gnn_sync_bn_world_size_2_equals_single_rank():
     """GeneralGNN with a communicator (sync-BN): two thread ranks with graph shards of one batch normalise with the
     GLOBAL batch statistics (all-reduced column sums in both moment passes and in the BN backward), and the step --
