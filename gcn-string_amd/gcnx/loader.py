@@ -174,10 +174,41 @@ def sp_matrix_to_sp_tensor(a):
     return SparseTensor(idx, val[order], (int(a.shape[0]), int(a.shape[1])))
 
 
+def _disjoint_coo(a_list):
+    """block_diag + sp.find + tf.sparse.reorder of a list of scipy matrices in one pass: the (row, col, value) triples of
+    the disjoint union in row-major order.  A graph's CSR rows are already in that order once its column indices are
+    sorted, and the blocks follow each other, so the union is the concatenation of the per-graph triples shifted by the
+    node offset -- no block_diag matrix, no 350 k-element lexsort (30 ms of the 50 a 32-graph E. coli batch took)."""
+    import scipy.sparse as sp
+
+    rows, cols, vals, off = [], [], [], 0
+    for a in a_list:
+        c = a if sp.isspmatrix_csr(a) else sp.csr_matrix(a)
+        if not c.has_sorted_indices:
+            c = c.sorted_indices()
+        n = c.shape[0]
+        r = np.repeat(np.arange(off, off + n, dtype=np.int64), np.diff(c.indptr))
+        k = c.indices.astype(np.int64) + off
+        v = c.data
+        if v.size and not v.all():             # sp.find drops explicitly stored zeros
+            keep = v != 0
+            r, k, v = r[keep], k[keep], v[keep]
+        rows.append(r); cols.append(k); vals.append(v)
+        off += n
+    if not rows:
+        return SparseTensor(np.zeros((0, 2), np.int64), np.zeros(0), (0, 0))
+    idx = np.stack([np.concatenate(rows), np.concatenate(cols)], axis=1)
+    return SparseTensor(idx, np.concatenate(vals), (off, off))
+
+
 def collate_disjoint(graphs, node_level=False):
-    x, a, i = to_disjoint([g.x for g in graphs], [g.a for g in graphs])
+    """DisjointLoader.collate: the same ((x, a, i), y) as to_disjoint + sp_matrix_to_sp_tensor, built directly."""
+    x_list = [g.x for g in graphs]
+    x = np.vstack(x_list)
+    n_nodes = np.array([x_.shape[0] for x_ in x_list], dtype=np.int64)
+    i = np.repeat(np.arange(len(n_nodes), dtype=np.int64), n_nodes)
     y = np.vstack([g.y for g in graphs]) if node_level else np.array([g.y for g in graphs])
-    return (x, sp_matrix_to_sp_tensor(a), i), y
+    return (x, _disjoint_coo([g.a for g in graphs]), i), y
 
 
 class DisjointLoader:

@@ -312,3 +312,38 @@ def test_from_networkx_reproduces_the_reference_data_contract():
     # a directed graph gives an asymmetric adjacency: allowed by the contract (the device side then transposes)
     dg = nx.DiGraph(); dg.add_node(0, x=np.zeros(2)); dg.add_node(1, x=np.ones(2)); dg.add_edge(0, 1, weight=2.0)
     assert np.array_equal(from_networkx(dg, [1, 0]).a.toarray(), [[0, 1], [0, 0]])
+
+
+def test_collate_builds_the_disjoint_coo_directly_and_equals_block_diag_find_reorder():
+    """DisjointLoader.collate (gcn.py:316-317, 350, 367) builds the row-major COO of the disjoint union by concatenating the
+    per-graph CSR triples (r3: 42 -> 3 ms for a 32-graph E. coli batch); it must equal the Spektral-order restatement --
+    to_disjoint (vstack, block_diag, repeat) + sp_matrix_to_sp_tensor (find, reorder) -- exactly: unsorted column indices,
+    explicitly stored zeros (sp.find drops them), a COO input, an empty graph-free batch edge, single-node graphs."""
+    import scipy.sparse as sp
+    from gcnx.loader import Graph, collate_disjoint, to_disjoint, sp_matrix_to_sp_tensor, _disjoint_coo
+    rng = np.random.default_rng(3)
+    graphs = []
+    for k, n in enumerate([1, 7, 30, 2, 64, 5]):
+        d = (rng.random((n, n)) < 0.3).astype(np.float64)
+        d = np.maximum(d, d.T); np.fill_diagonal(d, 1.0)
+        a = sp.csr_matrix(d)
+        if k == 2:                                   # unsorted indices inside the rows
+            perm = a.copy(); perm.indices = perm.indices.copy()
+            for r in range(n):
+                lo, hi = perm.indptr[r], perm.indptr[r + 1]
+                perm.indices[lo:hi] = perm.indices[lo:hi][::-1]; perm.data[lo:hi] = perm.data[lo:hi][::-1]
+            perm.has_sorted_indices = False
+            a = perm
+        if k == 3:
+            a = a.tocoo()
+        if k == 4:                                   # explicit zeros stay in the structure of a CSR until someone prunes them
+            a.data[::5] = 0.0
+        graphs.append(Graph(x=rng.standard_normal((n, 4)), a=a, y=np.eye(2)[k % 2]))
+    (x, st, i), y = collate_disjoint(graphs)
+    x2, a2, i2 = to_disjoint([g.x for g in graphs], [g.a for g in graphs])
+    st2 = sp_matrix_to_sp_tensor(a2)
+    assert np.array_equal(x, x2) and np.array_equal(i, i2) and st.dense_shape == st2.dense_shape
+    assert st.indices.dtype == np.int64 and np.array_equal(st.indices, st2.indices) and np.array_equal(st.values, st2.values)
+    assert y.shape == (6, 2)
+    e = _disjoint_coo([])
+    assert e.indices.shape == (0, 2) and e.dense_shape == (0, 0)
