@@ -265,14 +265,14 @@ class GCN2(_GraphRunner):
                 s16 = self._cap.view("s1_16", batch.n, self.f_in, np.uint16)
                 if D.spmm_bf16out(ctx, batch.a, batch.x, None, s16):          # (False: the tile kernels do not serve this batch)
                     y16 = self._cap.view("y1_16", batch.n, self.hidden, np.uint16)
-                    bufs["y1bits"] = self._cap.view("y1bits", batch.n, 16, np.int32)
+                    bufs["y1bits"] = self._cap.view("y1bits", batch.n, 16, np.int32) if with_loss == "grads" else None
                     # the bf16 images of the step's three weight operands (W1 and W2 forward, W2 for dX) in one launch
                     bufs["wimg"] = D.stream_images(ctx, [(p["w1"], True), (p["w2"], True), (p["w2"], False)],
                                                    self._cap.view("wimg", 3, 65536, np.uint16))
                     if not (D.gemm_fwd_bf16(ctx, s16, p["w1"], p["b1"], y16, act="relu", bits=bufs["y1bits"], wimg=bufs["wimg"][0])
                             and D.gemm_fwd_bf16(ctx, y16, p["w2"], None, bufs["h"], wimg=bufs["wimg"][1])):
                         raise RuntimeError("gcnx: the streaming bf16 GEMM refused a shape the bf16-storage path was chosen for")
-                    bufs["act16"], bufs["y1bits_ok"], bufs["s1_16"], bufs["y1_16"] = True, True, s16, y16
+                    bufs["act16"], bufs["y1bits_ok"], bufs["s1_16"], bufs["y1_16"] = True, with_loss == "grads", s16, y16
             if bufs["act16"]:
                 pass
             elif self._s_order():
@@ -434,10 +434,10 @@ class GCN2(_GraphRunner):
             raise RuntimeError("gcnx: a bf16-storage kernel refused a shape its producer had accepted")
 
     def _act16_try(self, batch, with_loss):
-        """bf16 storage of S1, Y1, dH2, dZ1 (the tensors only weight GEMMs read): a training step with plain bf16 GEMM operands
-        at the streaming kernels' shape, the aggregation on a tile plan.  The first producer (gcnx_spmm_csr_bf16out) has the
+        """bf16 storage of S1, Y1, dH2, dZ1 (the tensors only weight GEMMs read): a step -- training, or the forward pass of
+        evaluate() -- with plain bf16 GEMM operands at the streaming kernels' shape, the aggregation on a tile plan.  The first producer (gcnx_spmm_csr_bf16out) has the
         last word.  GCNX_ACT16=0 keeps fp32 storage (same results, bit for bit: tested)."""
-        return (with_loss == "grads" and self.prec == "bf16" and self._knob["act16"] and self.hidden == 256 and self.f_in == 256
+        return (self.prec == "bf16" and self._knob["act16"] and self.hidden == 256 and self.f_in == 256
                 and batch.n >= 32768 and batch.a.plan is not None and batch.a.vals is not None and self._knob["side"] == 1)
 
     def _allreduce_tail_bucket(self):

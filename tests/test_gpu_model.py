@@ -823,6 +823,9 @@ def test_gcn2_bf16_storage_of_gemm_only_activations_changes_no_bit(ctx):
             loss, acc = m.train_step(batch, None, lr=0.01)
             out.append((loss, acc, {k: v.copy() for k, v in m.gradients().items()}, [w.copy() for w in m.get_weights()]))
         assert bool(m._bufs.get("act16")) == store16
+        ev = m.evaluate_batch(batch, None)                 # the forward pass of evaluate() takes the same storage
+        assert bool(m._bufs.get("act16")) == store16
+        out.append((ev[0], ev[1], {"probs": ev[2]}, []))
         res[store16] = out
     for (l1, a1, g1, w1), (l0, a0, g0, w0) in zip(res[True], res[False]):
         assert l1 == l0 and a1 == a0
