@@ -134,6 +134,8 @@ __device__ __forceinline__ void gcnx_colpart_reduce_body(const float* __restrict
 // this reduction's own second-stage scratch behind them).
 size_t gcnx_colsum_partials_ws(int64_t rows, int32_t f);
 int gcnx_colsum_partials(gcnx_ctx* ctx, int64_t rows, int32_t f, float* out);
+int gcnx_pool_graph_list(gcnx_ctx* ctx, const int32_t* graph_ptr, const int32_t* glist, int32_t nlist, const float* x, int64_t ldx,
+                         int32_t f, int mode, float* pooled, int64_t ldp, float* cnt);
 // head.hip: the classifier head from the pool's partial sums as a launch of its own (what gcnx_gemm_dw2 falls back to when
 // the head does not fit inside its launch)
 int gcnx_head_from_parts(gcnx_ctx* ctx, const gcnx_head_args* leaf);

@@ -42,6 +42,33 @@ int gcnx_dense_softmax_cce(gcnx_ctx* ctx, const float* pooled, int64_t ldp, cons
                    0, 0, nullptr, nullptr, cce_mode);
 }
 
+// The head on pooled rows that are already there (gcnx_spmm_csr_relu_bits_pool left them, with the positive counts):
+// gcnx_dense_softmax_cce + the bias gradient of the ReLU layer under the pool from the counts,
+// db_relu[c] = sum_g pool'(dPooled)[g][c] * cnt[g][c].
+int gcnx_pooled_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, int pool_mode, const float* pooled, int64_t ldp,
+                                  const float* cnt, const float* w, const float* bias, const float* y, int32_t b, int32_t h, int32_t c,
+                                  float denom, float* probs, float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp,
+                                  float* db_relu, int cce_mode) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "classifier head");
+  GCNX_REQUIRE(ctx, b >= 0 && h >= 0 && c > 0, "gcnx_pooled_dense_softmax_cce: bad shape");
+  GCNX_REQUIRE(ctx, pool_mode == GCNX_POOL_SUM || pool_mode == GCNX_POOL_AVG, "gcnx_pooled_dense_softmax_cce: SUM / AVG pooling only");
+  GCNX_REQUIRE(ctx, !db_relu || (dw && dpooled && cnt && graph_ptr), "gcnx_pooled_dense_softmax_cce: db_relu needs the gradient outputs, the counts and graph_ptr");
+  if (db_relu) {      // workspace for the products b x h and their reduction, reserved before the head takes its slabs from it
+    const int nblk = gcnx_cdiv(b, kHeadRows);
+    const size_t slab_floats = nblk > 1 ? (((size_t)nblk * ((size_t)h * c + c + 2) + 3) & ~(size_t)3) : 0;
+    int rc = gcnx_ws_reserve(ctx, std::max(std::max(slab_floats * sizeof(float), gcnx_colsum_partials_ws(b, h)), (size_t)b * h * sizeof(float)));
+    if (rc) return rc;
+  }
+  int rc = gcnx_dense_softmax_cce(ctx, pooled, ldp, w, bias, y, b, h, c, denom, probs, loss_acc, dw, db, dpooled, lddp, cce_mode);
+  if (rc || !db_relu || b == 0 || h == 0) return rc;
+  GCNX_REQUIRE(ctx, h % 4 == 0 && (reinterpret_cast<uintptr_t>(db_relu) & 15) == 0, "gcnx_pooled_dense_softmax_cce: db_relu needs h %% 4 == 0 and a 16-byte aligned buffer");
+  hipLaunchKernelGGL(dp_cnt_kernel, dim3(gcnx_cdiv((int64_t)b * h, 256)), dim3(256), 0, ctx->stream, dpooled, lddp, cnt, graph_ptr, b, h,
+                     pool_mode == GCNX_POOL_AVG ? 1 : 0, (float*)ctx->ws);
+  GCNX_LAUNCH_OK(ctx);
+  return gcnx_colsum_partials(ctx, b, h, db_relu);
+}
+
 int gcnx_pool_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, int64_t ldx, int pool_mode,
                                 int32_t* argmax, float* pooled, int64_t ldp, const float* w, const float* bias,
                                 const float* y, int32_t b, int32_t h, int32_t c, float denom, float* probs,

@@ -139,7 +139,8 @@ template <int RG>
 __global__ __launch_bounds__(16 * RG) void pool_fwd_kernel(const int32_t* __restrict__ gp, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ pooled, int32_t f, int mode,
                                                        int32_t* __restrict__ argmax, int vec, int nsplit,
-                                                       float* __restrict__ cnt) {
+                                                       float* __restrict__ cnt, const int32_t* __restrict__ glist = nullptr,
+                                                       int64_t ldp = 0) {
   // nsplit > 1 (sum/avg only): blockIdx.z owns a slice of the graph's rows and writes a partial
   // row sum to pooled + z*B*f (the caller's workspace); pool_combine_kernel adds them in order.
   // cnt (sum/avg, may be NULL): the number of positive entries per (graph, column), same layout as pooled --
@@ -150,9 +151,12 @@ __global__ __launch_bounds__(16 * RG) void pool_fwd_kernel(const int32_t* __rest
   const int c = blockIdx.x * 64 + cl * 4;
   const int valid = f - c;
   const bool v4 = vec && valid >= 4;
-  const int g = blockIdx.y;
+  // glist (r3): the launch covers the listed graphs only (those taller than a tile: gcnx_pool_graph_list), rows of pooled at
+  // leading dimension ldp
+  const int g = glist ? glist[blockIdx.y] : (int)blockIdx.y;
   int lo = gp[g], hi = gp[g + 1];
   const int glo = lo, ghi = hi;
+  const int64_t prow = glist ? ldp : (int64_t)f;
   if (nsplit > 1) {
     const int per = (hi - lo + nsplit - 1) / nsplit;
     lo = min(hi, lo + (int)blockIdx.z * per);
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(16 * RG) void pool_fwd_kernel(const int32_t* __rest
         st4(cnt + (int64_t)g * f + c, make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w), false, valid);
       }
     }
-    st4(pooled + (int64_t)g * f + c, o, false, valid);
+    st4(pooled + (int64_t)g * prow + c, o, false, valid);
   }
 }
 
@@ -513,6 +517,17 @@ int gcnx_pool_partials(gcnx_ctx* ctx, const int32_t* graph_ptr, const float* x, 
   else
     hipLaunchKernelGGL(pool_fwd_kernel<16>, grid, dim3(256), 0, ctx->stream, graph_ptr, x, ldx, part, f, mode,
                        (int32_t*)nullptr, vec, nsplit, cnt_part);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+// SUM / AVG pool (and positive counts) of the listed graphs only, straight into their rows of pooled / cnt.
+int gcnx_pool_graph_list(gcnx_ctx* ctx, const int32_t* graph_ptr, const int32_t* glist, int32_t nlist, const float* x, int64_t ldx,
+                         int32_t f, int mode, float* pooled, int64_t ldp, float* cnt) {
+  if (nlist <= 0) return GCNX_OK;
+  const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
+  hipLaunchKernelGGL(pool_fwd_kernel<16>, dim3(gcnx_cdiv(f, 64), nlist), dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode,
+                     (int32_t*)nullptr, vec, 1, cnt, glist, ldp);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -649,9 +649,17 @@ struct DuoFold {
   const float* dp;         // dPooled [b, f]
   int64_t lddp;
   int avg;
-  uint32_t* bits;          // MODE 2: written; MODE 3: read
+  uint32_t* bits;          // MODE 2, 4: written; MODE 3: read
+  float* ppart = nullptr;  // MODE 4: [tile graphs][waves][f] column sums of the rows each wave computed, and ...
+  float* cpart = nullptr;  // ... the number of positive entries among them (same layout)
 };
-enum { kDuoPlain = 0, kDuoFold = 1, kDuoBitsOut = 2, kDuoFoldBits = 3 };
+// kDuoBitsPool (r3): the pooled layer's forward WITHOUT its output -- what the step needs of Y = relu(A H + b) on a tile
+// graph is the bit image [Y > 0] (folded backward aggregation) and the graph's column sums and positive counts (global
+// pool, db of the layer): a unit owns the whole graph, so both leave the epilogue and Y is neither written (1 GB at
+// config 3) nor read back by a pool launch (1 GB).  Per lane: sums of its 8 columns over the row groups, counts as two
+// registers of four byte counters; one 16-quad shuffle tree per slab; lanes 0..3 of every wave write the wave's partial
+// row; a small launch adds the 16 waves' rows in order (pool_parts_reduce_kernel).
+enum { kDuoPlain = 0, kDuoFold = 1, kDuoBitsOut = 2, kDuoFoldBits = 3, kDuoBitsPool = 4 };
 
 template <int THREADS, int FT, int LPR, bool WEIGHTED, int MODE = kDuoPlain, bool OUT16 = false>
 __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
   // tile_dma32_asm); the wait for it is the explicit vmcnt(0) in front of the barrier that precedes the reduction.
   constexpr int kDblCap = 624;
   constexpr unsigned kDblBuf = (kDblCap + 1) * RB;          // tile + its zero row
-  constexpr bool kCanDbl = THREADS == 1024 && (MODE == kDuoPlain || MODE == kDuoBitsOut);
+  constexpr bool kCanDbl = THREADS == 1024 && (MODE == kDuoPlain || MODE == kDuoBitsOut || MODE == kDuoBitsPool);
   static_assert(!kCanDbl || 2 * kDblBuf <= (unsigned)(CAP + 1) * RB, "two small tiles must stay below the bias slice");
   int cur = 0;                                   // buffer the current tile is in (double-buffered units)
   bool prefetched = false, zero_rows_ok = false; // this step's tile already requested; the small tiles' zero rows written
@@ -808,6 +816,8 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
         for (int i = tid; i < g.y * (FT / 4); i += THREADS) t4[i] = f4_step(t4[i]);
         __syncthreads();
       }
+      [[maybe_unused]] float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // kDuoBitsPool: this lane's column sums of the slab
+      [[maybe_unused]] unsigned pk[2] = {0u, 0u};                                 // ... and positive counts, a byte per column
 #pragma unroll
       for (int t = 0; t < NI; ++t) if (t * SPAN < g.y) {
         __builtin_amdgcn_sched_barrier(0);      // one row group at a time: bounded live ranges
@@ -857,17 +867,48 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
             if (!FOLD && act == GCNX_ACT_RELU) {
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            if constexpr (OUT16) store4_bf16(out, (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4, o);
-            else *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
+            if constexpr (MODE == kDuoBitsPool) {
+              const unsigned b4 = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+              bword |= b4 << (4 * (sub + LPR * (j ^ csw)));
+              ps[4 * j] += o.x; ps[4 * j + 1] += o.y; ps[4 * j + 2] += o.z; ps[4 * j + 3] += o.w;
+              pk[j] += (b4 * 0x00204081u) & 0x01010101u;           // bit k -> byte k
+            } else {
+              if constexpr (OUT16) store4_bf16(out, (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4, o);
+              else *reinterpret_cast<float4*>(out + (int64_t)(g.x + r) * ldo + c0 + (sub + LPR * (j ^ csw)) * 4) = o;
+            }
             if constexpr (MODE == kDuoBitsOut)
               bword |= ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u))
                        << (4 * (sub + LPR * (j ^ csw)));
           }
         }
-        if constexpr (MODE == kDuoBitsOut) {      // the quad's four lanes hold the row's 32 columns: one word per row
+        if constexpr (MODE == kDuoBitsOut || MODE == kDuoBitsPool) {      // the quad's four lanes hold the row's 32 columns: one word per row
           bword |= __shfl_xor(bword, 1);
           bword |= __shfl_xor(bword, 2);
           if (sub == 0 && pos < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
+        }
+      }
+      if constexpr (MODE == kDuoBitsPool) {     // the wave's 16 quads (fixed tree); lanes 0..3 write the wave's partial row
+        if (csw) {                              // quads 2..5 hold their two chunks in the opposite order (bank swizzle): undo it
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float t_ = ps[i]; ps[i] = ps[4 + i]; ps[4 + i] = t_; }
+          const unsigned t_ = pk[0]; pk[0] = pk[1]; pk[1] = t_;
+        }
+#pragma unroll
+        for (int sh = 4; sh < 64; sh <<= 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ps[i] += __shfl_xor(ps[i], sh);
+          pk[0] += (unsigned)__shfl_xor((int)pk[0], sh);
+          pk[1] += (unsigned)__shfl_xor((int)pk[1], sh);
+        }
+        if (lane < 4) {
+          const size_t prow = ((size_t)(u / upg) * (THREADS / 64) + (tid >> 6)) * (size_t)(upg * sg * FT) + c0;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) {
+            const int col = (sub + LPR * j) * 4;
+            *reinterpret_cast<float4*>(fo.ppart + prow + col) = make_float4(ps[4 * j], ps[4 * j + 1], ps[4 * j + 2], ps[4 * j + 3]);
+            *reinterpret_cast<float4*>(fo.cpart + prow + col) = make_float4((float)(pk[j] & 255u), (float)((pk[j] >> 8) & 255u),
+                                                                            (float)((pk[j] >> 16) & 255u), (float)(pk[j] >> 24));
+          }
         }
       }
       if constexpr (MODE == kDuoFoldBits) asm volatile("" ::"v"(touch));   // (the touch load has landed; nothing reads it)
@@ -1322,6 +1363,12 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
     GCNX_DUO_ATTR(true, kDuoPlain); GCNX_DUO_ATTR(false, kDuoPlain); GCNX_DUO_ATTR(true, kDuoFold); GCNX_DUO_ATTR(false, kDuoFold);
     GCNX_DUO_ATTR(true, kDuoBitsOut); GCNX_DUO_ATTR(false, kDuoBitsOut); GCNX_DUO_ATTR(true, kDuoFoldBits); GCNX_DUO_ATTR(false, kDuoFoldBits);
 #undef GCNX_DUO_ATTR
+    if constexpr (THREADS == 1024) {     // the pooled layer without its output (bits + pool partials)
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true, kDuoBitsPool>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, false, kDuoBitsPool>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    }
     if constexpr (THREADS == 1024) {     // the bf16-result forms (weighted, plain / folded from the bit image)
       GCNX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_duo_kernel<THREADS, FT, LPR, true, kDuoPlain, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -1356,7 +1403,11 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
 #define GCNX_DUO_LAUNCH(W, M)                                                                                                \
   hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, W, M>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr, rowrec, \
                      colidx, vals, h, ldh, bias, out, ldo, graphs, upg, sg, act, (int)nunits, n, dbg, fo)
-  if (out16) {
+  if (mode == kDuoBitsPool) {
+    if constexpr (THREADS == 1024) {
+      if (vals) GCNX_DUO_LAUNCH(true, kDuoBitsPool); else GCNX_DUO_LAUNCH(false, kDuoBitsPool);
+    }
+  } else if (out16) {
     if constexpr (THREADS == 1024) {
       if (mode == kDuoFoldBits)
         hipLaunchKernelGGL((spmm_duo_kernel<THREADS, FT, LPR, true, kDuoFoldBits, true>), dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, rowptr,
@@ -1411,6 +1462,8 @@ struct gcnx_spmm_plan {
   int cap1 = kDuoCap32, cap2 = kSoloCap32;   // tier limits the lists were built for
   int2* dev = nullptr;                  // [n1 | n2 | nchunks] int2 records
   int32_t* gids = nullptr;              // graph index of the n1 + n2 tile records (the folded backward's dPooled row)
+  int32_t* tall_gids = nullptr;         // the graphs taller than a tile (their rows go through the row chunks), ascending
+  int ntall = 0;
   PipeItem* items = nullptr;            // pipelined kernel: graphs, tallest first: [n16 graphs of 625..1024 rows | n32 of <= 624]
   int nitems = 0, n16 = 0;
   int2* pipe_chunks = nullptr;          // ... and the 32-row chunks of the graphs too tall for it (> 1248 rows), for the rows kernel
@@ -1432,6 +1485,7 @@ static void plan_free(gcnx_spmm_plan* p) {
   if (!p) return;
   if (p->dev) (void)hipFree(p->dev);
   if (p->gids) (void)hipFree(p->gids);
+  if (p->tall_gids) (void)hipFree(p->tall_gids);
   if (p->items) (void)hipFree(p->items);
   if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
   for (int i = 0; i < p->norders; ++i) {
@@ -1647,8 +1701,12 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     p->nitems = (int)items.size();
     for (const PipeItem& it : items) p->n16 += it.ng > kPipeCap32 ? 1 : 0;    // sorted by size: they come first
     p->npipe_chunks = (int)tall.size();
+    std::vector<int32_t> tall_gids;
+    for (int g = 0; g < nblocks; ++g) if (bp[g + 1] - bp[g] > cap2) tall_gids.push_back(g);
+    p->ntall = (int)tall_gids.size();
     hipError_t e = plan_upload(ctx, &p->dev, all);
     if (e == hipSuccess) e = plan_upload(ctx, &p->gids, gids);
+    if (e == hipSuccess) e = plan_upload(ctx, &p->tall_gids, tall_gids);
     if (e == hipSuccess) e = plan_upload(ctx, &p->pipe_chunks, tall);
     if (e == hipSuccess) e = plan_upload(ctx, &p->items, items);
     if (e != hipSuccess) {
@@ -1704,6 +1762,79 @@ int gcnx_spmm_csr(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, c
                   int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act,
                   const gcnx_spmm_plan* plan) {
   return spmm_csr_impl(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan, nullptr);
+}
+
+// pooled[g][c] (/ n_g for AVG) and cnt[g][c] of tile graph t = gids[t]: its 16 waves' partial rows, in wave order
+__global__ __launch_bounds__(256) void pool_parts_reduce_kernel(const float* __restrict__ ppart, const float* __restrict__ cpart,
+                                                                const int32_t* __restrict__ gids, const int32_t* __restrict__ gp,
+                                                                int ntile, int32_t f, int avg, float* __restrict__ pooled, int64_t ldp,
+                                                                float* __restrict__ cnt) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (int64_t)ntile * f) return;
+  const int t = (int)(i / f), c = (int)(i - (int64_t)t * f);
+  const float* pp = ppart + (size_t)t * 16 * f + c;
+  const float* cp = cpart + (size_t)t * 16 * f + c;
+  float4 a = *reinterpret_cast<const float4*>(pp), k = *reinterpret_cast<const float4*>(cp);
+#pragma unroll
+  for (int w = 1; w < 16; ++w) {
+    const float4 v = *reinterpret_cast<const float4*>(pp + (size_t)w * f), q = *reinterpret_cast<const float4*>(cp + (size_t)w * f);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    k.x += q.x; k.y += q.y; k.z += q.z; k.w += q.w;
+  }
+  const int g = gids[t];
+  if (avg) {
+    const float inv = (float)max(gp[g + 1] - gp[g], 1);
+    a.x /= inv; a.y /= inv; a.z /= inv; a.w /= inv;
+  }
+  *reinterpret_cast<float4*>(pooled + (int64_t)g * ldp + c) = a;
+  *reinterpret_cast<float4*>(cnt + (int64_t)g * f + c) = k;
+}
+
+// The pooled GCNConv's forward for a training step on a tile plan WITHOUT its output (see kDuoBitsPool): relu_bits, the
+// graphs' pooled rows and positive counts.  Graphs taller than a tile keep the old form -- their rows of `out` are written
+// by the row chunks (the folded backward gathers them) and pooled by the pool kernel over the plan's list of such graphs.
+// Rows of tile graphs in `out` are NOT written.
+int gcnx_spmm_csr_relu_bits_pool(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                                 int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f,
+                                 const gcnx_spmm_plan* plan, void* relu_bits, const int32_t* graph_ptr, int32_t b, int pool_mode,
+                                 float* pooled, int64_t ldp, float* cnt) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation + pool (GCNConv under the global pool)");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0 && b >= 0, "gcnx_spmm_csr_relu_bits_pool: negative size");
+  GCNX_REQUIRE(ctx, pool_mode == GCNX_POOL_SUM || pool_mode == GCNX_POOL_AVG, "gcnx_spmm_csr_relu_bits_pool: SUM / AVG pooling only");
+  if (n == 0 || f == 0 || b == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, rowptr && colidx && h && out && relu_bits && graph_ptr && pooled && cnt, "gcnx_spmm_csr_relu_bits_pool: NULL pointer");
+  GCNX_REQUIRE(ctx, ldh >= f && ldo >= f && ldp >= f, "gcnx_spmm_csr_relu_bits_pool: leading dimension smaller than f=%d", f);
+  const bool ok = plan && plan->nblocks == b && plan->n1 == 0 && plan->n2 > 0 && f % kSlab == 0 && f % 4 == 0 && ldh % 4 == 0 && ldo % 4 == 0 &&
+                  ldp % 4 == 0 && aligned16(h) && aligned16(out) && aligned16(pooled) && aligned16(cnt) && (!bias || aligned16(bias)) &&
+                  (reinterpret_cast<uintptr_t>(relu_bits) & 3) == 0 && ctx->knob_spmm_kernel != 1 && ctx->knob_spmm_kernel != 3 &&
+                  (long long)(2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
+  if (!ok) return GCNX_ERR_UNSUPPORTED;                   // (an answer: gcnx_spmm_csr_relu_bits + the pool then)
+  const RowRec* rowrec = nullptr;
+  const RowOrder* order = nullptr;
+  { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
+  if (order && order->nsegs_tall > 0) return GCNX_ERR_UNSUPPORTED;
+  const size_t part_floats = (size_t)plan->n2 * 16 * f;
+  int rc = gcnx_ws_reserve(ctx, 2 * part_floats * sizeof(float));
+  if (rc) return rc;
+  float* ppart = (float*)ctx->ws;
+  float* cpart = ppart + part_floats;
+  const DuoFold bo{nullptr, nullptr, 0, 0, (uint32_t*)relu_bits, ppart, cpart};
+  rc = launch_duo<1024, 32, 4>(ctx, rowptr, rowrec, colidx, vals, h, ldh, bias, out, ldo, n, f, GCNX_ACT_RELU, plan->dev + plan->n1, plan->n2, &bo,
+                               kDuoBitsPool);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pool_parts_reduce_kernel, dim3(gcnx_cdiv((long long)plan->n2 * f / 4, 256)), dim3(256), 0, ctx->stream, (const float*)ppart,
+                     (const float*)cpart, (const int32_t*)(plan->gids + plan->n1), graph_ptr, plan->n2, f, pool_mode == GCNX_POOL_AVG ? 1 : 0,
+                     pooled, ldp, cnt);
+  GCNX_LAUNCH_OK(ctx);
+  if (plan->nchunks > 0) {      // graphs taller than a tile: rows of `out` from the row chunks, then the pool over those graphs
+    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, GCNX_ACT_RELU, plan->dev + plan->n1 + plan->n2, plan->nchunks, nullptr,
+                  plan->chunk_rpc, 0);
+    GCNX_LAUNCH_OK(ctx);
+    rc = gcnx_pool_graph_list(ctx, graph_ptr, plan->tall_gids, plan->ntall, out, ldo, f, pool_mode, pooled, ldp, cnt);
+    if (rc) return rc;
+  }
+  return GCNX_OK;
 }
 
 int gcnx_spmm_csr_relu_bits(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,

@@ -95,6 +95,8 @@ SIGNATURES = {
     "gcnx_segment_pool_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _int, _vp, _vp, _i64, _vp],
     "gcnx_spmm_csr_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp],
     "gcnx_spmm_csr_relu_bits": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "gcnx_pooled_dense_softmax_cce": [_vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int],
+    "gcnx_spmm_csr_relu_bits_pool": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _int, _vp, _i64, _vp],
     "gcnx_pool_bwd_colsum": [_vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _int, _vp],
     "gcnx_bn_stats": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "gcnx_bn_finalize": [_vp, _vp, _f32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],

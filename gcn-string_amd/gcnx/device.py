@@ -565,6 +565,19 @@ def pool_dense_softmax_cce(ctx, seg, x, pooled, w, bias, y, probs, loss_acc=None
     return probs
 
 
+def pooled_dense_softmax_cce(ctx, seg, pooled, cnt, w, bias, y, probs, loss_acc=None, denom=None, dw=None, db=None, dpooled=None,
+                             mode="sum", db_relu=None, cce="logits"):
+    """dense_softmax_cce on pooled rows that are already there (spmm_relu_bits_pool), + db_relu from the positive counts
+    (gcnx_pooled_dense_softmax_cce)."""
+    b, h = pooled.shape
+    c = w.shape[1]
+    assert seg.n_graphs == b and (cnt is None or cnt.shape == (b, h))
+    ctx._ck(ctx.lib.gcnx_pooled_dense_softmax_cce(ctx.h, seg.dev.ptr, L.POOLS[mode], _p(pooled), pooled.ld, _p(cnt), _p(w), _p(bias), _p(y),
+                                                  b, h, c, float(denom if denom else max(b, 1)), _p(probs), _p(loss_acc), _p(dw), _p(db),
+                                                  _p(dpooled), dpooled.ld if dpooled is not None else 0, _p(db_relu), L.CCES[cce]))
+    return probs
+
+
 def spmm_relu_bits(ctx, a, h, bias, out, bits):
     """out = relu(A h + bias) on the tile kernels, which also write the bit image of [out > 0] (int32 [(f / 32) * n]) that
     spmm_pool_bwd(y_bits=...) folds from.  Returns False -- nothing launched -- if the tile kernels do not serve this
@@ -587,6 +600,22 @@ def spmm_pool_bwd(ctx, at, y, seg, dpooled, out, mode="sum", y_bits=None):
                                            seg.n_graphs, _p(dpooled), dpooled.ld, _p(out), out.ld, n, f, L.POOLS[mode],
                                            at.plan if at.n_blocks == seg.n_graphs else None, _p(y_bits)))
     return out
+
+
+def spmm_relu_bits_pool(ctx, a, h, bias, out, bits, seg, pooled, cnt, mode="sum"):
+    """The pooled GCNConv's forward of a training step without its output (gcnx_spmm_csr_relu_bits_pool): the bit image of
+    relu(A h + b), the graphs' pooled rows and positive counts; rows of ``out`` are written for graphs taller than a tile only.
+    False -- nothing launched -- when the tile kernels do not serve the batch."""
+    n, f = h.shape
+    assert a.n == n and out.shape == (n, f) and pooled.shape == (seg.n_graphs, f) and cnt.shape == (seg.n_graphs, f)
+    if a.plan is None or a.n_blocks != seg.n_graphs:
+        return False
+    rc = ctx.lib.gcnx_spmm_csr_relu_bits_pool(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(a.vals), _p(h), h.ld, _p(bias), _p(out), out.ld, n, f,
+                                              a.plan, bits.ptr, seg.dev.ptr, seg.n_graphs, L.POOLS[mode], _p(pooled), pooled.ld, _p(cnt))
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    ctx._ck(rc)
+    return True
 
 
 def gcn_conv_fused_ok(ctx, n, fi, fo, ldx=None):

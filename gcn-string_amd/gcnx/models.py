@@ -163,7 +163,8 @@ class GCN2(_GraphRunner):
                       "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0",
                       "s_order": os.environ.get("GCNX_S_ORDER", "1") != "0",
                       "buckets": os.environ.get("GCNX_COMM_BUCKETS", "1") != "0",
-                      "act16": os.environ.get("GCNX_ACT16", "1") != "0"}
+                      "act16": os.environ.get("GCNX_ACT16", "1") != "0",
+                      "pool_in_spmm": os.environ.get("GCNX_POOL_IN_SPMM", "1") != "0"}
         self._rng = np.random.default_rng(seed)
         self.built = False
         self._bufs = None
@@ -296,10 +297,16 @@ class GCN2(_GraphRunner):
                 D.gemm(ctx, bufs["y1"], p["w2"], None, bufs["h"], prec=prec)
             # pooled layer on the tile kernels with a backward pass to follow: its launch also writes [Y2 > 0] as a bit
             # image, which the folded backward aggregation expands instead of reading Y2 again (1 GB -> 32 MB at config 3)
-            bufs["y2bits_ok"] = False
+            bufs["y2bits_ok"] = bufs["pool_done"] = False
             if with_loss == "grads" and self._fold(batch) and batch.a.plan is not None and self.hidden % 32 == 0:
                 bufs["y2bits"] = self._cap.view("y2bits", batch.n, self.hidden // 32, np.int32)
-                bufs["y2bits_ok"] = D.spmm_relu_bits(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"])
+                # ... and on tile graphs the launch leaves the pooled rows and positive counts too: Y2 is neither written
+                # nor read back by a pool launch there (r3; rows of the graphs taller than a tile are, as before)
+                if self._knob["pool_in_spmm"] and not self._head_late(batch):
+                    bufs["pool_cnt2"] = self._cap.view("pool_cnt2", batch.n_graphs, self.hidden)
+                    bufs["pool_done"] = D.spmm_relu_bits_pool(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"], batch.seg,
+                                                              bufs["pooled"], bufs["pool_cnt2"], self.pool)
+                bufs["y2bits_ok"] = bufs["pool_done"] or D.spmm_relu_bits(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"])
             if not bufs["y2bits_ok"]:
                 D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
         # Global pool, then Dense(softmax) + CCE + accuracy + the head gradients in one launch; with few graphs the
@@ -314,6 +321,10 @@ class GCN2(_GraphRunner):
             bufs["_head_late"] = D.head_args(batch.seg, bufs["tp_part"], bufs["tp_cnt"], bufs["pool_sum"], bufs["pool_cnt"], p["w3"],
                                              p["b3"], batch.y, denom, bufs["probs"], self.loss_acc, self.g["w3"], self.g["b3"],
                                              self.g["b2"], bufs["pooled"], bufs["dpooled"], mode=self.pool, cce=self.cce_train)
+        elif with_loss == "grads" and bufs.get("pool_done"):
+            D.pooled_dense_softmax_cce(ctx, batch.seg, bufs["pooled"], bufs["pool_cnt2"], p["w3"], p["b3"], batch.y, bufs["probs"],
+                                       self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"], mode=self.pool,
+                                       db_relu=self.g["b2"], cce=self.cce_train)
         elif with_loss == "grads":
             # db2 rides along when the backward folds pool' into the aggregation (dZ2 is never materialised there)
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],

@@ -369,6 +369,23 @@ GCNX_API int gcnx_spmm_csr_pool_bwd(gcnx_ctx* ctx, const int32_t* rowptr, const 
 GCNX_API int gcnx_spmm_csr_relu_bits(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals,
                            const float* h, int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f,
                            const gcnx_spmm_plan* plan, void* relu_bits);
+/* The pooled GCNConv's forward of a TRAINING step on a tile plan without its output (r3): what the step needs of
+ * Y = relu(A h + b) is [Y > 0] as the bit image (the folded backward aggregation, gcnx_spmm_csr_pool_bwd(y_bits)), the
+ * graphs' pooled rows -- GlobalSumPool / GlobalAvgPool([Y, i]), gcn.py:334 -- and the positive counts per (graph, column)
+ * (the layer's bias gradient).  On graphs that fit an LDS tile all three leave the aggregation's epilogue: their rows of
+ * `out` are NOT written and no pool launch reads them back (2 GB of the config-3 step).  Graphs taller than a tile keep
+ * the two-launch form: their rows of `out` ARE written (the folded backward gathers them) and pooled from there.
+ * pooled [b, ldp], cnt [b, f].  GCNX_ERR_UNSUPPORTED (nothing launched) when the tile kernels do not serve the batch:
+ * gcnx_spmm_csr_relu_bits / gcnx_spmm_csr + gcnx_pool_dense_softmax_cce then. */
+GCNX_API int gcnx_spmm_csr_relu_bits_pool(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,
+                        int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, const gcnx_spmm_plan* plan,
+                        void* relu_bits, const int32_t* graph_ptr, int32_t b, int pool_mode, float* pooled, int64_t ldp, float* cnt);
+/* ... and the classifier head on those pooled rows: gcnx_dense_softmax_cce + db_relu[c] = sum_g pool'(dPooled)[g][c] *
+ * cnt[g][c] (the pooled layer's bias gradient; NULL to skip). */
+GCNX_API int gcnx_pooled_dense_softmax_cce(gcnx_ctx* ctx, const int32_t* graph_ptr, int pool_mode, const float* pooled, int64_t ldp,
+                        const float* cnt, const float* w, const float* bias, const float* y, int32_t b, int32_t h, int32_t c,
+                        float denom, float* probs, float* loss_acc, float* dw, float* db, float* dpooled, int64_t lddp,
+                        float* db_relu, int cce_mode);
 /* db[f] = column sums of the same never-materialised dZ (BiasAddGrad of that layer):
  * sum_g scale_g * dPooled[g] * #{j in g : y[j] > 0}; deterministic (fixed summation order). */
 GCNX_API int gcnx_pool_bwd_colsum(gcnx_ctx* ctx, const int32_t* graph_ptr, int32_t b, const float* dpooled,

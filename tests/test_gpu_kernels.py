@@ -1581,3 +1581,48 @@ def test_spmm_bf16_result_rows_on_the_tile_kernels(ctx, mode):
         assert not D.spmm_bf16out(ctx, a, x, None, out16)
     finally:
         ctx.set_tuning("spmm_kernel", "auto")
+
+
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+def test_spmm_relu_bits_pool_leaves_bits_pooled_rows_and_counts_without_the_output(ctx, mode):
+    """gcnx_spmm_csr_relu_bits_pool (r3): against the two-launch form -- gcnx_spmm_csr_relu_bits, then the global pool and the
+    positive counts of its output.  The bit image is identical; pooled rows agree to summation order (the tile kernel adds a
+    graph's rows per lane, per wave, then over its 16 waves), counts exactly; rows of `out` are written for the graphs taller
+    than a tile only (identical there, untouched elsewhere); double-buffered and single tiles, tall graphs in the batch."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    o = O()
+    hb = synth.block_diag_batch(150_000, 1_500_000, 256, seed=6, with_x=False)
+    sizes = np.diff(hb.graph_ptr)
+    assert len(sizes) >= 128 and (sizes <= 624).any() and ((sizes > 624) & (sizes <= 1276)).any() and (sizes > 1276).any()
+    n, f, b = hb.n, 256, len(sizes)
+    rng = np.random.default_rng(10)
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    seg = Segments(ctx, hb.graph_ptr)
+    h = ctx.to_device(rng.standard_normal((n, f), dtype=np.float32)); bias = ctx.to_device(rng.standard_normal(f).astype(np.float32))
+    y_ref = ctx.empty((n, f)); bits_ref = ctx.zeros((f // 32) * n, np.int32)
+    assert D.spmm_relu_bits(ctx, a, h, bias, y_ref, bits_ref)
+    yh = y_ref.numpy()
+    pooled_ref, _ = o.global_pool_fwd(yh.astype(np.float64), hb.graph_ptr, mode)
+    cnt_ref = np.add.reduceat((yh > 0).astype(np.float64), hb.graph_ptr[:-1].astype(np.int64), axis=0)
+    sentinel = np.float32(-777.0)
+    y = ctx.to_device(np.full((n, f), sentinel, np.float32)); bits = ctx.zeros((f // 32) * n, np.int32)
+    pooled = ctx.zeros((b, f)); cnt = ctx.zeros((b, f))
+    assert D.spmm_relu_bits_pool(ctx, a, h, bias, y, bits, seg, pooled, cnt, mode)
+    tile_rows = np.concatenate([np.arange(hb.graph_ptr[g], hb.graph_ptr[g + 1]) for g in range(b) if sizes[g] <= 1276])
+    tall_rows = np.concatenate([np.arange(hb.graph_ptr[g], hb.graph_ptr[g + 1]) for g in range(b) if sizes[g] > 1276])
+    img, img_ref = bits.numpy().reshape(f // 32, n), bits_ref.numpy().reshape(f // 32, n)
+    assert np.array_equal(img[:, tile_rows], img_ref[:, tile_rows])
+    got_y = y.numpy()
+    assert np.all(got_y[tile_rows] == sentinel) and np.array_equal(got_y[tall_rows], yh[tall_rows])
+    assert np.array_equal(cnt.numpy(), cnt_ref)
+    assert rel_err(pooled.numpy(), pooled_ref) < TIGHT
+    p2 = ctx.zeros((b, f)); c2 = ctx.zeros((b, f))                      # deterministic
+    assert D.spmm_relu_bits_pool(ctx, a, h, bias, y, bits, seg, p2, c2, mode)
+    assert np.array_equal(p2.numpy(), pooled.numpy())
+    try:                                                                # refused when the tile kernels are switched off
+        ctx.set_tuning("spmm_kernel", "rows")
+        assert not D.spmm_relu_bits_pool(ctx, a, h, bias, y, bits, seg, p2, c2, mode)
+    finally:
+        ctx.set_tuning("spmm_kernel", "auto")

@@ -836,6 +836,40 @@ def test_gcn2_bf16_storage_of_gemm_only_activations_changes_no_bit(ctx):
     assert np.isfinite(res[True][-1][0]) and any(np.abs(v).max() > 0 for v in res[True][0][2].values())
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gcn2_pooled_layer_without_its_output_equals_the_two_launch_form(ctx, prec):
+    """The pooled layer's forward leaves bits, pooled rows and counts and writes no Y2 on tile graphs (r3,
+    gcnx_spmm_csr_relu_bits_pool + gcnx_pooled_dense_softmax_cce).  Against the same model with the aggregation, the pool
+    and the head as before (the knob GCNX_POOL_IN_SPMM=0 sets): three steps -- eager, captured, replayed -- loss, accuracy,
+    every gradient and the weights to summation order of the pool (1e-5)."""
+    from gcnx import synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch
+    hb = synth.block_diag_batch(100_000, 1_000_000, 256, seed=12)
+    sizes = np.diff(hb.graph_ptr)
+    assert len(sizes) >= 128 and (sizes > 1276).any() and (sizes <= 624).any()
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    y = np.zeros((len(sizes), 2), np.float32); y[np.arange(len(sizes)), np.arange(len(sizes)) % 2] = 1
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(y))
+    res = {}
+    for fused in (True, False):
+        m = GCN2(ctx, 2, hidden=256, seed=3, prec=prec, pool="avg" if prec == "f32" else "sum")
+        m._knob["pool_in_spmm"] = fused
+        out = []
+        for step in range(3):
+            loss, acc = m.train_step(batch, None, lr=0.01)
+            out.append((loss, acc, {k: v.copy() for k, v in m.gradients().items()}, [w.copy() for w in m.get_weights()]))
+        assert bool(m._bufs.get("pool_done")) == fused
+        res[fused] = out
+    for (l1, a1, g1, w1), (l0, a0, g0, w0) in zip(res[True], res[False]):
+        assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and a1 == pytest.approx(a0)
+        for k in g1:
+            assert rel_err(g1[k], g0[k]) < 1e-5, k
+        for u, v in zip(w1, w0):
+            assert rel_err(u, v) < 1e-5
+
+
 @pytest.mark.parametrize("workload", ["block1m", "powerlaw"])
 def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     """BASELINE config 3 (1M nodes / 10M entries / F=256, 1 667 graphs) and config 5 (122 power-law graphs of 8 192
@@ -966,6 +1000,12 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
         else:
             m1 = m._bufs["y1"].numpy() > 0
         m2 = m._bufs["y2"].numpy() > 0
+        if m._bufs.get("pool_done"):    # (r3: the pooled layer's launch leaves bits, pooled rows and counts; Y2 rows are written for
+            # the graphs taller than a tile only -- the other rows' signs come from the bit image, word (slab, row), bit = column)
+            img = m._bufs["y2bits"].numpy().view(np.uint32).reshape(256 // 32, hb.n)
+            from_bits = ((img.T[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(hb.n, 256)
+            tile = np.repeat(np.diff(hb.graph_ptr) <= 1276, np.diff(hb.graph_ptr))
+            m2 = np.where(tile[:, None], from_bits, m2)
         if prec != "bf16":
             assert abs(loss - loss64) < TOL * abs(loss64), (prec, loss, loss64)
             f1, f2 = m1 != own1, m2 != own2
