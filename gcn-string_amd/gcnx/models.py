@@ -298,7 +298,8 @@ class GCN2(_GraphRunner):
             # pooled layer on the tile kernels with a backward pass to follow: its launch also writes [Y2 > 0] as a bit
             # image, which the folded backward aggregation expands instead of reading Y2 again (1 GB -> 32 MB at config 3)
             bufs["y2bits_ok"] = bufs["pool_done"] = False
-            if with_loss == "grads" and self._fold(batch) and batch.a.plan is not None and self.hidden % 32 == 0:
+            if (self._fold(batch) and batch.a.plan is not None and self.hidden % 32 == 0
+                    and (with_loss == "grads" or self._knob["pool_in_spmm"])):                 # (forward-only passes too: evaluate())
                 bufs["y2bits"] = self._cap.view("y2bits", batch.n, self.hidden // 32, np.int32)
                 # ... and on tile graphs the launch leaves the pooled rows and positive counts too: Y2 is neither written
                 # nor read back by a pool launch there (r3; rows of the graphs taller than a tile are, as before)
@@ -306,7 +307,8 @@ class GCN2(_GraphRunner):
                     bufs["pool_cnt2"] = self._cap.view("pool_cnt2", batch.n_graphs, self.hidden)
                     bufs["pool_done"] = D.spmm_relu_bits_pool(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"], batch.seg,
                                                               bufs["pooled"], bufs["pool_cnt2"], self.pool)
-                bufs["y2bits_ok"] = bufs["pool_done"] or D.spmm_relu_bits(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"])
+                bufs["y2bits_ok"] = bufs["pool_done"] or (with_loss == "grads" and
+                                                          D.spmm_relu_bits(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], bufs["y2bits"]))
             if not bufs["y2bits_ok"]:
                 D.spmm(ctx, batch.a, bufs["h"], p["b2"], bufs["y2"], act="relu")
         # Global pool, then Dense(softmax) + CCE + accuracy + the head gradients in one launch; with few graphs the
@@ -330,6 +332,9 @@ class GCN2(_GraphRunner):
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, dw=self.g["w3"], db=self.g["b3"], dpooled=bufs["dpooled"],
                                      db_relu=self.g["b2"] if self._fold(batch) else None, cce=self.cce_train, **head)
+        elif bufs.get("pool_done"):       # evaluate() / a plain forward: the head on the pooled rows the aggregation left
+            D.pooled_dense_softmax_cce(ctx, batch.seg, bufs["pooled"], None, p["w3"], p["b3"], batch.y if with_loss else None, bufs["probs"],
+                                       self.loss_acc if with_loss else None, denom, mode=self.pool, cce=self.cce_eval)
         elif with_loss:
             D.pool_dense_softmax_cce(ctx, batch.seg, bufs["y2"], bufs["pooled"], p["w3"], p["b3"], batch.y, bufs["probs"],
                                      self.loss_acc, denom, cce=self.cce_eval, **head)

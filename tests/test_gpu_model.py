@@ -861,6 +861,9 @@ def test_gcn2_pooled_layer_without_its_output_equals_the_two_launch_form(ctx, pr
             loss, acc = m.train_step(batch, None, lr=0.01)
             out.append((loss, acc, {k: v.copy() for k, v in m.gradients().items()}, [w.copy() for w in m.get_weights()]))
         assert bool(m._bufs.get("pool_done")) == fused
+        ev = m.evaluate_batch(batch, None)                 # the forward pass of evaluate(): the same launch, the head on its pooled rows
+        assert bool(m._bufs.get("pool_done")) == fused
+        out.append((ev[0], ev[1], {"probs": ev[2]}, []))
         res[fused] = out
     for (l1, a1, g1, w1), (l0, a0, g0, w0) in zip(res[True], res[False]):
         assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and a1 == pytest.approx(a0)
