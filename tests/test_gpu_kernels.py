@@ -1626,3 +1626,40 @@ def test_spmm_relu_bits_pool_leaves_bits_pooled_rows_and_counts_without_the_outp
         assert not D.spmm_relu_bits_pool(ctx, a, h, bias, y, bits, seg, p2, c2, mode)
     finally:
         ctx.set_tuning("spmm_kernel", "auto")
+
+
+def test_round3_entry_points_refuse_bad_arguments_loudly(ctx):
+    """Error behaviour of the entry points added in round 3: a wrong argument is an error with a message (GcnxError), a shape
+    the kernels do not serve is an ANSWER (False from the wrapper, nothing launched, gcnx_last_error untouched)."""
+    import ctypes as C
+    from gcnx import device as D, _lib as L, synth
+    from gcnx._lib import GcnxError
+    from gcnx.device import DeviceCSR, Segments
+    w = ctx.zeros((256, 256)); store = ctx.empty(65536, np.uint16)
+    # gcnx_gemm_stream_images: only 256 x 256 operands, at most four jobs, aligned images
+    jobs = (L.StreamImageJob * 1)(L.StreamImageJob(ctx.zeros((128, 256)).ptr, 128, 256, 1, store.ptr))
+    with pytest.raises(GcnxError, match="256 x 256"):
+        ctx._ck(ctx.lib.gcnx_gemm_stream_images(ctx.h, 1, C.cast(jobs, C.c_void_p)))
+    jobs = (L.StreamImageJob * 1)(L.StreamImageJob(w.ptr, 256, 256, 1, store.ptr + 2))
+    with pytest.raises(GcnxError, match="aligned"):
+        ctx._ck(ctx.lib.gcnx_gemm_stream_images(ctx.h, 1, C.cast(jobs, C.c_void_p)))
+    with pytest.raises(GcnxError, match="0 .. 4"):
+        ctx._ck(ctx.lib.gcnx_gemm_stream_images(ctx.h, 5, C.cast(jobs, C.c_void_p)))
+    # the pooled head: db_relu needs the counts
+    hb = synth.ecoli_batch(4, 32, seed=2)
+    seg = Segments(ctx, hb.graph_ptr)
+    pooled = ctx.zeros((4, 32)); w3 = ctx.zeros((32, 2)); yv = ctx.to_device(hb.y.astype(np.float32))
+    probs = ctx.empty((4, 2)); la = ctx.zeros(2); dw = ctx.empty((32, 2)); db = ctx.empty(2); dp = ctx.empty((4, 32)); dbr = ctx.empty(32)
+    with pytest.raises(GcnxError, match="counts"):
+        D.pooled_dense_softmax_cce(ctx, seg, pooled, None, w3, None, yv, probs, la, 4.0, dw=dw, db=db, dpooled=dp, db_relu=dbr)
+    D.pooled_dense_softmax_cce(ctx, seg, pooled, None, w3, None, yv, probs, la, 4.0)      # forward only: fine
+    assert np.allclose(probs.numpy(), 0.5)
+    # the pooled layer without its output: a batch without a tile plan is an answer, not an error
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, synth.gcn_norm_host(hb.rowptr, hb.colidx), hb.graph_ptr)
+    n = hb.n
+    h = ctx.zeros((n, 32)); y = ctx.empty((n, 32)); bits = ctx.zeros(n, np.int32); cnt = ctx.zeros((4, 32))
+    err_before = ctx.lib.gcnx_last_error(ctx.h)
+    assert not D.spmm_relu_bits_pool(ctx, a, h, None, y, bits, seg, pooled, cnt, "sum")
+    assert ctx.lib.gcnx_last_error(ctx.h) == err_before
+    assert not D.spmm_bf16out(ctx, a, h, None, ctx.empty((n, 32), np.uint16))
+    assert not D.gemm_dx_bf16(ctx, ctx.zeros((1000, 256), np.uint16), w, ctx.empty((1000, 256), np.uint16))
