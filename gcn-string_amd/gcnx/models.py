@@ -672,11 +672,17 @@ class GeneralGNN(_GraphRunner):
         self.cce_train, self.cce_eval = cce_train, cce_eval     # see GCN2.__init__
         self.comm = comm                                  # gcnx.comm.Communicator: sync-BN + gradient all-reduce
         unsupported = {"connectivity": (connectivity, "cat"), "batch_norm": (batch_norm, True), "dropout": (dropout, 0.0),
-                       "aggregate": (aggregate, "sum"), "hidden_activation": (hidden_activation, "prelu"),
-                       "pool": (pool, "sum"), "activation": (activation, "softmax")}
+                       "hidden_activation": (hidden_activation, "prelu"), "activation": (activation, "softmax")}
         for k, (got, want) in unsupported.items():
             if got != want:
                 raise NotImplementedError(f"GeneralGNN({k}={got!r}): only {want!r} (what gcn.py:320 uses) is built")
+        # Spektral's other aggregations / pools that map onto kernels that exist (r3): aggregate "mean" is the same gather with
+        # the weight 1 / (entries of the row) per entry, pool "avg" / "max" are modes of the segment pool and its backward
+        if aggregate not in ("sum", "mean"):
+            raise NotImplementedError(f"GeneralGNN(aggregate={aggregate!r}): 'sum' (gcn.py:320) and 'mean' are built")
+        if pool not in ("sum", "avg", "max"):
+            raise NotImplementedError(f"GeneralGNN(pool={pool!r}): 'sum' (gcn.py:320), 'avg' and 'max' are built")
+        self.aggregate, self.pool = aggregate, pool
         self.ctx, self.output, self.hidden, self.mp = ctx, int(output), int(hidden), int(message_passing)
         self.n_pre, self.n_post, self.prec = int(pre_process), int(post_process), prec
         self._rng = np.random.default_rng(seed)
@@ -840,10 +846,23 @@ class GeneralGNN(_GraphRunner):
             D.bn_finalize(ctx, None, 1, L["mean"], L["inv"], L["moving_mean"], L["moving_var"])
         D.bn_act(ctx, z, L["mean"], L["inv"], L["gamma"], L["beta"], y, act=L["act"], alpha=L.get("alpha"))
 
+    def _agg_operator(self, batch):
+        """The aggregation's operator: the 0 / 1 pattern of a (aggregate = "sum"), or the same pattern with 1 / (entries of
+        the row) on every entry ("mean": tf.math.unsorted_segment_mean over a row's messages), built once per batch."""
+        if self.aggregate == "sum":
+            return batch.a.unweighted()
+        cache = batch.__dict__.setdefault("_route", {})
+        if "agg_mean" not in cache:
+            a = batch.a
+            deg = np.diff(a.rowptr.numpy()).astype(np.float32)
+            vals = np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(np.float32), deg.astype(np.int64))
+            cache["agg_mean"] = D.DeviceCSR(self.ctx, a.n, a.nnz, a.rowptr, a.colidx, self.ctx.to_device(vals), a.block_ptr, a.n_blocks, False)
+        return cache["agg_mean"]
+
     def _forward(self, batch, bufs, training):
         h, mp = self.hidden, self.mp
         cat = bufs["cat"]
-        a = batch.a.unweighted()                          # GeneralConv ignores adjacency values (8.A.4)
+        a = self._agg_operator(batch)                     # GeneralConv ignores adjacency values (8.A.4)
         x = batch.x
         li = 0
         for k in range(self.n_pre):
@@ -857,7 +876,11 @@ class GeneralGNN(_GraphRunner):
             self._dense_bn(L, inp, bufs[f"z{li}"], bufs["h"], training)
             D.spmm(self.ctx, a, bufs["h"], None, cat.cols((mp - k - 1) * h, (mp - k) * h))
             li += 1
-        D.segment_pool(self.ctx, batch.seg, cat, bufs["pooled"], "sum")
+        if self.pool == "max":
+            if getattr(self, "_cap", None) is None:
+                self._cap = _Capacity(self.ctx)
+            bufs["pool_arg"] = self._cap.view("pool_arg", bufs["pooled"].shape[0], bufs["pooled"].shape[1], np.int32)
+        D.segment_pool(self.ctx, batch.seg, cat, bufs["pooled"], self.pool, bufs.get("pool_arg") if self.pool == "max" else None)
         x = bufs["pooled"]
         for k in range(self.n_post):
             L = self.layers[li]
@@ -909,7 +932,7 @@ class GeneralGNN(_GraphRunner):
     def _backward(self, batch, bufs, training=True):
         h, mp = self.hidden, self.mp
         cat, dcat = bufs["cat"], bufs["dcat"]
-        at = batch.a.unweighted().transpose()
+        at = self._agg_operator(batch).transpose()
         n_layers = len(self.layers)
         li = n_layers - 1
         d = bufs["dlogits"]                               # d(BN output of the last layer) from softmax+CCE
@@ -921,7 +944,7 @@ class GeneralGNN(_GraphRunner):
                 dx = self._tmp(bufs, f"dy{li - 1}", x.shape)
             self._bwd_dense_bn(L, d, x, bufs[f"z{li}"], dx, training)
             d = dx; li -= 1
-        D.segment_pool_bwd(self.ctx, batch.seg, bufs["dpooled"], dcat, "sum")
+        D.segment_pool_bwd(self.ctx, batch.seg, bufs["dpooled"], dcat, self.pool, bufs.get("pool_arg") if self.pool == "max" else None)
         for k in reversed(range(mp)):
             L = self.layers[li]
             D.spmm(self.ctx, at, dcat.cols((mp - k - 1) * h, (mp - k) * h), None, bufs["dh"])

@@ -518,12 +518,24 @@ def general_gnn_init(rng, f_in, n_out, hidden=256, message_passing=4, pre=2, pos
     return layers
 
 
-def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="softmax"):
-    """A.3: pre-MLP -> 4x [z=GeneralConv(out); out=concat([z,out])] -> GlobalSumPool -> post-MLP.
-    GeneralConv (A.4): h = PReLU(BN(x W + b)); out[t] = sum_{(t,s) in a.indices} h[s]
-    (values unused, no self-loop added, no normalisation).
+def aggregate_vals(rowptr, aggregate, dtype=np.float64):
+    """GeneralConv(aggregate=...) (A.4): "sum" -> None (0 / 1 pattern); "mean" -> 1 / (entries of the target row) per entry
+    (tf.math.unsorted_segment_mean over the messages of a row; a row without entries aggregates to 0)."""
+    if aggregate == "sum":
+        return None
+    if aggregate != "mean":
+        raise ValueError(f"aggregate={aggregate!r}: 'sum' and 'mean' are restated")
+    deg = np.diff(np.asarray(rowptr)).astype(dtype)
+    return np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(dtype), np.diff(np.asarray(rowptr)))
+
+
+def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="softmax", aggregate="sum", pool="sum"):
+    """A.3: pre-MLP -> 4x [z=GeneralConv(out); out=concat([z,out])] -> global pool -> post-MLP.
+    GeneralConv (A.4): h = PReLU(BN(x W + b)); out[t] = sum (or mean) over {(t,s) in a.indices} of h[s]
+    (values unused, no self-loop added, no normalisation).  pool: "sum" (gcn.py:320's default), "avg", "max".
     Returns probs, caches, list of (moving_mean, moving_var) updates in layer order."""
     rowptr, colidx, _ = csr
+    agg = aggregate_vals(rowptr, aggregate, x.dtype)
     caches = {"pre": [], "gnn": [], "post": []}
     stats = []
     out = x
@@ -531,11 +543,11 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
         out, c, mm, mv = dense_bn_act_fwd(out, p, training, "prelu"); caches["pre"].append(c); stats.append((mm, mv))
     for p in layers["gnn"]:
         h, c, mm, mv = dense_bn_act_fwd(out, p, training, "prelu"); stats.append((mm, mv))
-        z = spmm_csr(rowptr, colidx, None, h)
+        z = spmm_csr(rowptr, colidx, agg, h)
         c["width_in"] = out.shape[1]
         caches["gnn"].append(c)
         out = np.concatenate([z, out], axis=1)
-    pooled, _ = global_pool_fwd(out, graph_ptr, "sum")
+    pooled, caches["pool_arg"] = global_pool_fwd(out, graph_ptr, pool)
     caches["pooled_in_width"] = out.shape[1]
     out = pooled
     n_post = len(layers["post"])
@@ -547,9 +559,10 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
     return out, caches, stats
 
 
-def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits"):
+def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits", aggregate="sum", pool="sum"):
     rowptr, colidx, _ = csr
-    probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True)
+    agg = aggregate_vals(rowptr, aggregate, x.dtype)
+    probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True, aggregate=aggregate, pool=pool)
     yf = y.astype(probs.dtype)
     loss, dlogits = cce(yf, caches["post"][-1]["zb"], probs, None, cce_mode)
     acc = categorical_accuracy(yf, probs)
@@ -563,15 +576,15 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
             d, grads["post"][k] = dense_bn_act_bwd(None, c, p, None, True, dzb=dlogits)
         else:
             d, grads["post"][k] = dense_bn_act_bwd(d, c, p, "prelu", True)
-    d = global_pool_bwd(d, graph_ptr, x.shape[0], "sum")
+    d = global_pool_bwd(d, graph_ptr, x.shape[0], pool, caches["pool_arg"])
     for k in reversed(range(len(layers["gnn"]))):
         p, c = layers["gnn"][k], caches["gnn"][k]
         hid = p["kernel"].shape[1]
         dz, dskip = d[:, :hid], d[:, hid:]
-        if csr_t is not None:
+        if csr_t is not None and agg is None:
             dh = spmm_csr(csr_t[0], csr_t[1], None, dz)
         else:
-            dh = spmm_csr_T(rowptr, colidx, None, dz)
+            dh = spmm_csr_T(rowptr, colidx, agg, dz)
         dx, grads["gnn"][k] = dense_bn_act_bwd(dh, c, p, "prelu", True)
         d = dx + dskip
     for k in reversed(range(len(layers["pre"]))):

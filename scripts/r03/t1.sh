@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/t1
-timeout -k 10 900 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "round3_entry" > gpurun_out/t1/tests.log 2>&1; rc=$?; tail -15 gpurun_out/t1/tests.log; [ $rc = 0 ] || exit $rc
+timeout -k 10 900 python3 -m pytest tests/test_gpu_model.py -x -q -m gpu -k "general" > gpurun_out/t1/tests.log 2>&1; rc=$?; tail -15 gpurun_out/t1/tests.log; exit $rc

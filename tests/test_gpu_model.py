@@ -475,6 +475,41 @@ def test_gcn2_world_size_2_large_batch_with_bf16_storage_equals_single_rank():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("aggregate,pool", [("mean", "avg"), ("sum", "max"), ("mean", "sum")])
+def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, pool):
+    """GeneralGNN(aggregate="mean" | pool="avg" | "max") (Spektral options beside gcn.py:320's defaults; r3): inference forward,
+    training step (loss, probabilities, every gradient) against the fp64 oracle, which torch autograd pins for these options
+    (tests/test_oracle.py).  Gradients get the gross-error bound of the default-option test's larger cases (PReLU kinks)."""
+    from gcnx import synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GeneralGNN
+    from oracle import gcn_oracle as O
+    hb, layers, flat = _general_gnn_case(31, 16, 32, 2, 5)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+    m = GeneralGNN(ctx, 2, activation="softmax", hidden=32, message_passing=2, aggregate=aggregate, pool=pool, use_graph=False)
+    m.build(16)
+    m.set_weights(flat, order="layer")
+    x64, y64 = hb.x.astype(np.float64), hb.y.astype(np.float64)
+    csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
+    rprobs, _, _ = O.general_gnn_forward(layers, x64, csr, hb.graph_ptr, False, aggregate=aggregate, pool=pool)
+    assert rel_err(m(batch, training=False), rprobs) < TOL
+    rl, ra, rg, rp, _ = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64, aggregate=aggregate, pool=pool)
+    loss, acc = m.train_step(batch, None, lr=0.01)
+    assert abs(loss - rl) < TOL * max(1, rl) and acc == pytest.approx(ra)
+    assert rel_err(m._bufs["probs"].numpy(), rp) < TOL
+    got = m.gradients()
+    li = 0
+    for grp in ("pre", "gnn", "post"):
+        for g in rg[grp]:
+            layer_max = max(np.abs(v).max() for v in g.values())
+            for name, ref in g.items():
+                assert np.max(np.abs(got[li][name] - ref)) < 2e-2 * np.abs(ref).max() + 1e-5 * layer_max, (grp, li, name)
+            li += 1
+    with pytest.raises(NotImplementedError):
+        GeneralGNN(ctx, 2, activation="softmax", aggregate="prod")
+
+
 def test_general_gnn_sync_bn_world_size_2_equals_single_rank():
     """GeneralGNN with a communicator (sync-BN): two thread ranks with graph shards of one batch normalise with the
     GLOBAL batch statistics (all-reduced column sums in both moment passes and in the BN backward), and the step --

@@ -154,8 +154,10 @@ def test_finite_difference_gradcheck_gcnconv():
         assert rel_err(grad, num) < 1e-6
 
 
-def test_general_gnn_gradients_match_torch_autograd():
-    """n1 tier (GeneralGNN-complete): BN(train) + PReLU + concat-skip + sum-aggregation."""
+@pytest.mark.parametrize("aggregate,pool", [("sum", "sum"), ("mean", "avg"), ("sum", "max"), ("mean", "sum")])
+def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
+    """n1 tier (GeneralGNN-complete): BN(train) + PReLU + concat-skip + sum-aggregation (gcn.py:320's defaults), and the
+    Spektral options aggregate="mean" / pool="avg" | "max" (r3)."""
     import torch
     rng = np.random.default_rng(2)
     sizes = [6, 9, 4]
@@ -176,11 +178,15 @@ def test_general_gnn_gradients_match_torch_autograd():
             p["gamma"] = 1 + 0.1 * rng.standard_normal(p["gamma"].shape)
             p["beta"] = 0.1 * rng.standard_normal(p["beta"].shape)
             p["bias"] = 0.1 * rng.standard_normal(p["bias"].shape)
-    loss, acc, grads, probs, stats = O.general_gnn_loss_and_grads(layers, x, (rowptr, colidx, None), gp, y)
+    loss, acc, grads, probs, stats = O.general_gnn_loss_and_grads(layers, x, (rowptr, colidx, None), gp, y, aggregate=aggregate, pool=pool)
 
     T = lambda v: torch.tensor(v, requires_grad=True)
     tl = {g: [{k: T(v) for k, v in p.items() if not k.startswith("moving")} for p in ps] for g, ps in layers.items()}
-    at = torch.tensor(a.toarray())
+    dense = a.toarray()
+    if aggregate == "mean":
+        deg = dense.sum(1, keepdims=True)
+        dense = np.where(deg > 0, dense / np.maximum(deg, 1), 0.0)
+    at = torch.tensor(dense)
 
     def block(h, p, final=False):
         z = h @ p["kernel"] + p["bias"]
@@ -194,7 +200,8 @@ def test_general_gnn_gradients_match_torch_autograd():
         out = block(out, p)
     for p in tl["gnn"]:
         out = torch.cat([at @ block(out, p), out], 1)
-    out = torch.stack([out[gp[g]:gp[g + 1]].sum(0) for g in range(3)])
+    red = {"sum": lambda t: t.sum(0), "avg": lambda t: t.mean(0), "max": lambda t: t.amax(0)}[pool]
+    out = torch.stack([red(out[gp[g]:gp[g + 1]]) for g in range(3)])
     out = block(out, tl["post"][0]); pr = block(out, tl["post"][1], final=True)
     tloss = -(torch.tensor(y) * torch.log(torch.clamp(pr, 1e-7, 1 - 1e-7))).sum(1).mean()
     tloss.backward()
