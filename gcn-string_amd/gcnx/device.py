@@ -345,6 +345,16 @@ class DeviceCSR:
             self._t = DeviceCSR(ctx, self.n, self.nnz, rp, ci, v, self.block_ptr, self.n_blocks, False)
         return self._t
 
+    def row_mean(self):
+        """Same structure with 1 / (entries of the row) on every entry: GeneralConv(aggregate="mean") -- the mean over a row's
+        messages (tf.math.unsorted_segment_mean); a row without entries aggregates to 0.  Built once per operator."""
+        if getattr(self, "_row_mean", None) is None:
+            deg = np.diff(self.rowptr.numpy()).astype(np.int64)
+            vals = np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(np.float32), deg)
+            self._row_mean = DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, self.ctx.to_device(vals), self.block_ptr,
+                                       self.n_blocks, False)
+        return self._row_mean
+
     def unweighted(self):
         """Same structure, values ignored (GeneralConv aggregation)."""
         return DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, None, self.block_ptr, self.n_blocks,

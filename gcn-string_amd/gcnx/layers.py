@@ -188,8 +188,9 @@ class GeneralConv(Layer):
     def __init__(self, channels=256, batch_norm=True, dropout=0.0, aggregate="sum", activation="prelu", use_bias=True,
                  prec="f32", **kw):
         super().__init__(**kw)
-        if aggregate != "sum":
-            raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): only 'sum' (what gcn.py:320 uses) is built")
+        if aggregate not in ("sum", "mean"):
+            raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): 'sum' (what gcn.py:320 uses) and 'mean' are built")
+        self.aggregate = aggregate
         if dropout:
             raise NotImplementedError("GeneralConv(dropout > 0) is not built (the reference trains with 0.0)")
         if activation not in (None, "linear", "relu", "prelu"):
@@ -243,7 +244,7 @@ class GeneralConv(Layer):
         else:
             h = z
         y = out if out is not None else self._buf("y", (n, c))
-        au = a.unweighted()                                  # values ignored (8.A.4)
+        au = a.unweighted() if self.aggregate == "sum" else a.row_mean()   # values ignored (8.A.4); "mean": 1 / row length
         D.spmm(ctx, au, h, None, y)
         self._saved = (x, au, z, h, bool(training))
         return y

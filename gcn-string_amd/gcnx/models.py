@@ -849,15 +849,7 @@ class GeneralGNN(_GraphRunner):
     def _agg_operator(self, batch):
         """The aggregation's operator: the 0 / 1 pattern of a (aggregate = "sum"), or the same pattern with 1 / (entries of
         the row) on every entry ("mean": tf.math.unsorted_segment_mean over a row's messages), built once per batch."""
-        if self.aggregate == "sum":
-            return batch.a.unweighted()
-        cache = batch.__dict__.setdefault("_route", {})
-        if "agg_mean" not in cache:
-            a = batch.a
-            deg = np.diff(a.rowptr.numpy()).astype(np.float32)
-            vals = np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(np.float32), deg.astype(np.int64))
-            cache["agg_mean"] = D.DeviceCSR(self.ctx, a.n, a.nnz, a.rowptr, a.colidx, self.ctx.to_device(vals), a.block_ptr, a.n_blocks, False)
-        return cache["agg_mean"]
+        return batch.a.unweighted() if self.aggregate == "sum" else batch.a.row_mean()
 
     def _forward(self, batch, bufs, training):
         h, mp = self.hidden, self.mp

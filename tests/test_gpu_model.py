@@ -1069,7 +1069,8 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
 
 
 @pytest.mark.parametrize("batch_norm,activation", [(True, "prelu"), (True, "relu"), (False, "relu"), (False, None)])
-def test_general_conv_layer_surface(ctx, batch_norm, activation):
+@pytest.mark.parametrize("aggregate", ["sum", "mean"])
+def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     """spektral.layers.GeneralConv as a layer of its own (SURVEY 8(b) surface list; inside GeneralGNN at gcn.py:320):
     layer([x, a], training=) = sum-aggregation over a.indices of activation(BN(x W + b)) -- adjacency values ignored --
     and backward(dy), against the oracle's dense_bn_act + spmm; training updates the moving statistics, inference
@@ -1082,8 +1083,9 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation):
     vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)            # values present -- and ignored
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
     x = ctx.to_device(hb.x)
-    conv = GeneralConv(20, batch_norm=batch_norm, activation=activation, seed=4)
+    conv = GeneralConv(20, batch_norm=batch_norm, activation=activation, aggregate=aggregate, seed=4)
     conv([x, a], training=True)                                  # builds
+    agg = O.aggregate_vals(hb.rowptr, aggregate)                 # None ("sum") / 1 / row length per entry ("mean", r3)
     rng = np.random.default_rng(1)
     names = list(conv.params) + list(conv.state)
     assert names == (["kernel", "bias"] + (["alpha"] if activation == "prelu" else []) +
@@ -1102,10 +1104,10 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation):
     for training in ((False, True) if batch_norm else (False,)):
         y = conv([x, a], training=training)
         h, cache, mm, mv = O.dense_bn_act_fwd(x64, p, training, activation)
-        assert rel_err(y.numpy(), O.spmm_csr(rp, ci, None, h)) < TOL, training
+        assert rel_err(y.numpy(), O.spmm_csr(rp, ci, agg, h)) < TOL, training
     dy = rng.standard_normal(y.shape).astype(np.float32)
     dx = conv.backward(ctx.to_device(dy))
-    dh = O.spmm_csr_T(rp, ci, None, dy.astype(np.float64))
+    dh = O.spmm_csr_T(rp, ci, agg, dy.astype(np.float64))
     rdx, rg = O.dense_bn_act_bwd(dh, cache, p, activation)
     assert rel_err(dx.numpy(), rdx) < 2 * TOL
     for k in conv.grads:
