@@ -28,6 +28,8 @@ struct gcnx_ctx {
   // tuning knobs (diagnostics, not API), read once at ctx creation: GCNX_SPMM_KERNEL, GCNX_SPMM_SLAB, GCNX_SPMM_SG
   int knob_spmm_kernel = 0;  // 0 auto, 1 rows, 2 tile
   int knob_spmm_slab = 0, knob_spmm_sg = 0;
+  const float* lr_dev = nullptr;  // gcnx_set_lr_source: the update launches read the learning rate from this device scalar
+                                  // (NULL: from their `lr` argument) -- a captured step then serves every value of a schedule
   int knob_gemm_stream = 1;  // GCNX_GEMM_STREAM=0: bf16 GEMMs stay on the tiled kernel (A/B measurement)
   // Side stream for gradient "leaves" (weight / bias gradients that nothing downstream in the backward pass
   // consumes): gcnx_side_begin swaps stream and workspace, so every entry point launches there unchanged.

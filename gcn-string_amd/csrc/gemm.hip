@@ -455,7 +455,8 @@ __device__ __forceinline__ float splitk_sum(const float* __restrict__ part, int6
 __global__ __launch_bounds__(256) void reduce_sgd_kernel(const float* __restrict__ part, int64_t slab, int nsplit,
                                                          int64_t total, int n_s, float* __restrict__ params,
                                                          float* __restrict__ grads, int64_t off, int64_t n_params,
-                                                         float lr, SgdPending pd) {
+                                                         float lr_arg, SgdPending pd, const float* __restrict__ lr_dev) {
+  const float lr = lr_dev ? *lr_dev : lr_arg;            // (gcnx_set_lr_source)
   __shared__ float4 s4[128][2];
   float (*s)[64] = reinterpret_cast<float(*)[64]>(&s4[0][0]);
   int bid = blockIdx.x;
@@ -1415,7 +1416,7 @@ int gcnx_gemm_dw_sgd(gcnx_ctx* ctx, const float* x, int64_t ldx, const float* dh
   }
   const int n_s = gcnx_cdiv(total, 64), n_o = gcnx_cdiv(n_params, 256);
   hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)ctx->ws,
-                     total, nsplit, total, n_s, params, grads, (int64_t)(dw - grads), n_params, lr, pd);
+                     total, nsplit, total, n_s, params, grads, (int64_t)(dw - grads), n_params, lr, pd, ctx->lr_dev);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -1509,7 +1510,7 @@ int gcnx_gemm_dw2(gcnx_ctx* ctx, const float* xa, int64_t ldxa, const float* dha
   pd.slabs = sb; pd.total = tb; pd.nsplit = nsplit; pd.soff = dwb - base; pd.n_ps = gcnx_cdiv(tb, 64);
   const int n_s = gcnx_cdiv(ta, 64), n_o = params ? gcnx_cdiv(n_params, 256) : 0;
   hipLaunchKernelGGL(reduce_sgd_kernel, dim3(n_s + pd.n_pc + pd.n_ps + n_o), dim3(256), 0, ctx->stream, (const float*)sa,
-                     ta, nsplit, ta, n_s, params, base, (int64_t)(dwa - base), n_params, lr, pd);
+                     ta, nsplit, ta, n_s, params, base, (int64_t)(dwa - base), n_params, lr, pd, ctx->lr_dev);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n,
-                                                  float lr) {
+                                                  float lr_arg, const float* __restrict__ lr_dev) {
+  const float lr = lr_dev ? *lr_dev : lr_arg;            // (gcnx_set_lr_source)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) p[i] = p[i] - lr * g[i];
@@ -678,6 +679,17 @@ int gcnx_softmax_cce(gcnx_ctx* ctx, const float* logits, const float* y, int32_t
   return GCNX_OK;
 }
 
+// The learning rate of every update launch (gcnx_sgd, gcnx_gemm_dw_sgd, gcnx_gemm_dw2) from a device scalar instead of the
+// `lr` argument: a learning rate is otherwise a kernel ARGUMENT, so a captured step is tied to one value and a schedule
+// that changes every step (any keras LearningRateSchedule; the reference's PiecewiseConstantDecay has three values,
+// gcn.py:321-325) would capture a graph per step.  lr_dev = NULL restores the argument.  The pointer must stay valid.
+int gcnx_set_lr_source(gcnx_ctx* ctx, const float* lr_dev) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_set_lr_source: not inside a capture (a captured launch keeps the source it was recorded with)");
+  ctx->lr_dev = lr_dev;
+  return GCNX_OK;
+}
+
 int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr) {
   GCNX_CHECK_CTX(ctx);
   GCNX_RANGE(ctx, "SGD update");
@@ -686,7 +698,7 @@ int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float 
   GCNX_REQUIRE(ctx, params && grads, "gcnx_sgd: NULL pointer");
   int grid = gcnx_cdiv(n, 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ctx->stream, params, grads, n, lr);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ctx->stream, params, grads, n, lr, ctx->lr_dev);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -35,6 +35,7 @@ _int = C.c_int
 # name -> argtypes (every function returns int unless listed in _RESTYPE)
 SIGNATURES = {
     "gcnx_version": [],
+    "gcnx_set_lr_source": [_vp, _vp],
     "gcnx_device_count": [C.POINTER(_int)],
     "gcnx_ctx_create": [_int, C.POINTER(_vp)],
     "gcnx_ctx_destroy": [_vp],

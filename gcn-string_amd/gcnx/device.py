@@ -47,6 +47,11 @@ class Context:
 
     SPMM_KERNELS = {"auto": 0, "rows": 1, "tile": 2, "pipe": 3}
 
+    def set_lr_source(self, scalar):
+        """The update launches read the learning rate from this 1-element fp32 device array instead of their ``lr`` argument
+        (None: the argument again); gcnx_set_lr_source.  A captured step then serves every value of a schedule."""
+        self._ck(self.lib.gcnx_set_lr_source(self.h, scalar.ptr if scalar is not None else None))
+
     def set_tuning(self, key, value):
         """Kernel-selection knobs of this context (gcnx_set_tuning; diagnostics: results never depend on them).
         ``set_tuning("spmm_kernel", "auto" | "rows" | "tile" | "pipe")``, ``("gemm_stream", 0 | 1)``, ..."""

@@ -135,6 +135,25 @@ class _GraphRunner:
         self._mdone = []
         return out
 
+    # ---- the learning rate as a device scalar --------------------------------------------------------------------------
+    # A rate passed by value is an argument of the captured update launch: one graph per VALUE (the reference's
+    # PiecewiseConstantDecay has three, gcn.py:321-325; a schedule that moves every step would capture every step).  With the
+    # rate in a device scalar (gcnx_set_lr_source) one captured step serves them all and a new value costs a 4-byte queued copy.
+    lr_on_device = os.environ.get("GCNX_LR_DEVICE", "1") != "0"
+
+    def _lr_key(self, lr):
+        """Announce this step's rate; returns what the captured graphs are keyed on ("dev", or the value itself)."""
+        if not self.lr_on_device or lr is None:
+            self.ctx.set_lr_source(None)
+            return lr
+        if getattr(self, "_lr_buf", None) is None:
+            self._lr_buf, self._lr_val = self.ctx.zeros(1), None
+        self.ctx.set_lr_source(self._lr_buf)                # (a ctx can serve several models: each step names its own source)
+        if self._lr_val != float(lr):
+            self._lr_buf.copy_from_host(np.asarray([lr], np.float32), wait=False)
+            self._lr_val = float(lr)
+        return "dev"
+
     def _drop_graphs(self):
         for g in getattr(self, "_graphs", {}).values():
             if not isinstance(g, str):
@@ -595,8 +614,9 @@ class GCN2(_GraphRunner):
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
         self._step_applied = fused_comm or not multi
+        lr_key = self._lr_key(_lr)
         try:
-            self._run(("grad", batch.uid, denom, _lr if self._step_applied else None), seq)
+            self._run(("grad", batch.uid, denom, lr_key if self._step_applied else None), seq)
         except Exception as e:
             if not fused_comm:
                 raise
@@ -611,6 +631,7 @@ class GCN2(_GraphRunner):
         if multi and not fused_comm and not self._reduced_in_backward:
             self.comm.allreduce_sum(self.flat_g)
         self._last_batch = batch
+        self.ctx.set_lr_source(None)                      # (eager gcnx_sgd calls of other users of this ctx take their argument)
         return batch
 
     def train_step(self, inputs, target=None, lr=0.02, global_batch=None, fetch=True):
@@ -618,7 +639,8 @@ class GCN2(_GraphRunner):
         this rank's shard and ``global_batch`` the number of graphs over all ranks."""
         batch = self.loss_and_grads(inputs, target, global_batch, _lr=float(lr))
         if not self._step_applied:
-            self._run(("sgd", float(lr)), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
+            self._run(("sgd", self._lr_key(float(lr))), lambda: D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), lr))
+            self.ctx.set_lr_source(None)
         if fetch == "stash":
             self.stash_metrics(global_batch or batch.n_graphs)
             return None
@@ -1034,12 +1056,13 @@ class GeneralGNN(_GraphRunner):
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
         self._bind(batch)
         self._step_applied = fused_comm or not multi
+        lr_key = self._lr_key(_lr)
         if multi and not fused_comm:
             seq()                                          # host-mediated collectives inside: not captured
             self.comm.allreduce_sum(self.flat_g)
         else:
             try:
-                self._run(("grad", batch.uid, _lr, denom), seq)
+                self._run(("grad", batch.uid, lr_key, denom), seq)
             except Exception as e:
                 if not fused_comm:
                     raise
@@ -1049,6 +1072,7 @@ class GeneralGNN(_GraphRunner):
                 self._comm_capture_failed = True
                 self._drop_graphs()
                 return self.loss_and_grads(batch, None, _lr, global_batch)
+        self.ctx.set_lr_source(None)
         return batch
 
     def train_step(self, inputs, target=None, lr=0.02, fetch=True, global_batch=None):

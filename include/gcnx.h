@@ -435,6 +435,11 @@ GCNX_API int gcnx_bn_act_bwd_apply(gcnx_ctx* ctx, const float* dy, int64_t lddy,
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);
+/* The learning rate of every update launch (gcnx_sgd, gcnx_gemm_dw_sgd, gcnx_gemm_dw2) read from a device scalar instead
+ * of the `lr` argument (NULL: the argument again).  A learning rate passed by value is part of a captured launch; with a
+ * source the same captured step serves every value of a schedule -- keras.optimizers.schedules.*, gcn.py:321-325 -- and
+ * the host only rewrites 4 bytes (gcnx_h2d_async) when the value changes.  Not callable inside a capture. */
+GCNX_API int gcnx_set_lr_source(gcnx_ctx* ctx, const float* lr_dev);
 /* A reduction that gcnx_dense_bwd_deferred left undone: column-sum partial rows -> cout[cf] and split-K slabs ->
  * out[total], both still in the caller's scratch buffer.  All zeros = nothing pending.  Plain data, no ownership. */
 typedef struct gcnx_pending_reduce {

