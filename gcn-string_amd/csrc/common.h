@@ -55,6 +55,7 @@ struct gcnx_ctx {
   int knob_spmm_conc = 0;    // GCNX_SPMM_CONC=1: the plan path's three launches as concurrent branches
   int knob_spmm_tall_rpc = 8; // GCNX_SPMM_TALL_RPC=32: 32-row chunks for graphs taller than a tile (r2 behaviour; default 8)
   int knob_spmm_sort_win = 0; // GCNX_SPMM_SORT_WIN: degree order inside windows of this many row groups (0: whole graph)
+  int knob_spmm_bal = 1;     // GCNX_SPMM_BAL=0: tile graphs in plain size order (the snake deal of r2); c0 + 1000 * big%: cost model of the balanced deal
   int knob_spmm_cap1 = 0;    // GCNX_SPMM_CAP1: tallest graph of the two-workgroups-per-CU tile tier (-1: the kernel's capacity, 632;
                              // 0, the default since r3: every tile graph on the one-workgroup-per-CU tier -- measured faster at every size)
   int knob_pool_split = 0;   // GCNX_POOL_SPLIT=2..16: row slices per graph of the split global pool (0: the library's choice)

@@ -29,7 +29,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <new>
+#include <queue>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -1636,6 +1638,63 @@ static int launch_hubs(gcnx_ctx* ctx, const RowOrder* od, bool tall_only, const 
 
 extern "C" {
 
+// Balanced deal of the tile graphs (r3).  spmm_duo_kernel deals units statically: round r of (virtual) workgroup v is list
+// position r W + (r odd ? W - 1 - v : v).  Over the plain size-sorted list that snake leaves the busiest workgroup of
+// config 3 with 1.10 x the mean row count (1 599 graphs on 256 workgroups: 6.2 each, and the sizes are not linear in the
+// rank) -- the launch ends when THAT workgroup does.  Here the same positions are filled differently: every workgroup's
+// unit COUNT stays what the snake gives it, the graphs go largest-first to the least-loaded workgroup that still has a
+// free position (LPT), a few exchange passes between the busiest workgroup and the others follow, and each workgroup
+// walks its graphs in descending size (single-buffered tiles first, then the double-buffered ones, so the prefetch chain
+// is not broken).  Cost of a graph = rows (x `big` % for single-buffered tiles) + c0 rows for the index burst.  Results
+// are unchanged (a unit is computed the same way wherever it runs).  Applies when one unit is one graph (upg == 1: enough
+// graphs for 1.5 units per workgroup at <= 8 slabs); other shapes keep a valid, if not balanced, deal.
+static void balance_tile_list(std::vector<int2>& t, int W, int c0, int big_pct, int dbl_cap) {
+  const int n = (int)t.size();
+  if (W <= 1 || n <= W) return;
+  const int R = (n + W - 1) / W;
+  auto pos_of = [&](int v, int r) { return r * W + ((r & 1) ? W - 1 - v : v); };
+  std::vector<int> cap(W, 0);
+  for (int v = 0; v < W; ++v)
+    for (int r = 0; r < R; ++r) cap[v] += pos_of(v, r) < n ? 1 : 0;
+  auto cost = [&](const int2& g) { return (long long)g.y * (g.y > dbl_cap ? big_pct : 100) + 100LL * c0; };
+  std::vector<std::vector<int>> own(W);
+  std::vector<long long> load(W, 0);
+  typedef std::pair<long long, int> Key;                       // (load, workgroup): ties to the lower id -- deterministic
+  std::priority_queue<Key, std::vector<Key>, std::greater<Key>> heap;
+  for (int v = 0; v < W; ++v) heap.push(Key(0, v));
+  for (int i = 0; i < n; ++i) {                                // t is sorted by size, descending
+    const Key k = heap.top(); heap.pop();
+    const int v = k.second;
+    own[v].push_back(i); load[v] += cost(t[i]);
+    if ((int)own[v].size() < cap[v]) heap.push(Key(load[v], v));
+  }
+  for (int pass = 0; pass < 4 * W; ++pass) {                   // exchanges: one graph of the busiest workgroup against a smaller one
+    int vmax = 0;
+    for (int v = 1; v < W; ++v) if (load[v] > load[vmax]) vmax = v;
+    long long best = load[vmax]; int bo = -1, bi = -1, bj = -1;
+    for (int o = 0; o < W; ++o) {
+      if (o == vmax || load[o] >= load[vmax]) continue;
+      for (int i : own[vmax]) for (int j : own[o]) {
+        const long long d = cost(t[i]) - cost(t[j]);
+        if (d <= 0) continue;
+        const long long m = std::max(load[vmax] - d, load[o] + d);
+        if (m < best) { best = m; bo = o; bi = i; bj = j; }
+      }
+    }
+    if (bo < 0) break;
+    const long long d = cost(t[bi]) - cost(t[bj]);
+    *std::find(own[vmax].begin(), own[vmax].end(), bi) = bj;
+    *std::find(own[bo].begin(), own[bo].end(), bj) = bi;
+    load[vmax] -= d; load[bo] += d;
+  }
+  std::vector<int2> out(t.size());
+  for (int v = 0; v < W; ++v) {
+    std::sort(own[v].begin(), own[v].end());                   // list index ascending = size descending
+    for (int r = 0; r < (int)own[v].size(); ++r) out[pos_of(v, r)] = t[own[v][r]];
+  }
+  t.swap(out);
+}
+
 int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nblocks, gcnx_spmm_plan** out) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, out != nullptr, "gcnx_spmm_plan_create: out is NULL");
@@ -1673,6 +1732,11 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     auto by_size = [](const int2& x, const int2& y) { return x.y != y.y ? x.y > y.y : x.x < y.x; };
     std::sort(t1.begin(), t1.end(), by_size);
     std::sort(t2.begin(), t2.end(), by_size);
+    if (ctx->knob_spmm_bal > 0 && 2 * (long long)t2.size() >= 3LL * ctx->num_cus) {
+      const int c0 = ctx->knob_spmm_bal == 1 ? 60 : ctx->knob_spmm_bal % 1000;
+      const int big = ctx->knob_spmm_bal == 1 ? 110 : 100 + ctx->knob_spmm_bal / 1000;
+      balance_tile_list(t2, ctx->num_cus, c0, big, 624);
+    }
     std::vector<int32_t> gids;                     // by_row is sorted by row0 (graphs come in row order): look the records up
     gids.reserve(t1.size() + t2.size());
     for (const std::vector<int2>* tv : {&t1, &t2})

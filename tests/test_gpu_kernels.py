@@ -328,6 +328,40 @@ def test_spmm_full_size_properties(ctx):
     assert rel_err(o1.numpy()[rows], ref) < TIGHT
 
 
+def test_spmm_balanced_deal_of_the_tile_graphs_changes_no_bit(ctx):
+    """The plan's balanced deal (r3, csrc/spmm.hip balance_tile_list; knob spmm_bal): with >= 1.5 tile graphs per CU the
+    graph list is laid out so that the kernel's static snake deal gives every workgroup about the same cost instead of the
+    plain size order.  Only WHERE a unit runs changes: forward aggregation (bias + ReLU), the unweighted operator and the
+    folded pool backward are bit-identical with the deal on and off, and equal the oracle definition."""
+    from gcnx import device as D, synth
+    from gcnx.device import DeviceCSR, Segments
+    hb = synth.block_diag_batch(130_000, 1_000_000, 64, seed=11, mean_size=200, with_x=False)
+    assert hb.n_graphs >= 2 * 256
+    rng = np.random.default_rng(12)
+    f = 64
+    h = rng.standard_normal((hb.n, f), dtype=np.float32); bias = rng.standard_normal(f).astype(np.float32)
+    dp = rng.standard_normal((hb.n_graphs, f), dtype=np.float32)
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    res = {}
+    try:
+        for bal in (0, 1, 30045):
+            ctx.set_tuning("spmm_bal", bal)
+            a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)      # a new plan under this setting
+            assert a.plan is not None
+            o1, o2, o3 = ctx.zeros((hb.n, f)), ctx.zeros((hb.n, f)), ctx.zeros((hb.n, f))
+            D.spmm(ctx, a, ctx.to_device(h), ctx.to_device(bias), o1, act="relu")
+            D.spmm(ctx, a.unweighted(), ctx.to_device(h), None, o2)
+            D.spmm_pool_bwd(ctx, a, ctx.to_device(np.maximum(h, 0)), Segments(ctx, hb.graph_ptr), ctx.to_device(dp), o3, "sum")
+            res[bal] = (o1.numpy(), o2.numpy(), o3.numpy())
+    finally:
+        ctx.set_tuning("spmm_bal", 1)
+    for bal in (1, 30045):
+        for x, y in zip(res[0], res[bal]):
+            assert np.array_equal(x, y)
+    assert rel_err(res[1][0], _ref_spmm(hb, vals, h, bias, relu=True)) < TIGHT
+    assert rel_err(res[1][1], _ref_spmm(hb, None, h)) < TIGHT
+
+
 @pytest.mark.parametrize("n,fi,fo", [(1000, 128, 128), (77, 10, 6), (4096, 256, 256), (333, 32, 2), (65, 130, 70)])
 def test_gemm_forward_parity(ctx, n, fi, fo):
     from gcnx import device as D
