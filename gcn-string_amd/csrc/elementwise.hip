@@ -1,0 +1,105 @@
+// Element-wise pieces of Spektral's GeneralGNN options beside gcn.py:320's defaults (r3):
+//   * Keras Dropout(rate) -- MLP and GeneralConv are Dense -> BatchNormalization -> Dropout -> activation; with the
+//     positively homogeneous activations built here (PReLU, ReLU, linear) act(s u) = s act(u) for the keep / scale factor
+//     s in {0, 1 / (1 - rate)}, so the layer is the fused batch-norm + activation pass followed by one multiply, and its
+//     backward the same multiply on the incoming gradient;
+//   * connectivity = "sum": out = z + out.
+// The keep decision of element i of (layer stream, step) is a stateless hash, so the backward pass regenerates the mask
+// the forward pass used instead of storing it, and a captured step reads the step number from device memory (one
+// captured graph serves every step).  TensorFlow's generator is not reproduced (PARITY UNPINNED: tests hold the
+// arithmetic against the oracle fed with THIS mask, and the keep frequency against 1 - rate).
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {           // murmur3's finaliser
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+// uniform 32 bits for element `idx` of stream (seed, stream_id, step)
+__device__ __forceinline__ uint32_t keep_bits(uint32_t k0, uint32_t k1, uint64_t idx) {
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  return mix32(mix32(lo ^ k0) + (hi * 0x9E3779B9u ^ k1));
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int32_t f, uint32_t thresh,
+                                                      float scale, uint32_t seed, uint32_t stream_id, const uint32_t* __restrict__ step,
+                                                      float* __restrict__ out, int64_t ldo) {
+  const uint32_t st = step ? *step : 0u;
+  const uint32_t k0 = mix32(seed * 0x9E3779B9u + stream_id), k1 = mix32(st * 0x85EBCA6Bu + (seed ^ 0x27D4EB2Fu));
+  const int64_t total = n * (int64_t)f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / f;
+    const int c = (int)(i - r * f);
+    const bool keep = keep_bits(k0, k1, (uint64_t)i) >= thresh;
+    out[r * ldo + c] = keep ? x[r * ldx + c] * scale : 0.f;
+  }
+}
+
+__global__ void counter_add_kernel(uint32_t* c, uint32_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                  float* __restrict__ out, int64_t ldo, int64_t n, int32_t f) {
+  const int64_t total = n * (int64_t)f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / f;
+    const int c = (int)(i - r * f);
+    out[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+  }
+}
+
+int grid_for(gcnx_ctx* ctx, int64_t total) {
+  int64_t g = (total + 255) / 256;
+  const int64_t cap = 16LL * ctx->num_cus;
+  if (g > cap) g = cap;
+  return (int)(g > 0 ? g : 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcnx_dropout(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float rate, uint32_t seed, uint32_t stream_id,
+                 const uint32_t* step, float* out, int64_t ldo) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "dropout");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_dropout: negative size");
+  GCNX_REQUIRE(ctx, rate >= 0.f && rate < 1.f, "gcnx_dropout: rate %g outside [0, 1)", (double)rate);
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, x && out, "gcnx_dropout: NULL pointer");
+  GCNX_REQUIRE(ctx, ldx >= f && ldo >= f, "gcnx_dropout: leading dimension too small");
+  // keep iff bits >= thresh, thresh = rate * 2^32 (rate 0 keeps everything and scales by 1)
+  const double t = (double)rate * 4294967296.0;
+  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(ctx, n * (int64_t)f)), dim3(256), 0, ctx->stream, x, ldx, n, f, thresh,
+                     1.0f / (1.0f - rate), seed, stream_id, step, out, ldo);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_counter_add(gcnx_ctx* ctx, uint32_t* counter, uint32_t inc) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_REQUIRE(ctx, counter != nullptr, "gcnx_counter_add: NULL pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ctx->stream, counter, inc);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_add(gcnx_ctx* ctx, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t n, int32_t f) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "skip connection (sum)");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_add: negative size");
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, a && b && out, "gcnx_add: NULL pointer");
+  GCNX_REQUIRE(ctx, lda >= f && ldb >= f && ldo >= f, "gcnx_add: leading dimension too small");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(ctx, n * (int64_t)f)), dim3(256), 0, ctx->stream, a, lda, b, ldb, out, ldo, n, f);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+}  // extern "C"

@@ -934,3 +934,27 @@ def bn_act_bwd_apply(ctx, dy, z, mean, inv, gamma, beta, sums, count, dz, act=No
     ctx._ck(ctx.lib.gcnx_bn_act_bwd_apply(ctx.h, _p(dy), dy.ld, _p(z), z.ld, n, f, _p(mean), _p(inv), _p(gamma), _p(beta),
                                           L.ACTS[act], _p(alpha), _p(sums), float(count), 1 if training else 0, _p(dz), dz.ld))
     return dz
+
+
+def dropout(ctx, x, rate, seed, stream_id, step=None, out=None):
+    """Keras Dropout(rate), training mode (gcnx_dropout): out = x * keep / (1 - rate); the same call on the incoming gradient
+    is the backward pass (the mask is a stateless hash of (seed, stream_id, step, element)).  In place by default."""
+    out = x if out is None else out
+    n, f = x.shape
+    assert out.shape == (n, f)
+    ctx._ck(ctx.lib.gcnx_dropout(ctx.h, _p(x), x.ld, n, f, float(rate), int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF, _p(step),
+                                 _p(out), out.ld))
+    return out
+
+
+def counter_add(ctx, counter, inc=1):
+    """*counter += inc on the stream (a uint32 device scalar: the optimizer's step count)."""
+    ctx._ck(ctx.lib.gcnx_counter_add(ctx.h, _p(counter), int(inc)))
+
+
+def add(ctx, a, b, out):
+    """out = a + b (GeneralGNN(connectivity="sum"))."""
+    n, f = a.shape
+    assert b.shape == (n, f) and out.shape == (n, f)
+    ctx._ck(ctx.lib.gcnx_add(ctx.h, _p(a), a.ld, _p(b), b.ld, _p(out), out.ld, n, f))
+    return out

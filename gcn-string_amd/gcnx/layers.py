@@ -35,6 +35,7 @@ class Layer:
         self.built = False
         self.params, self.grads = {}, {}
         self._rng = np.random.default_rng(seed)
+        self._seed = 0 if seed is None else int(seed)    # of the layer's Dropout streams
         self._scratch = {}
 
     # parameter spec: list of (name, shape, initial host array)
@@ -191,13 +192,15 @@ class GeneralConv(Layer):
         if aggregate not in ("sum", "mean"):
             raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): 'sum' (what gcn.py:320 uses) and 'mean' are built")
         self.aggregate = aggregate
-        if dropout:
-            raise NotImplementedError("GeneralConv(dropout > 0) is not built (the reference trains with 0.0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"GeneralConv(dropout={dropout!r}): a rate in [0, 1)")
         if activation not in (None, "linear", "relu", "prelu"):
             raise NotImplementedError(f"GeneralConv activation {activation!r}")
-        if activation == "prelu" and not batch_norm:
-            raise NotImplementedError("GeneralConv(batch_norm=False, activation='prelu') is not built (PReLU is fused with BN)")
         self.channels, self.batch_norm, self.activation, self.use_bias, self.prec = int(channels), bool(batch_norm), activation, use_bias, prec
+        # Dropout(rate) between BatchNormalization and the activation (8.A.4), training only: applied as its factor on the
+        # activation's output (act(s u) = s act(u) for PReLU / ReLU / linear) and on the incoming gradient; the mask of call
+        # number t is a stateless hash of (seed, t) -- this library's generator, not TensorFlow's
+        self.dropout, self._drop_calls = float(dropout), 0
         self.state = {}
 
     def _param_spec(self, in_dim):
@@ -217,6 +220,11 @@ class GeneralConv(Layer):
             c = self.channels
             self.state = {"moving_mean": ctx.zeros(c), "moving_var": ctx.to_device(np.ones(c, np.float32))}
             self._mean, self._inv, self._sums, self._bn_scratch = ctx.zeros(c), ctx.zeros(c), ctx.zeros(2 * c), ctx.zeros(3 * c)
+        elif self.activation == "prelu":
+            # PReLU without BatchNormalization: the fused batch-norm + activation pass with the identity transform
+            c = self.channels
+            self._mean, self._inv, self._bn_scratch = ctx.zeros(c), ctx.to_device(np.ones(c, np.float32)), ctx.zeros(3 * c)
+            self._dummy = (ctx.zeros(c), ctx.zeros(c))
         return off
 
     def get_weights(self):
@@ -232,9 +240,12 @@ class GeneralConv(Layer):
             self.build(x.ctx, x.shape[1])
         ctx, n, c = self.ctx, x.shape[0], self.channels
         z, h = self._buf("z", (n, c)), self._buf("h", (n, c))
+        ident = not self.batch_norm and self.activation == "prelu"
         D.gemm(ctx, x, self.params["kernel"], self.params.get("bias"), z, prec=self.prec,
-               act=None if self.batch_norm else self.activation, alpha=None if self.batch_norm else self.params.get("alpha"))
-        if self.batch_norm:
+               act=None if (self.batch_norm or ident) else self.activation)
+        if ident:
+            D.bn_act(ctx, z, self._mean, self._inv, self._inv, self._mean, h, act="prelu", alpha=self.params["alpha"])
+        elif self.batch_norm:
             if training:
                 D.bn_moments(ctx, z, self._sums, self._mean, self._inv, self.state["moving_mean"], self.state["moving_var"])
             else:
@@ -243,18 +254,29 @@ class GeneralConv(Layer):
                      alpha=self.params.get("alpha"))
         else:
             h = z
+        drop_id = None
+        if training and self.dropout > 0.0:
+            drop_id = self._drop_calls = self._drop_calls + 1
+            D.dropout(ctx, h, self.dropout, self._seed, drop_id)
         y = out if out is not None else self._buf("y", (n, c))
         au = a.unweighted() if self.aggregate == "sum" else a.row_mean()   # values ignored (8.A.4); "mean": 1 / row length
         D.spmm(ctx, au, h, None, y)
-        self._saved = (x, au, z, h, bool(training))
+        self._saved = (x, au, z, h, bool(training), drop_id)
         return y
 
     def backward(self, dy, need_dx=True):
-        x, au, z, h, training = self._saved
+        x, au, z, h, training, drop_id = self._saved
         ctx = self.ctx
         dh = self._buf("dh", dy.shape)
         D.spmm(ctx, au.transpose(), dy, None, dh)            # dH = S^T dY
-        if self.batch_norm:
+        if drop_id is not None:
+            D.dropout(ctx, dh, self.dropout, self._seed, drop_id)
+        if not self.batch_norm and self.activation == "prelu":
+            D.bn_act_bwd(ctx, dh, z, self._mean, self._inv, self._inv, self._mean, dh, self._bn_scratch, act="prelu",
+                         alpha=self.params["alpha"], training=False, dgamma=self._dummy[0], dbeta=self._dummy[1],
+                         dalpha=self.grads["alpha"])
+            D.act_bias_grad(ctx, dh, None, dh, None, db=self.grads.get("bias"))
+        elif self.batch_norm:
             D.bn_act_bwd(ctx, dh, z, self._mean, self._inv, self.params["gamma"], self.params["beta"], dh, self._bn_scratch,
                          act=self.activation, alpha=self.params.get("alpha"), training=training,
                          dgamma=self.grads["gamma"], dbeta=self.grads["beta"], dalpha=self.grads.get("alpha"))

@@ -693,11 +693,22 @@ class GeneralGNN(_GraphRunner):
         self.use_graph, self._graphs = use_graph, {}
         self.cce_train, self.cce_eval = cce_train, cce_eval     # see GCN2.__init__
         self.comm = comm                                  # gcnx.comm.Communicator: sync-BN + gradient all-reduce
-        unsupported = {"connectivity": (connectivity, "cat"), "batch_norm": (batch_norm, True), "dropout": (dropout, 0.0),
-                       "hidden_activation": (hidden_activation, "prelu"), "activation": (activation, "softmax")}
-        for k, (got, want) in unsupported.items():
-            if got != want:
-                raise NotImplementedError(f"GeneralGNN({k}={got!r}): only {want!r} (what gcn.py:320 uses) is built")
+        if activation != "softmax":
+            raise NotImplementedError(f"GeneralGNN(activation={activation!r}): only 'softmax' (what gcn.py:320 uses) is built")
+        # Spektral's other options that map onto kernels that exist (r3; PARITY UNPINNED like the rest, the
+        # oracle's restatement of them is checked against torch autograd): connectivity "sum" (out = z + out), batch_norm False
+        # (no BatchNormalization layers), hidden_activation "relu" / None, dropout > 0 (the Dropout layer between
+        # BatchNormalization and the activation of every MLP / GeneralConv layer; training only; this library's own generator)
+        if connectivity not in ("cat", "sum"):
+            raise NotImplementedError(f"GeneralGNN(connectivity={connectivity!r}): 'cat' (gcn.py:320) and 'sum' are built")
+        if hidden_activation == "linear":
+            hidden_activation = None
+        if hidden_activation not in ("prelu", "relu", None):
+            raise NotImplementedError(f"GeneralGNN(hidden_activation={hidden_activation!r}): 'prelu' (gcn.py:320), 'relu' and None are built")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"GeneralGNN(dropout={dropout!r}): a rate in [0, 1)")
+        self.connectivity, self.batch_norm, self.dropout = connectivity, bool(batch_norm), float(dropout)
+        self.hidden_activation, self.seed = hidden_activation, int(seed)
         # Spektral's other aggregations / pools that map onto kernels that exist (r3): aggregate "mean" is the same gather with
         # the weight 1 / (entries of the row) per entry, pool "avg" / "max" are modes of the segment pool and its backward
         if aggregate not in ("sum", "mean"):
@@ -719,36 +730,46 @@ class GeneralGNN(_GraphRunner):
         w = f_in
         for _ in range(self.n_pre):
             dims.append(("pre", w, h, True)); w = h
+        cat, bn, prelu = self.connectivity == "cat", self.batch_norm, self.hidden_activation == "prelu"
         for k in range(mp):
-            dims.append(("gnn", h * (k + 1), h, True))
-        w = h * (mp + 1)
+            dims.append(("gnn", h * (k + 1) if cat else h, h, True))
+        w = self._wpool = h * (mp + 1) if cat else h
         for k in range(self.n_post):
             last = k == self.n_post - 1
             dims.append(("post", w, self.output if last else h, not last)); w = h
-        n_train = sum(fi * fo + 3 * fo + (fo if pr else 0) for _, fi, fo, pr in dims)
-        n_state = sum(2 * fo for _, _, fo, _ in dims)
+        n_train = sum(fi * fo + fo + (2 * fo if bn else 0) + (fo if pr and prelu else 0) for _, fi, fo, pr in dims)
+        n_state = sum(2 * fo for _, _, fo, _ in dims) if bn else 0
         self.n_params = n_train
         ctx = self.ctx
         self.flat_p, self.flat_g = ctx.zeros(n_train), ctx.zeros(n_train + 2)
-        self.flat_s = ctx.zeros(n_state)                  # moving_mean | moving_var per layer
+        self.flat_s = ctx.zeros(max(n_state, 1))          # moving_mean | moving_var per layer
         self.loss_acc = self.flat_g.flat(n_train, 2)
         self.layers = []
+        self._step_dev = ctx.zeros(1, np.int32)           # the optimizer's step count on the device (Dropout streams)
         off = soff = 0
         for grp, fi, fo, pr in dims:
-            L = {"group": grp, "fi": fi, "fo": fo, "act": "prelu" if pr else None}
-            for name, shape in (("kernel", (fi, fo)), ("bias", (fo,)), ("gamma", (fo,)), ("beta", (fo,))) + \
-                    ((("alpha", (fo,)),) if pr else ()):
+            L = {"group": grp, "fi": fi, "fo": fo, "act": self.hidden_activation if pr else None}
+            for name, shape in (("kernel", (fi, fo)), ("bias", (fo,))) + ((("gamma", (fo,)), ("beta", (fo,))) if bn else ()) + \
+                    ((("alpha", (fo,)),) if pr and prelu else ()):
                 n = int(np.prod(shape))
                 L[name] = self.flat_p.flat(off, n, shape)
                 L["g_" + name] = self.flat_g.flat(off, n, shape)
                 off += n
-            L["moving_mean"] = self.flat_s.flat(soff, fo); L["moving_var"] = self.flat_s.flat(soff + fo, fo); soff += 2 * fo
-            L["mean"], L["inv"] = ctx.zeros(fo), ctx.zeros(fo)
             L["sums"], L["scratch"] = ctx.zeros(2 * fo), ctx.zeros(3 * fo)
             from .layers import glorot_uniform
             L["kernel"].copy_from_host(glorot_uniform(self._rng, fi, fo))
-            L["gamma"].copy_from_host(np.ones(fo, np.float32))
-            L["moving_var"].copy_from_host(np.ones(fo, np.float32))
+            if bn:
+                L["moving_mean"] = self.flat_s.flat(soff, fo); L["moving_var"] = self.flat_s.flat(soff + fo, fo); soff += 2 * fo
+                L["mean"], L["inv"] = ctx.zeros(fo), ctx.zeros(fo)
+                L["gamma"].copy_from_host(np.ones(fo, np.float32))
+                L["moving_var"].copy_from_host(np.ones(fo, np.float32))
+                L["bn_gamma"], L["bn_beta"], L["bn_g_gamma"], L["bn_g_beta"] = L["gamma"], L["beta"], L["g_gamma"], L["g_beta"]
+            else:
+                # batch_norm=False: the fused batch-norm + activation passes run with the identity transform (mean 0, 1 / sigma 1,
+                # gamma 1, beta 0, inference-mode backward): exactly act(z) and dy * act'(z); nothing of it is a parameter
+                L["mean"], L["inv"] = ctx.zeros(fo), ctx.to_device(np.ones(fo, np.float32))
+                L["bn_gamma"], L["bn_beta"] = L["inv"], L["mean"]
+                L["bn_g_gamma"], L["bn_g_beta"] = ctx.zeros(fo), ctx.zeros(fo)
             self.layers.append(L)
         self.f_in, self.built = f_in, True
         self._alloc_images()
@@ -823,8 +844,9 @@ class GeneralGNN(_GraphRunner):
         if getattr(self, "_cap", None) is None:
             self._cap = _Capacity(ctx)
         v = self._cap.view
+        wp = self._wpool
         bufs = {"key": key, "cat": v("cat", n, wcat), "dcat": v("dcat", n, wcat), "h": v("h", n, h), "dh": v("dh", n, h),
-                "pooled": v("pooled", b, wcat), "dpooled": v("dpooled", b, wcat), "probs": v("probs", b, self.output),
+                "pooled": v("pooled", b, wp), "dpooled": v("dpooled", b, wp), "probs": v("probs", b, self.output),
                 "dlogits": v("dlogits", b, self.output), "zy": v("zy", b, self.output, zero=True)}
         for i, L in enumerate(self.layers):
             rows = b if L["group"] == "post" else n
@@ -836,8 +858,25 @@ class GeneralGNN(_GraphRunner):
     def _multi(self):
         return self.comm is not None and self.comm.world_size > 1
 
+    def _drop(self, L, t):
+        """The layer's Dropout factor applied to t in place (forward: the activation's output -- act(s u) = s act(u) for the
+        activations built; backward: the incoming gradient).  Stream = the layer's index, step = the device step count."""
+        seed = self.seed + (0x9E37 * self.comm.rank if self._multi() else 0)
+        D.dropout(self.ctx, t, self.dropout, seed, self.layers.index(L), self._step_dev)
+
     def _dense_bn(self, L, x, z, y, training):
+        self._dense_bn_core(L, x, z, y, training)
+        if training and self.dropout > 0.0:
+            self._drop(L, y)
+
+    def _dense_bn_core(self, L, x, z, y, training):
         ctx = self.ctx
+        if not self.batch_norm:
+            if not ("img_fwd" in L and self._images_fresh and
+                    D.gemm_wimage(ctx, x, L["img_fwd"], L["fi"], L["fo"], z, bias=L["bias"], prec=self.prec) is not None):
+                D.gemm(ctx, x, L["kernel"], L["bias"], z, prec=self._prec_of(L))
+            D.bn_act(ctx, z, L["mean"], L["inv"], L["bn_gamma"], L["bn_beta"], y, act=L["act"], alpha=L.get("alpha"))
+            return
         if "img_fwd" in L and self._images_fresh:
             # split-bf16 panel GEMM (csrc/gemm_panel.hip); in single-device training its epilogue also leaves the batch-norm
             # statistics of what it writes, as (rows, mean, M2) per workgroup: no pass over z for the moments
@@ -884,17 +923,22 @@ class GeneralGNN(_GraphRunner):
             y = cat.cols(mp * h, (mp + 1) * h) if k == self.n_pre - 1 else bufs[f"y{li}"]
             self._dense_bn(L, x, bufs[f"z{li}"], y, training)
             x = y; li += 1
+        sumc = self.connectivity == "sum"          # "sum": slice (mp - k) of `cat` holds out_k = z_k + out_(k-1) instead of z_k
         for k in range(mp):
             L = self.layers[li]
-            inp = cat.cols((mp - k) * h, (mp + 1) * h)
+            inp = cat.cols((mp - k) * h, (mp - k + 1) * h if sumc else (mp + 1) * h)
             self._dense_bn(L, inp, bufs[f"z{li}"], bufs["h"], training)
-            D.spmm(self.ctx, a, bufs["h"], None, cat.cols((mp - k - 1) * h, (mp - k) * h))
+            new = cat.cols((mp - k - 1) * h, (mp - k) * h)
+            D.spmm(self.ctx, a, bufs["h"], None, new)
+            if sumc:
+                D.add(self.ctx, new, inp, new)
             li += 1
         if self.pool == "max":
             if getattr(self, "_cap", None) is None:
                 self._cap = _Capacity(self.ctx)
             bufs["pool_arg"] = self._cap.view("pool_arg", bufs["pooled"].shape[0], bufs["pooled"].shape[1], np.int32)
-        D.segment_pool(self.ctx, batch.seg, cat, bufs["pooled"], self.pool, bufs.get("pool_arg") if self.pool == "max" else None)
+        D.segment_pool(self.ctx, batch.seg, cat.cols(0, h) if sumc else cat, bufs["pooled"], self.pool,
+                       bufs.get("pool_arg") if self.pool == "max" else None)
         x = bufs["pooled"]
         for k in range(self.n_post):
             L = self.layers[li]
@@ -905,7 +949,14 @@ class GeneralGNN(_GraphRunner):
     def _bwd_dense_bn(self, L, dy, x, z, dx, training, accumulate=False):
         ctx = self.ctx
         dz = dy                                            # in place
-        if training and self._multi():
+        if training and self.dropout > 0.0:
+            self._drop(L, dy)                              # Dropout backward: the forward's factor on the incoming gradient
+        bn = self.batch_norm
+        if not bn:
+            D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["bn_gamma"], L["bn_beta"], dz, L["scratch"], act=L["act"],
+                         alpha=L.get("alpha"), training=False, dgamma=L["bn_g_gamma"], dbeta=L["bn_g_beta"],
+                         dalpha=L.get("g_alpha"))
+        elif training and self._multi():
             # local column sums -> parameter gradients (summed over ranks by the final all-reduce with the rest);
             # the same sums, all-reduced, and the global row count give dz
             count = self._counts["b" if L["group"] == "post" else "n"]
@@ -918,7 +969,7 @@ class GeneralGNN(_GraphRunner):
             D.bn_act_bwd(ctx, dy, z, L["mean"], L["inv"], L["gamma"], L["beta"], dz, L["scratch"], act=L["act"],
                          alpha=L.get("alpha"), training=training, dgamma=L["g_gamma"], dbeta=L["g_beta"],
                          dalpha=L.get("g_alpha"))
-        if training:
+        if training and bn:
             # The Dense bias under a training-mode BatchNorm has the gradient sum_rows dz = gamma inv (sum g - n mean(g) -
             # mean(g xhat) sum xhat) = 0 identically (sum xhat = 0; with sync-BN the sums are the global ones): TensorFlow
             # evaluates that sum and returns rounding noise of order 1e-8; every training path here writes the exact value
@@ -958,13 +1009,21 @@ class GeneralGNN(_GraphRunner):
                 dx = self._tmp(bufs, f"dy{li - 1}", x.shape)
             self._bwd_dense_bn(L, d, x, bufs[f"z{li}"], dx, training)
             d = dx; li -= 1
-        D.segment_pool_bwd(self.ctx, batch.seg, bufs["dpooled"], dcat, self.pool, bufs.get("pool_arg") if self.pool == "max" else None)
+        sumc = self.connectivity == "sum"
+        D.segment_pool_bwd(self.ctx, batch.seg, bufs["dpooled"], dcat.cols(0, h) if sumc else dcat, self.pool,
+                           bufs.get("pool_arg") if self.pool == "max" else None)
         for k in reversed(range(mp)):
             L = self.layers[li]
-            D.spmm(self.ctx, at, dcat.cols((mp - k - 1) * h, (mp - k) * h), None, bufs["dh"])
-            inp = cat.cols((mp - k) * h, (mp + 1) * h)
-            self._bwd_dense_bn(L, bufs["dh"], inp, bufs[f"z{li}"], dcat.cols((mp - k) * h, (mp + 1) * h), training,
-                               accumulate=True)
+            dout = dcat.cols((mp - k - 1) * h, (mp - k) * h)
+            D.spmm(self.ctx, at, dout, None, bufs["dh"])
+            if sumc:                                       # d out_(k-1) = d out_k (the skip) + dz W^T
+                inp, din = cat.cols((mp - k) * h, (mp - k + 1) * h), dcat.cols((mp - k) * h, (mp - k + 1) * h)
+                self._bwd_dense_bn(L, bufs["dh"], inp, bufs[f"z{li}"], din, training)
+                D.add(self.ctx, din, dout, din)
+            else:
+                inp = cat.cols((mp - k) * h, (mp + 1) * h)
+                self._bwd_dense_bn(L, bufs["dh"], inp, bufs[f"z{li}"], dcat.cols((mp - k) * h, (mp + 1) * h), training,
+                                   accumulate=True)
             li -= 1
         d = dcat.cols(mp * h, (mp + 1) * h)
         for k in reversed(range(self.n_pre)):
@@ -1054,6 +1113,8 @@ class GeneralGNN(_GraphRunner):
                 self.comm.allreduce_sum(self.flat_g)
             if _lr is not None and (fused_comm or not multi):   # the update rides in the same captured graph
                 D.sgd(self.ctx, self.flat_p, self.flat_g.flat(0, self.n_params), _lr)
+            if self.dropout > 0.0:
+                D.counter_add(self.ctx, self._step_dev, 1)     # the next step draws new Dropout masks (also from a replayed graph)
         self._bind(batch)
         self._step_applied = fused_comm or not multi
         lr_key = self._lr_key(_lr)

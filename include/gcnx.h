@@ -432,6 +432,21 @@ GCNX_API int gcnx_bn_act_bwd_apply(gcnx_ctx* ctx, const float* dy, int64_t lddy,
                           int32_t f, const float* mean, const float* inv, const float* gamma, const float* beta, int act,
                           const float* alpha, const float* sums, float count, int training, float* dz, int64_t lddz);
 
+/* ---- GeneralGNN options beside gcn.py:320's defaults (csrc/elementwise.hip) ------------------ */
+/* Keras Dropout(rate) in training mode (the Dropout layer of Spektral's MLP and GeneralConv):
+ * out = x * keep / (1 - rate), keep ~ Bernoulli(1 - rate) per element.  The keep decision of element (row, col) is a
+ * stateless hash of (seed, stream_id, *step, row * f + col) -- step may be NULL (0) -- so calling it again with the same
+ * arguments on the incoming gradient IS the layer's backward pass (no stored mask), and a captured step that reads `step`
+ * from device memory draws a fresh mask on every replay (gcnx_counter_add advances it).  TensorFlow's random generator
+ * is not reproduced.  out may alias x. */
+GCNX_API int gcnx_dropout(gcnx_ctx* ctx, const float* x, int64_t ldx, int64_t n, int32_t f, float rate, uint32_t seed,
+                          uint32_t stream_id, const uint32_t* step, float* out, int64_t ldo);
+/* *counter += inc on the stream (the optimizer's step count: optimizer.iterations, gcn.py:338). */
+GCNX_API int gcnx_counter_add(gcnx_ctx* ctx, uint32_t* counter, uint32_t inc);
+/* out = a + b, row by row (GeneralGNN(connectivity="sum"): out = z + out).  out may alias a or b. */
+GCNX_API int gcnx_add(gcnx_ctx* ctx, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                      int64_t n, int32_t f);
+
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);

@@ -459,17 +459,26 @@ def bn_bwd(dy, cache, gamma, count=None, red=None):
     return dx, dgamma_local, dbeta_local
 
 
-def dense_bn_act_fwd(x, p, training, act, final_softmax=False):
-    """One MLP layer / the dense half of GeneralConv: Dense -> BN -> Dropout(0) -> act."""
+def dense_bn_act_fwd(x, p, training, act, final_softmax=False, drop=None):
+    """One MLP layer / the dense half of GeneralConv: Dense -> BN -> Dropout -> act (A.3: MLP is, per layer,
+    Dense -> BatchNormalization -> Dropout(rate) -> PReLU | Activation(final); GeneralConv.call the same chain, A.4).
+    A layer without "gamma" has no BatchNormalization (batch_norm=False).  ``drop`` = the Dropout layer's factor per
+    element, keep / (1 - rate) (training only; None = Dropout(0) or inference): it multiplies the activation's input, and
+    cache["zb"] holds that input (for the last layer: the logits the loss takes)."""
     z = x @ p["kernel"] + p["bias"]
-    zb, bnc, mm, mv = bn_fwd(z, p["gamma"], p["beta"], p["moving_mean"], p["moving_var"], training)
+    if "gamma" in p:
+        zb, bnc, mm, mv = bn_fwd(z, p["gamma"], p["beta"], p["moving_mean"], p["moving_var"], training)
+    else:
+        zb, bnc, mm, mv = z, None, None, None
+    if drop is not None:
+        zb = zb * drop
     if final_softmax:
         y = softmax(zb)                                  # zb = the Softmax op's input (the logits Keras' loss takes)
     elif act == "prelu":
         y = act_fwd(zb, "prelu", p["alpha"])
     else:
         y = act_fwd(zb, act)
-    return y, {"x": x, "zb": zb, "bn": bnc, "y": y}, mm, mv
+    return y, {"x": x, "zb": zb, "bn": bnc, "y": y, "drop": drop}, mm, mv
 
 
 def dense_bn_act_bwd(dy, cache, p, act, need_dx=True, dzb=None):
@@ -483,37 +492,45 @@ def dense_bn_act_bwd(dy, cache, p, act, need_dx=True, dzb=None):
             dzb = act_bwd(dy, zb, "prelu", p["alpha"])
         else:
             dzb = act_bwd(dy, zb, act)
-    dz, g["gamma"], g["beta"] = bn_bwd(dzb, cache["bn"], p["gamma"])
+    if cache.get("drop") is not None:
+        dzb = dzb * cache["drop"]                        # Dropout backward: the same factor
+    if cache["bn"] is not None:
+        dz, g["gamma"], g["beta"] = bn_bwd(dzb, cache["bn"], p["gamma"])
+    else:
+        dz = dzb
     g["kernel"] = cache["x"].T @ dz
     g["bias"] = dz.sum(0)
     dx = dz @ p["kernel"].T if need_dx else None
     return dx, g
 
 
-def layer_init(rng, fan_in, fan_out, prelu=True, dtype=np.float64):
-    p = {
-        "kernel": glorot_uniform(rng, fan_in, fan_out, dtype), "bias": np.zeros(fan_out, dtype),
-        "gamma": np.ones(fan_out, dtype), "beta": np.zeros(fan_out, dtype),
-        "moving_mean": np.zeros(fan_out, dtype), "moving_var": np.ones(fan_out, dtype),
-    }
+def layer_init(rng, fan_in, fan_out, prelu=True, dtype=np.float64, batch_norm=True):
+    p = {"kernel": glorot_uniform(rng, fan_in, fan_out, dtype), "bias": np.zeros(fan_out, dtype)}
+    if batch_norm:
+        p.update({"gamma": np.ones(fan_out, dtype), "beta": np.zeros(fan_out, dtype),
+                  "moving_mean": np.zeros(fan_out, dtype), "moving_var": np.ones(fan_out, dtype)})
     if prelu:
         p["alpha"] = np.zeros(fan_out, dtype)
     return p
 
 
-def general_gnn_init(rng, f_in, n_out, hidden=256, message_passing=4, pre=2, post=2, dtype=np.float64):
+def general_gnn_init(rng, f_in, n_out, hidden=256, message_passing=4, pre=2, post=2, dtype=np.float64, connectivity="cat",
+                     batch_norm=True, hidden_activation="prelu"):
     """GeneralGNN(output, hidden=256, message_passing=4, pre_process=2, post_process=2,
     connectivity='cat', batch_norm=True, aggregate='sum', hidden_activation='prelu',
-    pool='sum')  -- defaults of gcn.py:320 (A.3)."""
+    pool='sum')  -- defaults of gcn.py:320 (A.3).  Options (r3): connectivity "sum" (out = z + out: every GeneralConv sees
+    `hidden` inputs), batch_norm False (no BatchNormalization layers), hidden_activation "relu" / None (no alpha)."""
     layers = {"pre": [], "gnn": [], "post": []}
+    prelu = hidden_activation == "prelu"
     w = f_in
     for _ in range(pre):
-        layers["pre"].append(layer_init(rng, w, hidden, True, dtype)); w = hidden
+        layers["pre"].append(layer_init(rng, w, hidden, prelu, dtype, batch_norm)); w = hidden
     for _ in range(message_passing):
-        layers["gnn"].append(layer_init(rng, w, hidden, True, dtype)); w = w + hidden  # cat
+        layers["gnn"].append(layer_init(rng, w, hidden, prelu, dtype, batch_norm))
+        w = w + hidden if connectivity == "cat" else hidden
     for k in range(post):
         last = k == post - 1
-        layers["post"].append(layer_init(rng, w, n_out if last else hidden, not last, dtype))
+        layers["post"].append(layer_init(rng, w, n_out if last else hidden, prelu and not last, dtype, batch_norm))
         w = hidden
     return layers
 
@@ -529,40 +546,48 @@ def aggregate_vals(rowptr, aggregate, dtype=np.float64):
     return np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(dtype), np.diff(np.asarray(rowptr)))
 
 
-def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="softmax", aggregate="sum", pool="sum"):
+def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="softmax", aggregate="sum", pool="sum",
+                        connectivity="cat", hidden_activation="prelu", drops=None):
     """A.3: pre-MLP -> 4x [z=GeneralConv(out); out=concat([z,out])] -> global pool -> post-MLP.
     GeneralConv (A.4): h = PReLU(BN(x W + b)); out[t] = sum (or mean) over {(t,s) in a.indices} of h[s]
     (values unused, no self-loop added, no normalisation).  pool: "sum" (gcn.py:320's default), "avg", "max".
+    connectivity "sum": out = z + out.  hidden_activation: "prelu" | "relu" | None.  drops: the Dropout layers' factors
+    (keep / (1 - rate), one array per layer, {"pre": [...], "gnn": [...], "post": [...]}; training only).
     Returns probs, caches, list of (moving_mean, moving_var) updates in layer order."""
     rowptr, colidx, _ = csr
     agg = aggregate_vals(rowptr, aggregate, x.dtype)
     caches = {"pre": [], "gnn": [], "post": []}
     stats = []
+    act = hidden_activation
+    drop = (lambda grp, k: drops[grp][k]) if (drops is not None and training) else (lambda grp, k: None)
     out = x
-    for p in layers["pre"]:
-        out, c, mm, mv = dense_bn_act_fwd(out, p, training, "prelu"); caches["pre"].append(c); stats.append((mm, mv))
-    for p in layers["gnn"]:
-        h, c, mm, mv = dense_bn_act_fwd(out, p, training, "prelu"); stats.append((mm, mv))
+    for k, p in enumerate(layers["pre"]):
+        out, c, mm, mv = dense_bn_act_fwd(out, p, training, act, drop=drop("pre", k)); caches["pre"].append(c); stats.append((mm, mv))
+    for k, p in enumerate(layers["gnn"]):
+        h, c, mm, mv = dense_bn_act_fwd(out, p, training, act, drop=drop("gnn", k)); stats.append((mm, mv))
         z = spmm_csr(rowptr, colidx, agg, h)
         c["width_in"] = out.shape[1]
         caches["gnn"].append(c)
-        out = np.concatenate([z, out], axis=1)
+        out = np.concatenate([z, out], axis=1) if connectivity == "cat" else z + out
     pooled, caches["pool_arg"] = global_pool_fwd(out, graph_ptr, pool)
     caches["pooled_in_width"] = out.shape[1]
     out = pooled
     n_post = len(layers["post"])
     for k, p in enumerate(layers["post"]):
         last = k == n_post - 1
-        out, c, mm, mv = dense_bn_act_fwd(out, p, training, "prelu" if not last else None,
-                                          final_softmax=last and final_activation == "softmax")
+        out, c, mm, mv = dense_bn_act_fwd(out, p, training, act if not last else None,
+                                          final_softmax=last and final_activation == "softmax", drop=drop("post", k))
         caches["post"].append(c); stats.append((mm, mv))
     return out, caches, stats
 
 
-def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits", aggregate="sum", pool="sum"):
+def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits", aggregate="sum", pool="sum",
+                               connectivity="cat", hidden_activation="prelu", drops=None):
     rowptr, colidx, _ = csr
     agg = aggregate_vals(rowptr, aggregate, x.dtype)
-    probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True, aggregate=aggregate, pool=pool)
+    act = hidden_activation
+    probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True, aggregate=aggregate, pool=pool,
+                                               connectivity=connectivity, hidden_activation=hidden_activation, drops=drops)
     yf = y.astype(probs.dtype)
     loss, dlogits = cce(yf, caches["post"][-1]["zb"], probs, None, cce_mode)
     acc = categorical_accuracy(yf, probs)
@@ -575,19 +600,19 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
         if k == n_post - 1:
             d, grads["post"][k] = dense_bn_act_bwd(None, c, p, None, True, dzb=dlogits)
         else:
-            d, grads["post"][k] = dense_bn_act_bwd(d, c, p, "prelu", True)
+            d, grads["post"][k] = dense_bn_act_bwd(d, c, p, act, True)
     d = global_pool_bwd(d, graph_ptr, x.shape[0], pool, caches["pool_arg"])
     for k in reversed(range(len(layers["gnn"]))):
         p, c = layers["gnn"][k], caches["gnn"][k]
         hid = p["kernel"].shape[1]
-        dz, dskip = d[:, :hid], d[:, hid:]
+        dz, dskip = (d[:, :hid], d[:, hid:]) if connectivity == "cat" else (d, d)
         if csr_t is not None and agg is None:
             dh = spmm_csr(csr_t[0], csr_t[1], None, dz)
         else:
             dh = spmm_csr_T(rowptr, colidx, agg, dz)
-        dx, grads["gnn"][k] = dense_bn_act_bwd(dh, c, p, "prelu", True)
+        dx, grads["gnn"][k] = dense_bn_act_bwd(dh, c, p, act, True)
         d = dx + dskip
     for k in reversed(range(len(layers["pre"]))):
         p, c = layers["pre"][k], caches["pre"][k]
-        d, grads["pre"][k] = dense_bn_act_bwd(d, c, p, "prelu", k > 0)
+        d, grads["pre"][k] = dense_bn_act_bwd(d, c, p, act, k > 0)
     return loss, acc, grads, probs, stats

@@ -213,6 +213,87 @@ def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
                 assert np.allclose(val, ref, rtol=1e-9, atol=1e-13), (grp, k, name)
 
 
+@pytest.mark.parametrize("connectivity,batch_norm,act,rate", [("sum", True, "prelu", 0.0), ("cat", False, "prelu", 0.0),
+                                                              ("cat", True, "relu", 0.0), ("cat", True, "prelu", 0.4),
+                                                              ("sum", False, None, 0.25), ("sum", True, "relu", 0.5)])
+def test_general_gnn_options_match_torch_autograd(connectivity, batch_norm, act, rate):
+    """Spektral's GeneralGNN options beside gcn.py:320's defaults as the oracle restates them (r3): connectivity="sum",
+    batch_norm=False, hidden_activation "relu" / None, dropout > 0 (the Dropout layer sits between BatchNormalization and the
+    activation in every MLP / GeneralConv layer, the last post layer included; its factors are given, keep / (1 - rate)) --
+    loss, probabilities and every gradient against torch autograd on the same graph."""
+    import torch
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    sizes = [7, 5, 8]
+    n = sum(sizes); gp = np.concatenate([[0], np.cumsum(sizes)])
+    blocks = []
+    for sz in sizes:
+        rp, ci = _rand_csr(rng, sz, 0.4)
+        blocks.append(sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(sz, sz)))
+    a = sp.block_diag(blocks).tocsr(); a.sort_indices()
+    rowptr, colidx = a.indptr.astype(np.int64), a.indices.astype(np.int64)
+    x = rng.standard_normal((n, 5)); y = np.eye(2)[rng.integers(0, 2, 3)]
+    hid = 8
+    layers = O.general_gnn_init(rng, 5, 2, hidden=hid, message_passing=2, pre=2, post=2, connectivity=connectivity,
+                                batch_norm=batch_norm, hidden_activation=act)
+    assert layers["gnn"][1]["kernel"].shape[0] == (2 * hid if connectivity == "cat" else hid)
+    assert ("gamma" in layers["pre"][0]) == batch_norm and ("alpha" in layers["pre"][0]) == (act == "prelu")
+    for grp in layers.values():
+        for p in grp:
+            if "alpha" in p:
+                p["alpha"] = 0.25 * rng.random(p["alpha"].shape)
+            if "gamma" in p:
+                p["gamma"] = 1 + 0.1 * rng.standard_normal(p["gamma"].shape)
+                p["beta"] = 0.1 * rng.standard_normal(p["beta"].shape)
+            p["bias"] = 0.1 * rng.standard_normal(p["bias"].shape)
+    drops = None
+    if rate > 0:
+        mk = lambda rows, p: (rng.random((rows, p["kernel"].shape[1])) >= rate) / (1.0 - rate)
+        drops = {"pre": [mk(n, p) for p in layers["pre"]], "gnn": [mk(n, p) for p in layers["gnn"]],
+                 "post": [mk(3, p) for p in layers["post"]]}
+    kw = dict(connectivity=connectivity, hidden_activation=act, drops=drops)
+    loss, acc, grads, probs, stats = O.general_gnn_loss_and_grads(layers, x, (rowptr, colidx, None), gp, y, cce_mode="probs", **kw)
+    # inference ignores the Dropout layers
+    p_inf, _, _ = O.general_gnn_forward(layers, x, (rowptr, colidx, None), gp, False, **kw)
+    p_inf0, _, _ = O.general_gnn_forward(layers, x, (rowptr, colidx, None), gp, False, connectivity=connectivity, hidden_activation=act)
+    assert np.array_equal(p_inf, p_inf0)
+
+    T = lambda v: torch.tensor(v, requires_grad=True)
+    tl = {g: [{k: T(v) for k, v in p.items() if not k.startswith("moving")} for p in ps] for g, ps in layers.items()}
+    at = torch.tensor(a.toarray())
+
+    def block(h, p, drop, final=False):
+        z = h @ p["kernel"] + p["bias"]
+        if "gamma" in p:
+            mu, var = z.mean(0), z.var(0, unbiased=False)
+            z = p["gamma"] * (z - mu) / torch.sqrt(var + 1e-3) + p["beta"]
+        if drop is not None:
+            z = z * torch.tensor(drop)
+        if final:
+            return torch.softmax(z, 1)
+        if act == "prelu":
+            return torch.relu(z) + p["alpha"] * torch.minimum(z, torch.zeros_like(z))
+        return torch.relu(z) if act == "relu" else z
+    dr = lambda grp, k: None if drops is None else drops[grp][k]
+    out = torch.tensor(x)
+    for k, p in enumerate(tl["pre"]):
+        out = block(out, p, dr("pre", k))
+    for k, p in enumerate(tl["gnn"]):
+        z = at @ block(out, p, dr("gnn", k))
+        out = torch.cat([z, out], 1) if connectivity == "cat" else z + out
+    out = torch.stack([out[gp[g]:gp[g + 1]].sum(0) for g in range(3)])
+    out = block(out, tl["post"][0], dr("post", 0)); pr = block(out, tl["post"][1], dr("post", 1), final=True)
+    tloss = -(torch.tensor(y) * torch.log(torch.clamp(pr, 1e-7, 1 - 1e-7))).sum(1).mean()
+    tloss.backward()
+    assert abs(loss - tloss.item()) < 1e-12 and rel_err(probs, pr.detach().numpy()) < 1e-12
+    for grp in grads:
+        for k, g in enumerate(grads[grp]):
+            assert set(g) == set(tl[grp][k]), (grp, k)
+            for name, val in g.items():
+                ref = tl[grp][k][name].grad.numpy()
+                assert np.allclose(val, ref, rtol=1e-9, atol=1e-13), (grp, k, name)
+
+
 @pytest.mark.parametrize("name", GOLDEN)
 def test_numpy_oracle_reproduces_goldens(name):
     g = load_golden(name)
