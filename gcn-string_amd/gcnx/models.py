@@ -748,7 +748,7 @@ class GeneralGNN(_GraphRunner):
         self._step_dev = ctx.zeros(1, np.int32)           # the optimizer's step count on the device (Dropout streams)
         off = soff = 0
         for grp, fi, fo, pr in dims:
-            L = {"group": grp, "fi": fi, "fo": fo, "act": self.hidden_activation if pr else None}
+            L = {"group": grp, "fi": fi, "fo": fo, "act": self.hidden_activation if pr else None, "index": len(self.layers)}
             for name, shape in (("kernel", (fi, fo)), ("bias", (fo,))) + ((("gamma", (fo,)), ("beta", (fo,))) if bn else ()) + \
                     ((("alpha", (fo,)),) if pr and prelu else ()):
                 n = int(np.prod(shape))
@@ -862,7 +862,7 @@ class GeneralGNN(_GraphRunner):
         """The layer's Dropout factor applied to t in place (forward: the activation's output -- act(s u) = s act(u) for the
         activations built; backward: the incoming gradient).  Stream = the layer's index, step = the device step count."""
         seed = self.seed + (0x9E37 * self.comm.rank if self._multi() else 0)
-        D.dropout(self.ctx, t, self.dropout, seed, self.layers.index(L), self._step_dev)
+        D.dropout(self.ctx, t, self.dropout, seed, L["index"], self._step_dev)
 
     def _dense_bn(self, L, x, z, y, training):
         self._dense_bn_core(L, x, z, y, training)
