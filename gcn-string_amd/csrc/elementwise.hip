@@ -3,7 +3,8 @@
 //     positively homogeneous activations built here (PReLU, ReLU, linear) act(s u) = s act(u) for the keep / scale factor
 //     s in {0, 1 / (1 - rate)}, so the layer is the fused batch-norm + activation pass followed by one multiply, and its
 //     backward the same multiply on the incoming gradient;
-//   * connectivity = "sum": out = z + out.
+//   * connectivity = "sum": out = z + out;
+//   * aggregate = "max" | "min" and their gradient (ties share it, as TensorFlow's unsorted_segment_max gradient does).
 // The keep decision of element i of (layer stream, step) is a stateless hash, so the backward pass regenerates the mask
 // the forward pass used instead of storing it, and a captured step reads the step number from device memory (one
 // captured graph serves every step).  TensorFlow's generator is not reproduced (PARITY UNPINNED: tests hold the
@@ -53,6 +54,53 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, i
   }
 }
 
+// GeneralConv(aggregate = "max" | "min") (tf.math.unsorted_segment_max / _min over a row's messages): one wave
+// per output row, lanes over the columns, the row's entries walked in CSR order.  A row without entries gets the
+// reduction's identity (lowest / largest float, as TensorFlow does).  `cnt` receives the number of entries that attain the
+// extremum (ties), which the gradient divides by.
+template <bool MIN>
+__global__ __launch_bounds__(256) void spmm_minmax_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                          const float* __restrict__ h, int64_t ldh, float* __restrict__ out, int64_t ldo,
+                                                          float* __restrict__ cnt, int64_t ldc, int32_t n, int32_t f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  for (int c = lane; c < f; c += 64) {
+    float m = MIN ? 3.402823466e+38f : -3.402823466e+38f, k = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const float v = h[(int64_t)colidx[e] * ldh + c];
+      if (MIN ? v < m : v > m) { m = v; k = 1.f; }
+      else if (v == m) k += 1.f;
+    }
+    out[row * ldo + c] = m;
+    if (cnt) cnt[row * ldc + c] = k;
+  }
+}
+
+// Its gradient (TensorFlow's _UnsortedSegmentMinOrMaxGrad): every message equal to the row's extremum receives
+// dy / (number of such messages).  Walked from the SOURCE side over the transposed operator: dh[s] = sum over the targets t
+// of row s of A^T of [h[s] == out[t]] * dy[t] / cnt[t] -- a gather in CSR order, deterministic.
+__global__ __launch_bounds__(256) void spmm_minmax_bwd_kernel(const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ colidx_t,
+                                                              const float* __restrict__ h, int64_t ldh, const float* __restrict__ out,
+                                                              int64_t ldo, const float* __restrict__ cnt, int64_t ldc,
+                                                              const float* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
+                                                              int64_t lddh, int32_t n, int32_t f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr_t[row], e1 = rowptr_t[row + 1];
+  for (int c = lane; c < f; c += 64) {
+    const float hv = h[row * ldh + c];
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int64_t t = colidx_t[e];
+      if (out[t * ldo + c] == hv) acc += dy[t * lddy + c] / cnt[t * ldc + c];
+    }
+    dh[row * lddh + c] = acc;
+  }
+}
+
 int grid_for(gcnx_ctx* ctx, int64_t total) {
   int64_t g = (total + 255) / 256;
   const int64_t cap = 16LL * ctx->num_cus;
@@ -98,6 +146,38 @@ int gcnx_add(gcnx_ctx* ctx, const float* a, int64_t lda, const float* b, int64_t
   GCNX_REQUIRE(ctx, a && b && out, "gcnx_add: NULL pointer");
   GCNX_REQUIRE(ctx, lda >= f && ldb >= f && ldo >= f, "gcnx_add: leading dimension too small");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(ctx, n * (int64_t)f)), dim3(256), 0, ctx->stream, a, lda, b, ldb, out, ldo, n, f);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_spmm_csr_minmax(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* h, int64_t ldh, float* out,
+                         int64_t ldo, float* cnt, int64_t ldc, int32_t n, int32_t f, int is_min) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation (max / min)");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr_minmax: negative size");
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, rowptr && colidx && h && out, "gcnx_spmm_csr_minmax: NULL pointer");
+  GCNX_REQUIRE(ctx, ldh >= f && ldo >= f && (!cnt || ldc >= f), "gcnx_spmm_csr_minmax: leading dimension too small");
+  GCNX_REQUIRE(ctx, h != out, "gcnx_spmm_csr_minmax: in-place aggregation is not supported");
+  const dim3 grid(gcnx_cdiv(n, 4));
+  if (is_min) hipLaunchKernelGGL((spmm_minmax_kernel<true>), grid, dim3(256), 0, ctx->stream, rowptr, colidx, h, ldh, out, ldo, cnt, ldc, n, f);
+  else hipLaunchKernelGGL((spmm_minmax_kernel<false>), grid, dim3(256), 0, ctx->stream, rowptr, colidx, h, ldh, out, ldo, cnt, ldc, n, f);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_spmm_csr_minmax_bwd(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* h, int64_t ldh,
+                             const float* out, int64_t ldo, const float* cnt, int64_t ldc, const float* dy, int64_t lddy, float* dh,
+                             int64_t lddh, int32_t n, int32_t f) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation backward (max / min)");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr_minmax_bwd: negative size");
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, rowptr_t && colidx_t && h && out && cnt && dy && dh, "gcnx_spmm_csr_minmax_bwd: NULL pointer");
+  GCNX_REQUIRE(ctx, ldh >= f && ldo >= f && ldc >= f && lddy >= f && lddh >= f, "gcnx_spmm_csr_minmax_bwd: leading dimension too small");
+  GCNX_REQUIRE(ctx, dh != dy && dh != h, "gcnx_spmm_csr_minmax_bwd: in-place is not supported");
+  hipLaunchKernelGGL(spmm_minmax_bwd_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, rowptr_t, colidx_t, h, ldh, out, ldo, cnt,
+                     ldc, dy, lddy, dh, lddh, n, f);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

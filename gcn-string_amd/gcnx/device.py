@@ -958,3 +958,22 @@ def add(ctx, a, b, out):
     assert b.shape == (n, f) and out.shape == (n, f)
     ctx._ck(ctx.lib.gcnx_add(ctx.h, _p(a), a.ld, _p(b), b.ld, _p(out), out.ld, n, f))
     return out
+
+
+def spmm_minmax(ctx, a, h, out, cnt=None, mode="max"):
+    """GeneralConv(aggregate="max" | "min") (gcnx_spmm_csr_minmax): out[t] = max / min over the entries (t, s) of h[s]
+    (values ignored); cnt = the number of entries attaining it (for the gradient)."""
+    n, f = h.shape
+    assert a.n == n and out.shape == (n, f) and mode in ("max", "min")
+    ctx._ck(ctx.lib.gcnx_spmm_csr_minmax(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(h), h.ld, _p(out), out.ld, _p(cnt),
+                                         cnt.ld if cnt is not None else 0, n, f, 1 if mode == "min" else 0))
+    return out
+
+
+def spmm_minmax_bwd(ctx, at, h, out, cnt, dy, dh):
+    """Gradient of spmm_minmax wrt h (gcnx_spmm_csr_minmax_bwd); ``at`` is the transposed operator."""
+    n, f = h.shape
+    assert at.n == n and out.shape == (n, f) and cnt.shape == (n, f) and dy.shape == (n, f) and dh.shape == (n, f)
+    ctx._ck(ctx.lib.gcnx_spmm_csr_minmax_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(h), h.ld, _p(out), out.ld, _p(cnt), cnt.ld,
+                                             _p(dy), dy.ld, _p(dh), dh.ld, n, f))
+    return dh

@@ -189,8 +189,8 @@ class GeneralConv(Layer):
     def __init__(self, channels=256, batch_norm=True, dropout=0.0, aggregate="sum", activation="prelu", use_bias=True,
                  prec="f32", **kw):
         super().__init__(**kw)
-        if aggregate not in ("sum", "mean"):
-            raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): 'sum' (what gcn.py:320 uses) and 'mean' are built")
+        if aggregate not in ("sum", "mean", "max", "min"):
+            raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): 'sum' (what gcn.py:320 uses), 'mean', 'max' and 'min' are built")
         self.aggregate = aggregate
         if not 0.0 <= float(dropout) < 1.0:
             raise ValueError(f"GeneralConv(dropout={dropout!r}): a rate in [0, 1)")
@@ -259,16 +259,24 @@ class GeneralConv(Layer):
             drop_id = self._drop_calls = self._drop_calls + 1
             D.dropout(ctx, h, self.dropout, self._seed, drop_id)
         y = out if out is not None else self._buf("y", (n, c))
-        au = a.unweighted() if self.aggregate == "sum" else a.row_mean()   # values ignored (8.A.4); "mean": 1 / row length
-        D.spmm(ctx, au, h, None, y)
-        self._saved = (x, au, z, h, bool(training), drop_id)
+        au = a.row_mean() if self.aggregate == "mean" else a.unweighted()  # values ignored (8.A.4); "mean": 1 / row length
+        cnt = None
+        if self.aggregate in ("max", "min"):                # unsorted_segment_max / _min; the tie counts for the gradient
+            cnt = self._buf("aggcnt", (n, c))
+            D.spmm_minmax(ctx, au, h, y, cnt, self.aggregate)
+        else:
+            D.spmm(ctx, au, h, None, y)
+        self._saved = (x, au, z, h, bool(training), drop_id, y, cnt)
         return y
 
     def backward(self, dy, need_dx=True):
-        x, au, z, h, training, drop_id = self._saved
+        x, au, z, h, training, drop_id, y, cnt = self._saved
         ctx = self.ctx
         dh = self._buf("dh", dy.shape)
-        D.spmm(ctx, au.transpose(), dy, None, dh)            # dH = S^T dY
+        if cnt is not None:
+            D.spmm_minmax_bwd(ctx, au.transpose(), h, y, cnt, dy, dh)
+        else:
+            D.spmm(ctx, au.transpose(), dy, None, dh)        # dH = S^T dY
         if drop_id is not None:
             D.dropout(ctx, dh, self.dropout, self._seed, drop_id)
         if not self.batch_norm and self.activation == "prelu":

@@ -711,8 +711,8 @@ class GeneralGNN(_GraphRunner):
         self.hidden_activation, self.seed = hidden_activation, int(seed)
         # Spektral's other aggregations / pools that map onto kernels that exist (r3): aggregate "mean" is the same gather with
         # the weight 1 / (entries of the row) per entry, pool "avg" / "max" are modes of the segment pool and its backward
-        if aggregate not in ("sum", "mean"):
-            raise NotImplementedError(f"GeneralGNN(aggregate={aggregate!r}): 'sum' (gcn.py:320) and 'mean' are built")
+        if aggregate not in ("sum", "mean", "max", "min"):
+            raise NotImplementedError(f"GeneralGNN(aggregate={aggregate!r}): 'sum' (gcn.py:320), 'mean', 'max' and 'min' are built")
         if pool not in ("sum", "avg", "max"):
             raise NotImplementedError(f"GeneralGNN(pool={pool!r}): 'sum' (gcn.py:320), 'avg' and 'max' are built")
         self.aggregate, self.pool = aggregate, pool
@@ -910,7 +910,7 @@ class GeneralGNN(_GraphRunner):
     def _agg_operator(self, batch):
         """The aggregation's operator: the 0 / 1 pattern of a (aggregate = "sum"), or the same pattern with 1 / (entries of
         the row) on every entry ("mean": tf.math.unsorted_segment_mean over a row's messages), built once per batch."""
-        return batch.a.unweighted() if self.aggregate == "sum" else batch.a.row_mean()
+        return batch.a.row_mean() if self.aggregate == "mean" else batch.a.unweighted()     # ("max" / "min": the pattern only)
 
     def _forward(self, batch, bufs, training):
         h, mp = self.hidden, self.mp
@@ -927,11 +927,22 @@ class GeneralGNN(_GraphRunner):
         for k in range(mp):
             L = self.layers[li]
             inp = cat.cols((mp - k) * h, (mp - k + 1) * h if sumc else (mp + 1) * h)
-            self._dense_bn(L, inp, bufs[f"z{li}"], bufs["h"], training)
+            minmax = self.aggregate in ("max", "min")
+            # ("max" / "min": the layer's messages, its aggregate and the tie counts are kept for the gradient in per-layer
+            # buffers -- `h` is reused by the next layer, the `cat` slice summed over with connectivity "sum")
+            hk = self._tmp(bufs, f"msg{li}", (batch.n, h)) if minmax else bufs["h"]
+            self._dense_bn(L, inp, bufs[f"z{li}"], hk, training)
             new = cat.cols((mp - k - 1) * h, (mp - k) * h)
-            D.spmm(self.ctx, a, bufs["h"], None, new)
-            if sumc:
-                D.add(self.ctx, new, inp, new)
+            if minmax:                                    # tf.math.unsorted_segment_max / _min over a row's messages
+                ck = self._tmp(bufs, f"aggcnt{li}", (batch.n, h))
+                zk = self._tmp(bufs, f"agg{li}", (batch.n, h)) if sumc else new
+                D.spmm_minmax(self.ctx, a, hk, zk, ck, self.aggregate)
+                if sumc:
+                    D.add(self.ctx, zk, inp, new)
+            else:
+                D.spmm(self.ctx, a, bufs["h"], None, new)
+                if sumc:
+                    D.add(self.ctx, new, inp, new)
             li += 1
         if self.pool == "max":
             if getattr(self, "_cap", None) is None:
@@ -1015,7 +1026,11 @@ class GeneralGNN(_GraphRunner):
         for k in reversed(range(mp)):
             L = self.layers[li]
             dout = dcat.cols((mp - k - 1) * h, (mp - k) * h)
-            D.spmm(self.ctx, at, dout, None, bufs["dh"])
+            if self.aggregate in ("max", "min"):
+                zk = bufs[f"agg{li}"] if sumc else cat.cols((mp - k - 1) * h, (mp - k) * h)
+                D.spmm_minmax_bwd(self.ctx, at, bufs[f"msg{li}"], zk, bufs[f"aggcnt{li}"], dout, bufs["dh"])
+            else:
+                D.spmm(self.ctx, at, dout, None, bufs["dh"])
             if sumc:                                       # d out_(k-1) = d out_k (the skip) + dz W^T
                 inp, din = cat.cols((mp - k) * h, (mp - k + 1) * h), dcat.cols((mp - k) * h, (mp - k + 1) * h)
                 self._bwd_dense_bn(L, bufs["dh"], inp, bufs[f"z{li}"], din, training)

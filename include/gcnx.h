@@ -447,6 +447,19 @@ GCNX_API int gcnx_counter_add(gcnx_ctx* ctx, uint32_t* counter, uint32_t inc);
 GCNX_API int gcnx_add(gcnx_ctx* ctx, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
                       int64_t n, int32_t f);
 
+/* GeneralConv(aggregate = "max" | "min") (tf.math.unsorted_segment_max / _min over the messages gather(h, a.indices[:,1]) of
+ * every target row; adjacency values ignored): out[t, c] = max (min) over the entries (t, s) of h[s, c]; a row
+ * without entries gets the lowest (largest) float, as TensorFlow does.  cnt (may be NULL; needed for the gradient) receives
+ * the number of entries attaining the extremum. */
+GCNX_API int gcnx_spmm_csr_minmax(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* h, int64_t ldh,
+                                  float* out, int64_t ldo, float* cnt, int64_t ldc, int32_t n, int32_t f, int is_min);
+/* Its gradient wrt h (TensorFlow's _UnsortedSegmentMinOrMaxGrad: the messages equal to the extremum share dy equally), from
+ * the source side: rowptr_t / colidx_t is the TRANSPOSED operator (rows = sources, entries = their targets);
+ * dh[s, c] = sum over targets t of [h[s, c] == out[t, c]] * dy[t, c] / cnt[t, c].  Deterministic (CSR order). */
+GCNX_API int gcnx_spmm_csr_minmax_bwd(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* h, int64_t ldh,
+                                      const float* out, int64_t ldo, const float* cnt, int64_t ldc, const float* dy, int64_t lddy,
+                                      float* dh, int64_t lddh, int32_t n, int32_t f);
+
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);

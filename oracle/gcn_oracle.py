@@ -546,6 +546,37 @@ def aggregate_vals(rowptr, aggregate, dtype=np.float64):
     return np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(dtype), np.diff(np.asarray(rowptr)))
 
 
+F32_MAX = float(np.finfo(np.float32).max)
+
+
+def aggregate_minmax(rowptr, colidx, h, mode):
+    """GeneralConv(aggregate="max" | "min") (A.4): tf.math.unsorted_segment_max / _min over the messages h[a.indices[:,1]] of
+    every target row; a row without messages gets the lowest / largest float32 (TensorFlow's value for an empty segment).
+    Returns (out, cnt): cnt = how many messages attain the extremum (the gradient's divisor)."""
+    n = len(rowptr) - 1
+    red = np.max if mode == "max" else np.min
+    out = np.full((n, h.shape[1]), -F32_MAX if mode == "max" else F32_MAX, h.dtype)
+    cnt = np.zeros((n, h.shape[1]), h.dtype)
+    for t in range(n):
+        idx = colidx[rowptr[t]:rowptr[t + 1]]
+        if len(idx):
+            m = h[idx]
+            out[t] = red(m, axis=0)
+            cnt[t] = (m == out[t]).sum(0)
+    return out, cnt
+
+
+def aggregate_minmax_bwd(rowptr, colidx, h, out, cnt, dy):
+    """TensorFlow's _UnsortedSegmentMinOrMaxGrad: the messages equal to the segment's extremum share its gradient equally."""
+    dh = np.zeros_like(h)
+    for t in range(len(rowptr) - 1):
+        idx = colidx[rowptr[t]:rowptr[t + 1]]
+        if len(idx):
+            sel = (h[idx] == out[t]).astype(h.dtype)
+            np.add.at(dh, idx, sel * (dy[t] / cnt[t]))
+    return dh
+
+
 def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="softmax", aggregate="sum", pool="sum",
                         connectivity="cat", hidden_activation="prelu", drops=None):
     """A.3: pre-MLP -> 4x [z=GeneralConv(out); out=concat([z,out])] -> global pool -> post-MLP.
@@ -555,7 +586,8 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
     (keep / (1 - rate), one array per layer, {"pre": [...], "gnn": [...], "post": [...]}; training only).
     Returns probs, caches, list of (moving_mean, moving_var) updates in layer order."""
     rowptr, colidx, _ = csr
-    agg = aggregate_vals(rowptr, aggregate, x.dtype)
+    minmax = aggregate in ("max", "min")
+    agg = None if minmax else aggregate_vals(rowptr, aggregate, x.dtype)
     caches = {"pre": [], "gnn": [], "post": []}
     stats = []
     act = hidden_activation
@@ -565,7 +597,11 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
         out, c, mm, mv = dense_bn_act_fwd(out, p, training, act, drop=drop("pre", k)); caches["pre"].append(c); stats.append((mm, mv))
     for k, p in enumerate(layers["gnn"]):
         h, c, mm, mv = dense_bn_act_fwd(out, p, training, act, drop=drop("gnn", k)); stats.append((mm, mv))
-        z = spmm_csr(rowptr, colidx, agg, h)
+        if minmax:
+            z, c["agg_cnt"] = aggregate_minmax(rowptr, colidx, h, aggregate)
+            c["agg_out"] = z
+        else:
+            z = spmm_csr(rowptr, colidx, agg, h)
         c["width_in"] = out.shape[1]
         caches["gnn"].append(c)
         out = np.concatenate([z, out], axis=1) if connectivity == "cat" else z + out
@@ -584,7 +620,8 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
 def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits", aggregate="sum", pool="sum",
                                connectivity="cat", hidden_activation="prelu", drops=None):
     rowptr, colidx, _ = csr
-    agg = aggregate_vals(rowptr, aggregate, x.dtype)
+    minmax = aggregate in ("max", "min")
+    agg = None if minmax else aggregate_vals(rowptr, aggregate, x.dtype)
     act = hidden_activation
     probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True, aggregate=aggregate, pool=pool,
                                                connectivity=connectivity, hidden_activation=hidden_activation, drops=drops)
@@ -606,7 +643,9 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
         p, c = layers["gnn"][k], caches["gnn"][k]
         hid = p["kernel"].shape[1]
         dz, dskip = (d[:, :hid], d[:, hid:]) if connectivity == "cat" else (d, d)
-        if csr_t is not None and agg is None:
+        if minmax:
+            dh = aggregate_minmax_bwd(rowptr, colidx, c["y"], c["agg_out"], c["agg_cnt"], dz)
+        elif csr_t is not None and agg is None:
             dh = spmm_csr(csr_t[0], csr_t[1], None, dz)
         else:
             dh = spmm_csr_T(rowptr, colidx, agg, dz)

@@ -328,6 +328,37 @@ def test_spmm_full_size_properties(ctx):
     assert rel_err(o1.numpy()[rows], ref) < TIGHT
 
 
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_spmm_minmax_aggregation_and_its_gradient_with_ties(ctx, mode):
+    """gcnx_spmm_csr_minmax / _bwd (GeneralConv(aggregate="max" | "min"), tf.math.unsorted_segment_max / _min): values, tie counts
+    and the gradient -- every message equal to the extremum gets dy / count -- on integer-valued messages (exact ties), a ragged
+    width, rows without entries (identity value, no gradient), against the oracle's restatement (which torch.amax / amin pin,
+    tests/test_oracle.py); the gradient runs over the transposed operator of a DIRECTED pattern."""
+    import scipy.sparse as sp
+    from gcnx import device as D
+    from gcnx.device import DeviceCSR
+    o = O()
+    rng = np.random.default_rng(17)
+    n, f = 301, 37
+    m = sp.random(n, n, density=0.03, random_state=3, format="csr"); m.data[:] = 1.0
+    m = m.tolil(); m[7, :] = 0; m[200, :] = 0; m = m.tocsr(); m.eliminate_zeros(); m.sort_indices()
+    rp, ci = m.indptr.astype(np.int32), m.indices.astype(np.int32)
+    a = DeviceCSR.from_host_csr(ctx, rp, ci, None, None)
+    h = rng.integers(-3, 4, (n, f)).astype(np.float32)
+    dy = rng.standard_normal((n, f), dtype=np.float32)
+    out, cnt, dh = ctx.empty((n, f)), ctx.empty((n, f)), ctx.empty((n, f))
+    dh_ = ctx.to_device(h)
+    D.spmm_minmax(ctx, a, dh_, out, cnt, mode)
+    rout, rcnt = o.aggregate_minmax(rp.astype(np.int64), ci.astype(np.int64), h.astype(np.float64), mode)
+    assert np.array_equal(out.numpy(), rout.astype(np.float32)) and np.array_equal(cnt.numpy(), rcnt.astype(np.float32))
+    assert rcnt.max() >= 2 and out.numpy()[7, 0] == (np.finfo(np.float32).max if mode == "min" else -np.finfo(np.float32).max)
+    D.spmm_minmax_bwd(ctx, a.transpose(), dh_, out, cnt, ctx.to_device(dy), dh)
+    rdh = o.aggregate_minmax_bwd(rp.astype(np.int64), ci.astype(np.int64), h.astype(np.float64), rout, rcnt, dy.astype(np.float64))
+    assert rel_err(dh.numpy(), rdh) < TIGHT
+    dh2 = ctx.empty((n, f)); D.spmm_minmax_bwd(ctx, a.transpose(), dh_, out, cnt, ctx.to_device(dy), dh2)
+    assert np.array_equal(dh.numpy(), dh2.numpy())                                    # deterministic
+
+
 def test_spmm_balanced_deal_of_the_tile_graphs_changes_no_bit(ctx):
     """The plan's balanced deal (r3, csrc/spmm.hip balance_tile_list; knob spmm_bal): with >= 1.5 tile graphs per CU the
     graph list is laid out so that the kernel's static snake deal gives every workgroup about the same cost instead of the

@@ -475,26 +475,29 @@ def test_gcn2_world_size_2_large_batch_with_bf16_storage_equals_single_rank():
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("aggregate,pool", [("mean", "avg"), ("sum", "max"), ("mean", "sum")])
-def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, pool):
-    """GeneralGNN(aggregate="mean" | pool="avg" | "max") (Spektral options beside gcn.py:320's defaults; r3): inference forward,
+@pytest.mark.parametrize("aggregate,pool,connectivity", [("mean", "avg", "cat"), ("sum", "max", "cat"), ("mean", "sum", "cat"),
+                                                         ("max", "sum", "cat"), ("min", "avg", "sum"), ("max", "max", "sum")])
+def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, pool, connectivity):
+    """GeneralGNN(aggregate="mean" | "max" | "min", pool="avg" | "max") (Spektral options beside gcn.py:320's defaults; r3): inference forward,
     training step (loss, probabilities, every gradient) against the fp64 oracle, which torch autograd pins for these options
     (tests/test_oracle.py).  Gradients get the gross-error bound of the default-option test's larger cases (PReLU kinks)."""
     from gcnx import synth
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch, GeneralGNN
     from oracle import gcn_oracle as O
-    hb, layers, flat = _general_gnn_case(31, 16, 32, 2, 5)
+    hb, layers, flat = _general_gnn_case(31, 16, 32, 2, 5, connectivity=connectivity)
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, None, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
-    m = GeneralGNN(ctx, 2, activation="softmax", hidden=32, message_passing=2, aggregate=aggregate, pool=pool, use_graph=False)
+    m = GeneralGNN(ctx, 2, activation="softmax", hidden=32, message_passing=2, aggregate=aggregate, pool=pool,
+                   connectivity=connectivity, use_graph=False)
     m.build(16)
     m.set_weights(flat, order="layer")
     x64, y64 = hb.x.astype(np.float64), hb.y.astype(np.float64)
     csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
-    rprobs, _, _ = O.general_gnn_forward(layers, x64, csr, hb.graph_ptr, False, aggregate=aggregate, pool=pool)
+    rprobs, _, _ = O.general_gnn_forward(layers, x64, csr, hb.graph_ptr, False, aggregate=aggregate, pool=pool, connectivity=connectivity)
     assert rel_err(m(batch, training=False), rprobs) < TOL
-    rl, ra, rg, rp, _ = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64, aggregate=aggregate, pool=pool)
+    rl, ra, rg, rp, _ = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64, aggregate=aggregate, pool=pool,
+                                                     connectivity=connectivity)
     loss, acc = m.train_step(batch, None, lr=0.01)
     assert abs(loss - rl) < TOL * max(1, rl) and acc == pytest.approx(ra)
     assert rel_err(m._bufs["probs"].numpy(), rp) < TOL
@@ -733,7 +736,7 @@ def test_general_gnn_weight_orders(ctx):
 def test_general_gnn_rejects_unbuilt_options(ctx):
     from gcnx.models import GeneralGNN
     with pytest.raises(NotImplementedError):
-        GeneralGNN(ctx, 2, activation="softmax", aggregate="max")
+        GeneralGNN(ctx, 2, activation="softmax", aggregate="prod")
     with pytest.raises(NotImplementedError):
         GeneralGNN(ctx, 2, activation=None)
     with pytest.raises(NotImplementedError):
@@ -1144,7 +1147,7 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
 
 
 @pytest.mark.parametrize("batch_norm,activation", [(True, "prelu"), (True, "relu"), (False, "relu"), (False, None), (False, "prelu")])
-@pytest.mark.parametrize("aggregate", ["sum", "mean"])
+@pytest.mark.parametrize("aggregate", ["sum", "mean", "max"])
 def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     """spektral.layers.GeneralConv as a layer of its own (SURVEY 8(b) surface list; inside GeneralGNN at gcn.py:320):
     layer([x, a], training=) = sum-aggregation over a.indices of activation(BN(x W + b)) -- adjacency values ignored --
@@ -1160,7 +1163,8 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     x = ctx.to_device(hb.x)
     conv = GeneralConv(20, batch_norm=batch_norm, activation=activation, aggregate=aggregate, seed=4)
     conv([x, a], training=True)                                  # builds
-    agg = O.aggregate_vals(hb.rowptr, aggregate)                 # None ("sum") / 1 / row length per entry ("mean", r3)
+    minmax = aggregate in ("max", "min")
+    agg = None if minmax else O.aggregate_vals(hb.rowptr, aggregate)   # None ("sum") / 1 / row length per entry ("mean", r3)
     rng = np.random.default_rng(1)
     names = list(conv.params) + list(conv.state)
     assert names == (["kernel", "bias"] + (["alpha"] if activation == "prelu" else []) +
@@ -1179,10 +1183,15 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     for training in ((False, True) if batch_norm else (False,)):
         y = conv([x, a], training=training)
         h, cache, mm, mv = O.dense_bn_act_fwd(x64, p, training, activation)
-        assert rel_err(y.numpy(), O.spmm_csr(rp, ci, agg, h)) < TOL, training
+        if minmax:
+            ry, rcnt = O.aggregate_minmax(rp, ci, h, aggregate)
+        else:
+            ry = O.spmm_csr(rp, ci, agg, h)
+        assert rel_err(y.numpy(), ry) < TOL, training
     dy = rng.standard_normal(y.shape).astype(np.float32)
     dx = conv.backward(ctx.to_device(dy))
-    dh = O.spmm_csr_T(rp, ci, agg, dy.astype(np.float64))
+    dh = (O.aggregate_minmax_bwd(rp, ci, h, ry, rcnt, dy.astype(np.float64)) if minmax else
+          O.spmm_csr_T(rp, ci, agg, dy.astype(np.float64)))
     rdx, rg = O.dense_bn_act_bwd(dh, cache, p, activation)
     assert rel_err(dx.numpy(), rdx) < 2 * TOL
     for k in conv.grads:
@@ -1190,7 +1199,7 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     if batch_norm:
         assert rel_err(conv.state["moving_mean"].numpy(), mm) < TOL and rel_err(conv.state["moving_var"].numpy(), mv) < TOL
     with pytest.raises(NotImplementedError):
-        GeneralConv(8, aggregate="max")
+        GeneralConv(8, aggregate="prod")
 
 
 def test_general_conv_layer_dropout(ctx):

@@ -154,7 +154,7 @@ def test_finite_difference_gradcheck_gcnconv():
         assert rel_err(grad, num) < 1e-6
 
 
-@pytest.mark.parametrize("aggregate,pool", [("sum", "sum"), ("mean", "avg"), ("sum", "max"), ("mean", "sum")])
+@pytest.mark.parametrize("aggregate,pool", [("sum", "sum"), ("mean", "avg"), ("sum", "max"), ("mean", "sum"), ("max", "sum"), ("min", "avg")])
 def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
     """n1 tier (GeneralGNN-complete): BN(train) + PReLU + concat-skip + sum-aggregation (gcn.py:320's defaults), and the
     Spektral options aggregate="mean" / pool="avg" | "max" (r3)."""
@@ -198,8 +198,15 @@ def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
     out = torch.tensor(x)
     for p in tl["pre"]:
         out = block(out, p)
+    nbrs = [colidx[rowptr[t]:rowptr[t + 1]] for t in range(n)]
+
+    def aggregate_t(h):          # "max" / "min": per target row over its messages (torch.amax / amin share the gradient among ties)
+        if aggregate in ("sum", "mean"):
+            return at @ h
+        f = torch.amax if aggregate == "max" else torch.amin
+        return torch.stack([f(h[torch.tensor(ix)], 0) for ix in nbrs])
     for p in tl["gnn"]:
-        out = torch.cat([at @ block(out, p), out], 1)
+        out = torch.cat([aggregate_t(block(out, p)), out], 1)
     red = {"sum": lambda t: t.sum(0), "avg": lambda t: t.mean(0), "max": lambda t: t.amax(0)}[pool]
     out = torch.stack([red(out[gp[g]:gp[g + 1]]) for g in range(3)])
     out = block(out, tl["post"][0]); pr = block(out, tl["post"][1], final=True)
@@ -211,6 +218,32 @@ def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
             for name, val in g.items():
                 ref = tl[grp][k][name].grad.numpy()   # Dense bias under BN has an exactly-zero gradient
                 assert np.allclose(val, ref, rtol=1e-9, atol=1e-13), (grp, k, name)
+
+
+def test_aggregate_minmax_ties_share_the_gradient():
+    """aggregate="max" / "min" with exact ties (integer-valued messages): value, tie count and TensorFlow's gradient rule --
+    every message equal to the extremum gets dy / count -- against torch.amax / amin, whose backward shares the gradient the
+    same way; an empty row gets the lowest / largest float32 and passes no gradient."""
+    import torch
+    rng = np.random.default_rng(8)
+    rowptr, colidx = _rand_csr(rng, 12, 0.35)
+    rowptr = rowptr.copy(); colidx = colidx.copy()
+    e0, e1 = rowptr[5], rowptr[6]                      # make row 5 empty
+    colidx = np.concatenate([colidx[:e0], colidx[e1:]]); rowptr[6:] -= (e1 - e0)
+    h = rng.integers(-2, 3, (12, 5)).astype(np.float64)
+    dy = rng.standard_normal((12, 5))
+    for mode in ("max", "min"):
+        out, cnt = O.aggregate_minmax(rowptr, colidx, h, mode)
+        dh = O.aggregate_minmax_bwd(rowptr, colidx, h, out, cnt, dy)
+        assert out[5, 0] == (-O.F32_MAX if mode == "max" else O.F32_MAX) and cnt[5, 0] == 0
+        assert cnt.max() >= 2                            # ties are present
+        th = torch.tensor(h, requires_grad=True)
+        f = torch.amax if mode == "max" else torch.amin
+        rows = [t for t in range(12) if rowptr[t + 1] > rowptr[t]]
+        tout = torch.stack([f(th[torch.tensor(colidx[rowptr[t]:rowptr[t + 1]])], 0) for t in rows])
+        (tout * torch.tensor(dy[rows])).sum().backward()
+        assert np.array_equal(out[rows], tout.detach().numpy())
+        assert np.allclose(dh, th.grad.numpy(), rtol=1e-12, atol=1e-14)
 
 
 @pytest.mark.parametrize("connectivity,batch_norm,act,rate", [("sum", True, "prelu", 0.0), ("cat", False, "prelu", 0.0),
