@@ -236,7 +236,15 @@ __device__ __forceinline__ void head_body(const float* __restrict__ pooled, int6
   const int lo = train ? 0 : h * c + c;
   for (int idx = lo + tid; idx < npart; idx += 256) {
     float acc = 0.f;
-    for (int q = 0; q < nblk; ++q) acc += slabs[(int64_t)q * npart + idx];
+    int q = 0;
+    for (; q + 8 <= nblk; q += 8) {                        // eight slabs' loads in flight, added in workgroup order (as a plain
+      float v[8];                                          // loop the 53 slabs of a config-3 batch were 53 L2 round trips in a row)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(int64_t)(q + u) * npart + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; q < nblk; ++q) acc += slabs[(int64_t)q * npart + idx];
     if (idx < h * c) dw[idx] = acc;
     else if (idx < h * c + c) { if (db) db[idx - h * c] = acc; }
     else if (idx == h * c + c) loss_acc[0] = acc / denom;
