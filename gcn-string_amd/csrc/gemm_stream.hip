@@ -776,23 +776,35 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_stream_kernel(const float* __r
 // the shape is not one this kernel is built for.
 // Slab reduction of the panel form: dw[p * 65536 + e] = sum over the slices, in slice order, of slabs[(p * nslices + s)][e].
 __global__ __launch_bounds__(256) void dw_panel_reduce_kernel(const float* __restrict__ slabs, int nslices, float* __restrict__ dw) {
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  // 64 float4 outputs x 4 slice groups per workgroup: each group adds its quarter of the slices in ascending order with eight
+  // loads in flight, the four group sums are combined as (g0 + g1) + (g2 + g3) -- a fixed order (one thread walking all
+  // ~117 slices four at a time was 29 dependent L2 round trips: 10.9 us for 7.7 MB)
+  __shared__ float4 sm[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t e = ((size_t)blockIdx.x * 64 + el) * 4;
   const float* p = slabs + (size_t)blockIdx.y * nslices * 65536 + e;
+  const int per = (nslices + 3) / 4;
+  const int s0 = grp * per, s1 = min(nslices, s0 + per);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int s = 0;
-  for (; s + 4 <= nslices; s += 4) {                       // four slabs in flight per thread, added in slice order
-    const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)(s + 0) * 65536), v1 = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * 65536);
-    const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(s + 2) * 65536), v3 = *reinterpret_cast<const float4*>(p + (size_t)(s + 3) * 65536);
-    acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-    acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-    acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-    acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+  int s = s0;
+  for (; s + 8 <= s1; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(s + u) * 65536);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
   }
-  for (; s < nslices; ++s) {
+  for (; s < s1; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * 65536);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
-  *reinterpret_cast<float4*>(dw + (size_t)blockIdx.y * 65536 + e) = acc;
+  sm[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    const float4 a = sm[0][el], b = sm[1][el], c = sm[2][el], d = sm[3][el];
+    *reinterpret_cast<float4*>(dw + (size_t)blockIdx.y * 65536 + e) =
+        make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  }
 }
 
 // dW[fi, 256] = X^T dH for fi = 256 p (p <= 8) at mid-size batches (GeneralGNN: n = 22 576): the streaming kernel over
@@ -824,7 +836,7 @@ int gcnx_gemm_dw_panels(gcnx_ctx* ctx, const float* x, int64_t ldx, const float*
     hipLaunchKernelGGL((gemm_dw_stream_kernel<1>), grid, dim3(512), DwLds<1>::total, ctx->stream, x, ldx, dh, lddh, (float*)ctx->ws, n, rows_per);
   }
   if (hipGetLastError() != hipSuccess) return -1;
-  hipLaunchKernelGGL(dw_panel_reduce_kernel, dim3(65536 / 4 / 256, panels), dim3(256), 0, ctx->stream, (const float*)ctx->ws, slices, dw);
+  hipLaunchKernelGGL(dw_panel_reduce_kernel, dim3(65536 / 4 / 64, panels), dim3(256), 0, ctx->stream, (const float*)ctx->ws, slices, dw);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 
