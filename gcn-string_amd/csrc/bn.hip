@@ -194,6 +194,53 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __
   }
 }
 
+// gcnx_bn_moments for a batch of at most kRows rows (the post-MLP of GeneralGNN runs on one row per graph: 32 rows at an
+// E. coli-sized batch) in ONE launch: a workgroup owns 64 columns through both passes -- column sums, mean, column sums of
+// the centred data, variance -- with the arithmetic of the four-launch sequence in the same order (one chunk: the chunk
+// reduction adds zeros), so the results are the same bits.  `part` is scratch for one chunk ([2][f]).
+__global__ __launch_bounds__(256) void bn_moments_small_kernel(const float* __restrict__ z, int64_t ldz, int64_t n, int32_t f,
+                                                               float momentum, float eps, float* __restrict__ part,
+                                                               float* __restrict__ mean, float* __restrict__ inv,
+                                                               float* __restrict__ moving_mean, float* __restrict__ moving_var, int vec) {
+  __shared__ float s_mean[64];
+  const int c0 = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+  const bool fast = vec && (int)blockIdx.x * 64 + 64 <= f;
+  const float count = (float)n;
+  colsums<2>(n, f, part, fast, [&](int64_t r, int c, int valid, float4 (&t)[2], auto fs) {
+    const float4 v = ld4g(z + r * ldz + c, decltype(fs)::value || (vec && valid >= 4), valid);
+    t[0] = v;
+    t[1] = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+  });
+  __syncthreads();                                   // this workgroup's columns of `part` were written by its own threads
+  const int el = threadIdx.x, c = blockIdx.x * 64 + el;
+  if (el < 64) s_mean[el] = c < f ? 0.f + ((part[c] + 0.f) + (0.f + 0.f)) / count : 0.f;      // pass 1 of bn_reduce_finalize_kernel
+  __syncthreads();
+  float4 sh = f4(0.f);
+  if (f - c0 > 0) {
+    const int q = (threadIdx.x & 15) * 4;
+    sh = make_float4(s_mean[q], s_mean[q + 1], s_mean[q + 2], s_mean[q + 3]);
+  }
+  colsums<2>(n, f, part, fast, [&](int64_t r, int c_, int valid, float4 (&t)[2], auto fs) {
+    float4 v = ld4g(z + r * ldz + c_, decltype(fs)::value || (vec && valid >= 4), valid);
+    v = make_float4(v.x - sh.x, v.y - sh.y, v.z - sh.z, v.w - sh.w);
+    t[0] = v;
+    t[1] = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+  });
+  __syncthreads();
+  if (el < 64 && c < f) {
+    const float s0 = (part[c] + 0.f) + (0.f + 0.f), s1 = (part[f + c] + 0.f) + (0.f + 0.f);
+    const float d = s0 / count;
+    const float m = s_mean[el] + d;
+    const float v = fmaxf(s1 / count - d * d, 0.f);
+    if (moving_mean) {
+      moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * m;
+      moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * v;
+    }
+    mean[c] = m;
+    inv[c] = 1.0f / sqrtf(v + eps);
+  }
+}
+
 __device__ __forceinline__ float prelu(float x, float a) { return x > 0.f ? x : a * x; }
 
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z, int64_t ldz, int64_t n, int32_t f,
@@ -384,6 +431,12 @@ int gcnx_bn_moments(gcnx_ctx* ctx, const float* z, int64_t ldz, int64_t n, int32
   if (rc) return rc;
   const int vec = (int)(al16(z) && ldz % 4 == 0);
   dim3 gs(gcnx_cdiv(f, 64), nchunks), gr(gcnx_cdiv(f, 64));
+  if (nchunks == 1) {                                  // a batch of at most kRows rows: both passes in one launch, same bits
+    hipLaunchKernelGGL(bn_moments_small_kernel, gr, dim3(256), 0, ctx->stream, z, ldz, n, f, momentum, eps, (float*)ctx->ws, mean, inv,
+                       moving_mean, moving_var, vec);
+    GCNX_LAUNCH_OK(ctx);
+    return GCNX_OK;
+  }
   // pass 1: mean.  pass 2: variance of the data centred on that mean (two-pass, like tf.nn.moments)
   hipLaunchKernelGGL(bn_stats_kernel, gs, dim3(256), 0, ctx->stream, z, ldz, n, f, (const float*)nullptr, (float*)ctx->ws, vec);
   GCNX_LAUNCH_OK(ctx);

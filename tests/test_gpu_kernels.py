@@ -147,12 +147,13 @@ def test_side_sections_order_and_capture(ctx):
         assert ctx.lib.gcnx_side_begin(ctx.h) == 1
 
 
-def test_bn_moments_equals_stats_finalize_pairs(ctx):
-    """gcnx_bn_moments (4 launches) is bit-identical to bn_stats + bn_finalize taken twice (6 launches), and matches
-    numpy's two-pass moments; the moving statistics get the Keras momentum update."""
+@pytest.mark.parametrize("n,f", [(20001, 200), (32, 256), (256, 130), (7, 2)])
+def test_bn_moments_equals_stats_finalize_pairs(ctx, n, f):
+    """gcnx_bn_moments (4 launches; ONE for a batch of at most 256 rows -- the post-MLP of GeneralGNN runs on one row per graph)
+    is bit-identical to bn_stats + bn_finalize taken twice (6 launches), and matches numpy's two-pass moments; the moving
+    statistics get the Keras momentum update."""
     from gcnx import device as D
     rng = np.random.default_rng(21)
-    n, f = 20001, 200
     z = (rng.standard_normal((n, f)) * 3 + 50).astype(np.float32)     # large mean: the centred pass matters
     dz = ctx.to_device(z)
     mean, inv, sums = ctx.empty(f), ctx.empty(f), ctx.empty(2 * f)
