@@ -373,6 +373,71 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     st4g(dz + r * lddz + c, grad(ld4g(dy + r * lddy + c, v4, valid), ld4g(z + r * ldz + c, v4, valid)), v4, valid);
 }
 
+// gcnx_bn_act_bwd for a batch of at most kRows rows in ONE launch (the post-MLP of GeneralGNN: one row per graph): a
+// workgroup owns 64 columns -- the three column sums (bn_bwd_stats_kernel's terms and order), their single-chunk
+// "reduction" and the parameter gradients (part_reduce_kernel's arithmetic), then dz for its columns
+// (bn_bwd_apply_kernel's arithmetic per element) -- the bits of the three-launch sequence.  dz may alias dy.
+__global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z,
+                                                               int64_t ldz, int64_t n, int32_t f, const float* __restrict__ mean,
+                                                               const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act, const float* __restrict__ alpha,
+                                                               float* __restrict__ part, float* __restrict__ sums, float* __restrict__ dbeta,
+                                                               float* __restrict__ dgamma, float* __restrict__ dalpha, int training,
+                                                               float* __restrict__ dz, int64_t lddz, int vec) {
+  __shared__ float s_sum[2][64];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cl * 4;
+  const int valid0 = f - c;
+  BnCols q{};
+  if (valid0 > 0) q = bn_cols(mean, inv, gamma, beta, alpha, act, c, valid0);
+  colsums<3>(n, f, part, vec && (int)blockIdx.x * 64 + 64 <= f, [&](int64_t r, int cc, int valid, float4 (&t)[3], auto fast) {
+    const bool v4 = decltype(fast)::value || (vec && valid >= 4);
+    const float4 d = ld4g(dy + r * lddy + cc, v4, valid), zz = ld4g(z + r * ldz + cc, v4, valid);
+    float4 xh;
+    bn_bwd_terms(d.x, zz.x, q.mu.x, q.iv.x, q.ga.x, q.be.x, q.al.x, act, t[0].x, xh.x, t[2].x);
+    bn_bwd_terms(d.y, zz.y, q.mu.y, q.iv.y, q.ga.y, q.be.y, q.al.y, act, t[0].y, xh.y, t[2].y);
+    bn_bwd_terms(d.z, zz.z, q.mu.z, q.iv.z, q.ga.z, q.be.z, q.al.z, act, t[0].z, xh.z, t[2].z);
+    bn_bwd_terms(d.w, zz.w, q.mu.w, q.iv.w, q.ga.w, q.be.w, q.al.w, act, t[0].w, xh.w, t[2].w);
+    t[1] = make_float4(t[0].x * xh.x, t[0].y * xh.y, t[0].z * xh.z, t[0].w * xh.w);
+  });
+  __syncthreads();                                   // this workgroup's columns of `part`: written by its own threads
+  if (threadIdx.x < 192) {                           // part_reduce_kernel with one chunk: (x + 0) + (0 + 0)
+    const int k = threadIdx.x >> 6, el = threadIdx.x & 63, col = blockIdx.x * 64 + el;
+    if (col < f) {
+      const float v = ((0.f + part[(int64_t)k * f + col]) + 0.f) + (0.f + 0.f);
+      sums[(int64_t)k * f + col] = v;
+      float* extra = k == 0 ? dbeta : (k == 1 ? dgamma : dalpha);
+      if (extra) extra[col] = v;
+      if (k < 2) s_sum[k][el] = v;
+    }
+  }
+  __syncthreads();
+  if (valid0 <= 0) return;
+  const bool v4 = vec && valid0 >= 4;
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  if (training) {
+    const float ic = 1.0f / (float)n;
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = j < valid0 ? s_sum[0][cl * 4 + j] * ic : 0.f; b[j] = j < valid0 ? s_sum[1][cl * 4 + j] * ic : 0.f; }
+    s1 = make_float4(a[0], a[1], a[2], a[3]);
+    s2 = make_float4(b[0], b[1], b[2], b[3]);
+  }
+  for (int64_t r = rg; r < n; r += 16) {
+    const float4 d = ld4g(dy + r * lddy + c, v4, valid0), zz = ld4g(z + r * ldz + c, v4, valid0);
+    float4 g, xh, unused, o;
+    bn_bwd_terms(d.x, zz.x, q.mu.x, q.iv.x, q.ga.x, q.be.x, q.al.x, act, g.x, xh.x, unused.x);
+    bn_bwd_terms(d.y, zz.y, q.mu.y, q.iv.y, q.ga.y, q.be.y, q.al.y, act, g.y, xh.y, unused.y);
+    bn_bwd_terms(d.z, zz.z, q.mu.z, q.iv.z, q.ga.z, q.be.z, q.al.z, act, g.z, xh.z, unused.z);
+    bn_bwd_terms(d.w, zz.w, q.mu.w, q.iv.w, q.ga.w, q.be.w, q.al.w, act, g.w, xh.w, unused.w);
+    o.x = q.ga.x * q.iv.x * (g.x - s1.x - xh.x * s2.x);
+    o.y = q.ga.y * q.iv.y * (g.y - s1.y - xh.y * s2.y);
+    o.z = q.ga.z * q.iv.z * (g.z - s1.z - xh.z * s2.z);
+    o.w = q.ga.w * q.iv.w * (g.w - s1.w - xh.w * s2.w);
+    st4g(dz + r * lddz + c, o, v4, valid0);
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int reduce_parts(gcnx_ctx* ctx, int nchunks, int ns, int32_t f, float* out, float* o0 = nullptr, float* o1 = nullptr,
@@ -525,6 +590,19 @@ int gcnx_bn_act_bwd(gcnx_ctx* ctx, const float* dy, int64_t lddy, const float* z
                     const float* mean, const float* inv, const float* gamma, const float* beta, int act,
                     const float* alpha, int training, float* dz, int64_t lddz, float* dgamma, float* dbeta,
                     float* dalpha, float* sums_scratch) {
+  if (ctx && n > 0 && n <= kRows && f > 0 && dy && z && dz && mean && inv && gamma && beta && sums_scratch && lddy >= f && ldz >= f &&
+      lddz >= f && act >= GCNX_ACT_NONE && act <= GCNX_ACT_PRELU && (act != GCNX_ACT_PRELU || alpha)) {
+    // a batch of one chunk (the post-MLP's rows): statistics, their reduction and dz in one launch, the same bits
+    GCNX_CHECK_CTX(ctx);
+    GCNX_RANGE(ctx, "batch norm + activation backward (small batch)");
+    int rc1 = gcnx_ws_reserve(ctx, (size_t)3 * f * sizeof(float));
+    if (rc1) return rc1;
+    const int vec = al16(dy) && al16(z) && al16(dz) && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0;
+    hipLaunchKernelGGL(bn_act_bwd_small_kernel, dim3(gcnx_cdiv(f, 64)), dim3(256), 0, ctx->stream, dy, lddy, z, ldz, n, f, mean, inv, gamma,
+                       beta, act, alpha, (float*)ctx->ws, sums_scratch, dbeta, dgamma, dalpha, training, dz, lddz, vec);
+    GCNX_LAUNCH_OK(ctx);
+    return GCNX_OK;
+  }
   int rc = gcnx_bn_act_bwd_stats(ctx, dy, lddy, z, ldz, n, f, mean, inv, gamma, beta, act, alpha, sums_scratch, dgamma,
                                  dbeta, dalpha);
   if (rc || n == 0 || f == 0) return rc;

@@ -173,6 +173,45 @@ def test_bn_moments_equals_stats_finalize_pairs(ctx, n, f):
     assert rel_err(mm.numpy(), 0.99 * 0.5 + 0.01 * z64.mean(0)) < TIGHT
 
 
+@pytest.mark.parametrize("n,f,act", [(32, 256, "prelu"), (7, 2, None), (256, 130, "relu"), (3000, 96, "prelu")])
+def test_bn_act_bwd_one_call_equals_stats_plus_apply_and_the_oracle(ctx, n, f, act):
+    """gcnx_bn_act_bwd (ONE launch for a batch of at most 256 rows -- the post-MLP of GeneralGNN -- three otherwise) against its
+    two halves gcnx_bn_act_bwd_stats + gcnx_bn_act_bwd_apply (the sync-BN form) bit for bit: dz, the column sums, dgamma, dbeta,
+    dalpha; and against the oracle's batch-norm + activation backward in fp64.  In place (dz over dy) as the models call it."""
+    from gcnx import device as D
+    o = O()
+    rng = np.random.default_rng(n + f)
+    z = (rng.standard_normal((n, f)) * 2 + 1).astype(np.float32)
+    dy = rng.standard_normal((n, f)).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(f)).astype(np.float32); beta = (0.3 * rng.standard_normal(f)).astype(np.float32)
+    alpha = (0.25 * rng.random(f)).astype(np.float32) if act == "prelu" else None
+    z64 = z.astype(np.float64)
+    mean = z64.mean(0).astype(np.float32); inv = (1.0 / np.sqrt(z64.var(0) + 1e-3)).astype(np.float32)
+    dev = lambda a: None if a is None else ctx.to_device(a)
+    dm, di, dg, db_, da = dev(mean), dev(inv), dev(gamma), dev(beta), dev(alpha)
+    dzv = dev(z)
+    # one call, in place
+    d1 = dev(dy); s1 = ctx.zeros(3 * f); gg1, gb1, ga1 = ctx.zeros(f), ctx.zeros(f), (ctx.zeros(f) if act == "prelu" else None)
+    D.bn_act_bwd(ctx, d1, dzv, dm, di, dg, db_, d1, s1, act=act, alpha=da, training=True, dgamma=gg1, dbeta=gb1, dalpha=ga1)
+    # the two halves
+    d2 = dev(dy); s2 = ctx.zeros(3 * f); gg2, gb2, ga2 = ctx.zeros(f), ctx.zeros(f), (ctx.zeros(f) if act == "prelu" else None)
+    D.bn_act_bwd_stats(ctx, d2, dzv, dm, di, dg, db_, s2, act=act, alpha=da, dgamma=gg2, dbeta=gb2, dalpha=ga2)
+    D.bn_act_bwd_apply(ctx, d2, dzv, dm, di, dg, db_, s2, n, d2, act=act, alpha=da, training=True)
+    assert np.array_equal(d1.numpy(), d2.numpy()) and np.array_equal(s1.numpy()[:2 * f], s2.numpy()[:2 * f])
+    assert np.array_equal(gg1.numpy(), gg2.numpy()) and np.array_equal(gb1.numpy(), gb2.numpy())
+    if act == "prelu":
+        assert np.array_equal(ga1.numpy(), ga2.numpy())
+    # oracle (fp64), with the same mean / inv
+    xhat = (z64 - mean.astype(np.float64)) * inv.astype(np.float64)
+    zb = gamma.astype(np.float64) * xhat + beta.astype(np.float64)
+    dy64 = dy.astype(np.float64)
+    dzb = o.act_bwd(dy64, zb, act, None if alpha is None else alpha.astype(np.float64))
+    ref, rgam, rbet = o.bn_bwd(dzb, {"xhat": xhat, "inv": inv.astype(np.float64), "training": True}, gamma.astype(np.float64))
+    assert rel_err(d1.numpy(), ref) < 2e-5 and rel_err(gg1.numpy(), rgam) < 2e-5 and rel_err(gb1.numpy(), rbet) < 2e-5
+    if act == "prelu":
+        assert rel_err(ga1.numpy(), (dy64 * np.minimum(zb, 0)).sum(0)) < 2e-5
+
+
 def test_new_entry_points_zero_sizes_and_argument_errors(ctx):
     """Edge cases of the entry points added for the fused head, side sections, BN moments and the device collate:
     empty inputs are no-ops (or zero the outputs), bad arguments come back as GCNX_ERR_INVALID with a message."""
