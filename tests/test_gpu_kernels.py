@@ -433,7 +433,8 @@ def test_spmm_balanced_deal_of_the_tile_graphs_changes_no_bit(ctx):
     assert rel_err(res[1][1], _ref_spmm(hb, None, h)) < TIGHT
 
 
-@pytest.mark.parametrize("n,fi,fo", [(1000, 128, 128), (77, 10, 6), (4096, 256, 256), (333, 32, 2), (65, 130, 70)])
+@pytest.mark.parametrize("n,fi,fo", [(1000, 128, 128), (77, 10, 6), (4096, 256, 256), (333, 32, 2), (65, 130, 70),
+                                     (32, 1280, 256), (5, 256, 2), (64, 67, 130), (1, 64, 1)])     # (few rows: the thin kernel)
 def test_gemm_forward_parity(ctx, n, fi, fo):
     from gcnx import device as D
     rng = np.random.default_rng(n)
