@@ -565,7 +565,7 @@ __device__ __forceinline__ void tile_dma32_asm(unsigned lds_byte, const float* _
       const unsigned off = (unsigned)(i / PPR) * ld32 + (unsigned)(i % PPR) * 4u;
       const float* src = gbase + off;
       const unsigned base = __builtin_amdgcn_readfirstlane(lds_byte + (unsigned)(u * THREADS + (tid & ~63)) * 16u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "memory");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "memory", "m0");
     }
   }
 }
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
             while (__builtin_amdgcn_ballot_w64(deg > base) != 0) {
               int xc[4];
               float xv[4];
-              fetch_entries<WEIGHTED, 1>(ebufs, ea + base, slot, ea + deg, g.x, CAP, xc, xv);
+              fetch_entries<WEIGHTED, 1>(ebufs, ea + base, slot, ea + deg, g.x, pad, xc, xv);
               unsigned xp[2] = {(unsigned)xc[0] | ((unsigned)xc[1] << 16), (unsigned)xc[2] | ((unsigned)xc[3] << 16)};
               GCNX_DSTEP4(0, xp, xv, deg, base)
               GCNX_DSTEP4(1, xp, xv, deg, base)
@@ -958,7 +958,7 @@ struct PipeItem { int row0, ng; };                    // graph rows [row0, row0 
 // LDS-DMA of one 16-byte piece per lane (see above why not the builtin).  lds_base: wave-uniform byte address (M0); the
 // DMA adds lane * 16.
 __device__ __forceinline__ void pipe_dma16(const float* gptr, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_base) : "memory", "m0");
 }
 // LDS address of an entry's row: base + (16-bit half of packed) * row_bytes, one instruction.
 template <int HI>
@@ -1580,9 +1580,13 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
       if (dhubs) (void)hipFree(dhubs);
       return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_plan_bind: %s", hipGetErrorString(e));
     }
-    if (slot->dev) (void)hipFree(slot->dev);
-    if (slot->hub_segs) (void)hipFree(slot->hub_segs);
-    if (slot->hub_rows) (void)hipFree(slot->hub_rows);
+    // (a captured graph may hold the old arrays in its kernel arguments -- e.g. a step captured on this rowptr before a
+    // re-bind: like a workspace block that had to grow they are retired, not freed, while any graph is alive)
+    for (void* old : {(void*)slot->dev, (void*)slot->hub_segs, (void*)slot->hub_rows}) {
+      if (!old) continue;
+      if (ctx->live_graphs > 0) ctx->retired_ws.push_back(old);
+      else (void)hipFree(old);
+    }
     slot->rowptr = rowptr; slot->dev = dev; slot->n = n;
     slot->hub_segs = dsegs; slot->hub_rows = dhubs;
     slot->nhubs = (int)hubs.size(); slot->nsegs = (int)segs.size(); slot->nhubs_tall = nh_tall; slot->nsegs_tall = ns_tall;
@@ -1802,9 +1806,10 @@ int gcnx_spmm_plan_destroy(gcnx_ctx* ctx, gcnx_spmm_plan* plan) {
 int gcnx_spmm_plan_bind(gcnx_ctx* ctx, gcnx_spmm_plan* plan, const int32_t* rowptr, int32_t n) {
   GCNX_CHECK_CTX(ctx);
   GCNX_REQUIRE(ctx, plan && rowptr && n >= 0, "gcnx_spmm_plan_bind: NULL plan / rowptr");
-  GCNX_REQUIRE(ctx, !ctx->capturing, "gcnx_spmm_plan_bind synchronises and cannot be captured");
   const RowRec* unused = nullptr;
-  return plan_order(ctx, plan, rowptr, n, true, &unused);
+  // inside a capture: an order already bound to this rowptr stands (nothing can be rebuilt here, and a captured sequence
+  // that binds is a sequence that ran eagerly first); one that is missing fails in plan_order with its own message
+  return plan_order(ctx, plan, rowptr, n, !ctx->capturing, &unused);
 }
 
 static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* vals, const float* h,

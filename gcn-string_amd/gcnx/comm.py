@@ -7,7 +7,8 @@ LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment -- torch is never imported
 lives in the process.  Rank 0 creates the RCCL unique id and publishes it through an atomically renamed file whose
 name is keyed by an id the LAUNCHER hands to every rank: ``GCNX_RUN_ID`` (a fresh uuid per launch: bench.py's own
 launcher, or any other launcher that exports it), else torchrun's run id + restart count + MASTER_PORT together with
-the elastic agent's pid (the one parent torchrun guarantees its workers share).  Single node by contract.
+the elastic agent's pid (the one parent torchrun guarantees its workers share), else MASTER_PORT alone (launchers that put
+a wrapper shell around every rank share no parent); a file older than the launch is never accepted.  Single node by contract.
 """
 from __future__ import annotations
 
@@ -34,9 +35,13 @@ def _rendezvous_path(env=None):
         key = f"{run_id}_{port}"
     elif "TORCHELASTIC_RUN_ID" in env:               # torchrun: its workers are children of ONE elastic agent
         key = f"{env['TORCHELASTIC_RUN_ID']}_{env.get('TORCHELASTIC_RESTART_COUNT', '0')}_{port}_{os.getppid()}"
-    else:                                            # some other launcher that exported neither: its pid (the ranks' common
-        key = f"port{port}_{os.getppid()}"           # parent) keeps a crashed earlier run's file on the same port from matching
-    return os.path.join(tempfile.gettempdir(), f"gcnx_uid_{key}")
+    else:                                            # some other launcher that exported neither (mpirun / srun behind per-rank
+        key = f"port{port}"                          # wrapper shells: no common parent pid to key on) -- the ranks meet on the port;
+    return os.path.join(tempfile.gettempdir(), f"gcnx_uid_{key}")   # a crashed earlier run's file is told apart by its age (below)
+
+
+_T_IMPORT = time.time()          # this rank's start, to within the interpreter's start-up
+_STALE_SLACK_S = 20.0            # ranks of one launch start within this of each other
 
 
 def _rccl_unique_id():
@@ -54,15 +59,18 @@ def exchange_unique_id(rank, world_size, timeout_s=120.0, path=None, make_id=_rc
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as fh:
             fh.write(raw)
-        os.replace(tmp, path)
+        os.replace(tmp, path)                        # atomically over whatever an earlier run left under this key
         return raw
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as fh:
-                raw = fh.read()
-            if len(raw) == L.UNIQUE_ID_BYTES:
-                return raw
+            # a file older than this launch is a crashed earlier run's (rank 0 removes its file after the first barrier; a run
+            # that died before that leaves it): never this launch's id, whose file is written after the ranks have started
+            if os.path.getmtime(path) >= _T_IMPORT - _STALE_SLACK_S:
+                with open(path, "rb") as fh:
+                    raw = fh.read()
+                if len(raw) == L.UNIQUE_ID_BYTES:
+                    return raw
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout_s:

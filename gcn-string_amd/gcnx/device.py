@@ -296,11 +296,24 @@ class DeviceCSR:
             p = _Plan(self.ctx, h)
             holder._spmm_plan = p
         if self._plan is not p:
-            # the tile kernels' degree order of THIS operator's rows (gcnx_spmm_plan_bind: synchronises, so it happens here,
-            # once per view, and never inside a captured call)
-            self.ctx._ck(self.ctx.lib.gcnx_spmm_plan_bind(self.ctx.h, p.h, self.rowptr.ptr, self.n))
+            # the tile kernels' degree order of THIS operator's rows (gcnx_spmm_plan_bind: synchronises and rebuilds, so it
+            # happens here, ONCE per (plan, rowptr) -- the normalised / unweighted / row-mean views share rowptr and with it
+            # the order -- and never inside a captured call: a view created inside a captured sequence finds the order bound)
+            key = (self.rowptr.ptr, self.n)
+            if key not in p.bound:
+                self.ctx._ck(self.ctx.lib.gcnx_spmm_plan_bind(self.ctx.h, p.h, self.rowptr.ptr, self.n))
+                p.bound.add(key)
             self._plan = p
         return p.h
+
+    def rebind(self):
+        """The row pointers behind ``rowptr`` were rewritten in place: rebuild the plan's row order for them
+        (gcnx_spmm_plan_bind, case (b) of include/gcnx.h).  Not inside a captured sequence."""
+        self._plan = None
+        p = getattr(self.block_ptr, "_spmm_plan", None) if self.block_ptr is not None else None
+        if p is not None:
+            p.bound.discard((self.rowptr.ptr, self.n))
+        return self.plan
 
     @classmethod
     def from_host_csr(cls, ctx, rowptr, colidx, vals=None, graph_ptr=None, symmetric=None):
@@ -361,14 +374,20 @@ class DeviceCSR:
         return self._row_mean
 
     def unweighted(self):
-        """Same structure, values ignored (GeneralConv aggregation)."""
-        return DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, None, self.block_ptr, self.n_blocks,
-                         self.symmetric)
+        """Same structure, values ignored (GeneralConv aggregation).  One view per operator (as row_mean): the models ask
+        for it inside their step sequence, and a view keeps its transposed CSR and its plan binding."""
+        if self.vals is None:
+            return self
+        if getattr(self, "_unweighted", None) is None:
+            self._unweighted = DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, None, self.block_ptr, self.n_blocks,
+                                         self.symmetric)
+        return self._unweighted
 
 
 class _Plan:
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        self.bound = set()          # (rowptr pointer, n) pairs whose row order the plan holds
 
     def __del__(self):
         try:

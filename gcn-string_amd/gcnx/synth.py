@@ -133,6 +133,8 @@ def ecoli_batch(n_graphs=32, f=128, seed=1):
 
 def _lognormal_sizes(rng, total, mean_size, lo, hi):
     b = max(1, int(round(total / mean_size)))
+    if b * lo > total or b * hi < total:
+        raise ValueError(f"{b} graphs of {lo}..{hi} nodes cannot hold {total} nodes (mean_size={mean_size})")
     s = np.clip(rng.lognormal(np.log(mean_size), 0.5, size=b), lo, hi)
     s = np.maximum(lo, np.floor(s * (total / s.sum()))).astype(np.int64)
     diff = int(total - s.sum())

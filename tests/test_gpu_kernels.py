@@ -1769,3 +1769,57 @@ def test_round3_entry_points_refuse_bad_arguments_loudly(ctx):
     assert ctx.lib.gcnx_last_error(ctx.h) == err_before
     assert not D.spmm_bf16out(ctx, a, h, None, ctx.empty((n, 32), np.uint16))
     assert not D.gemm_dx_bf16(ctx, ctx.zeros((1000, 256), np.uint16), w, ctx.empty((1000, 256), np.uint16))
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_double_buffered_tiles_with_rows_past_the_register_held_entries(ctx, weighted):
+    """in a double-buffered unit (graphs of <= 624 rows on the 1024-thread tile shape) the on-demand
+    fetch of a row's entries past the 32 / 16 held in registers must pad with the CURRENT buffer's zero row -- it padded with
+    the single-tile zero row, an LDS address outside the allocation when the unit sits in the second buffer.  Many graphs of
+    100..600 rows, each with a few rows of 40..250 entries, f = 256 (eight slabs per unit: every unit prefetches): the tile
+    kernels against the row gather, which adds a row's entries in the same (CSR) order -- bit for bit -- and the oracle."""
+    from gcnx import device as D, synth
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    sizes = rng.integers(100, 601, size=160)
+    sizes[:4] = (624, 600, 101, 320)
+    blocks = []
+    for i, m in enumerate(sizes):
+        a = sp.random(m, m, density=min(1.0, 8.0 / m), random_state=i, format="lil")
+        for r in rng.choice(m, size=3, replace=False):                 # a few long rows per graph
+            deg = int(rng.integers(40, min(230, m - 1) + 1))
+            a[r, rng.choice(m, size=deg, replace=False)] = 1.0
+        a = a.tocsr()
+        a = ((a + a.T) > 0).astype(np.float32) + sp.identity(m, dtype=np.float32, format="csr")
+        blocks.append((a > 0).astype(np.float32))
+    a = sp.block_diag(blocks).tocsr(); a.sort_indices()
+    n = a.shape[0]
+    gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    f = 256
+    hb = synth.HostBatch(rng.standard_normal((n, f), dtype=np.float32), a.indptr.astype(np.int32), a.indices.astype(np.int32),
+                         None, gp, np.zeros((len(sizes), 2), np.float32))
+    deg = np.diff(hb.rowptr)
+    # (<= 256 entries: longer rows the row gather splits over its four waves -- another summation order)
+    assert 200 < deg.max() <= 256 and (deg > 32).sum() >= 3 * len(sizes)
+    csr, vals = _csr(ctx, hb, weighted)
+    assert csr.plan is not None
+    bias = rng.standard_normal(f).astype(np.float32)
+    h, db = ctx.to_device(hb.x), ctx.to_device(bias)
+    outs = {}
+    try:
+        for kernel in ("tile", "rows"):
+            ctx.set_tuning("spmm_kernel", kernel)
+            o = ctx.zeros((n, f))
+            D.spmm(ctx, csr, h, db, o, act="relu")
+            outs[kernel] = o.numpy()
+        # the bit-image form (kDuoBitsOut: double-buffered too) writes the same rows
+        ctx.set_tuning("spmm_kernel", "tile")
+        o = ctx.zeros((n, f))
+        bits = ctx.zeros((f // 32) * n, np.int32)
+        assert D.spmm_relu_bits(ctx, csr, h, db, o, bits)
+        outs["bits"] = o.numpy()
+    finally:
+        ctx.set_tuning("spmm_kernel", "auto")
+    assert np.array_equal(outs["tile"], outs["rows"])
+    assert np.array_equal(outs["bits"], outs["rows"])
+    assert rel_err(outs["tile"], _ref_spmm(hb, vals, hb.x, bias, True)) < TIGHT

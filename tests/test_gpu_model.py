@@ -1270,3 +1270,41 @@ def test_learning_rate_from_a_device_scalar_serves_a_schedule_with_one_captured_
     p = ctx.to_device(np.ones(8, np.float32)); g = ctx.to_device(np.ones(8, np.float32))
     D.sgd(ctx, p, g, 0.5)                                  # the context is back on by-value rates after a model's step
     assert np.array_equal(p.numpy(), np.full(8, 0.5, np.float32))
+
+
+def test_general_gnn_captured_step_on_a_batch_with_a_tile_plan(ctx):
+    """a batch of >= 128 graphs gets a gcnx_spmm_plan, whose per-rowptr row order must be bound OUTSIDE
+    stream capture.  GeneralGNN asks for the unweighted view of the adjacency inside its step sequence; the view (and with
+    it the binding) is now one object per operator, and binding is once per (plan, rowptr) -- so the second train_step,
+    which captures, finds the order bound.  Three captured steps equal three eager steps; a GCN2 step captured on the
+    same batch before keeps replaying correctly after the GeneralGNN has bound its own view (retired, not freed, arrays)."""
+    from gcnx import synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GCN2, GeneralGNN
+    rng = np.random.default_rng(5)
+    hb = synth.block_diag_batch(12000, 120000, 16, seed=7, mean_size=80)
+    assert hb.n_graphs >= 128
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    assert a.plan is not None and a.unweighted() is a.unweighted() and a.unweighted().plan == a.plan
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+    g2 = GCN2(ctx, 2, hidden=64, use_graph=True)
+    for _ in range(3):
+        g2.train_step(batch, None, lr=0.0)
+    ref2 = g2.gradients()
+    runs = {}
+    for use_graph in (False, True):
+        m = GeneralGNN(ctx, 2, activation="softmax", hidden=64, message_passing=2, use_graph=use_graph, seed=3)
+        out = [m.train_step(batch, None, lr=0.01) for _ in range(3)]
+        runs[use_graph] = (out, m.get_weights())
+    for (le, ae), (lg, ag) in zip(runs[False][0], runs[True][0]):
+        assert le == lg and ae == ag
+    for we, wg in zip(runs[False][1], runs[True][1]):
+        assert np.array_equal(we, wg)
+    # an explicit re-bind of the operator (row pointers "changed in place") while the GCN2 graph is alive: the graph still
+    # replays into valid arrays
+    a.rebind()
+    g2.train_step(batch, None, lr=0.0)
+    again = g2.gradients()
+    for k in ref2:
+        assert np.array_equal(again[k], ref2[k]), k

@@ -234,6 +234,29 @@ def test_bench_launcher_starts_ranks_itself_and_rendezvous_is_keyed_by_the_launc
     p3 = comm._rendezvous_path({"TORCHELASTIC_RUN_ID": "none", "TORCHELASTIC_RESTART_COUNT": "1", "MASTER_PORT": "29500"})
     assert p1.endswith("gcnx_uid_abc_29500") and str(os.getppid()) not in os.path.basename(p1)
     assert p2 != p3 and os.path.basename(p2).endswith(f"_{os.getppid()}")
+    # a launcher that exports neither (per-rank wrapper shells: no common parent): the ranks meet on the port alone ...
+    p4 = comm._rendezvous_path({"MASTER_PORT": "29511"})
+    assert os.path.basename(p4) == "gcnx_uid_port29511"
+    # ... and a crashed earlier run's file under that key is never taken for this launch's id: rank 1 ignores a stale file
+    # (older than the launch) and picks up the one rank 0 writes over it
+    import threading
+    import time
+    path = str(tmp_path / "gcnx_uid_port29511")
+    stale = b"S" * comm.L.UNIQUE_ID_BYTES
+    with open(path, "wb") as fh:
+        fh.write(stale)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    with pytest.raises(TimeoutError):
+        comm.exchange_unique_id(1, 2, timeout_s=0.3, path=path)
+    fresh = b"F" * comm.L.UNIQUE_ID_BYTES
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("raw", comm.exchange_unique_id(1, 2, timeout_s=20, path=path)))
+    t.start()
+    time.sleep(0.2)
+    assert comm.exchange_unique_id(0, 2, path=path, make_id=lambda: fresh) == fresh
+    t.join(30)
+    assert got.get("raw") == fresh
 
 
 def test_shardable_generators_do_not_depend_on_the_number_of_ranks():
