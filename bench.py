@@ -338,6 +338,78 @@ def generalgnn_extra(ctx, steps=60):
     return out
 
 
+CONFIG3_STEP_1GPU_MS = {"value": 2.84, "source": "BENCH_r03.json config3_step (round 3, one MI355X, bf16 operands)"}
+
+
+def config4_plan(world):
+    """The strong-scaling cut of BASELINE config 4: per-rank (graphs, nodes, entries) of the config-3 batch as
+    shard.partition_by_cost deals it to `world` ranks -- from the graphs' sizes alone, no graph is built."""
+    from gcnx import shard, synth
+    sizes, pairs = synth.block_diag_plan(1_000_000, 10_000_000, seed=2)
+    bounds = shard.partition_by_cost(sizes + 2 * pairs + sizes, world)
+    return [{"rank": r, "graphs": int(bounds[r + 1] - bounds[r]), "nodes": int(sizes[bounds[r]:bounds[r + 1]].sum()),
+             "entries": int((sizes + 2 * pairs)[bounds[r]:bounds[r + 1]].sum())} for r in range(world)], int(len(sizes))
+
+
+def config4_extra(ctx, comm, rank, world, lr, use_graph, steps=20, burn=30):
+    """Extra key of an N > 1 line: BASELINE config 4 -- the config-3 batch (1M nodes / 10M entries /
+    F = 256, hidden 256, bf16 weight-GEMM operands) STRONG-scaled over the N ranks: every rank builds and holds its shard
+    (contiguous graph range, cost-balanced), the step is forward + CCE + all gradients + the RCCL all-reduce + SGD, loss
+    normalised by the global batch.  Timed like the main line (barrier + sync on both sides, max over ranks).  The one-GPU
+    reference it is compared with is measured in the same run: rank 0 runs the whole batch's step alone while the other
+    ranks wait at a barrier (their GPUs idle); the committed round-3 figure is reported next to it."""
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GCN2
+    prec = CONFIG_PREC["block1m"]
+
+    def timed(hb, global_graphs, cm, k_burn, k_steps):
+        a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, hb.vals, hb.graph_ptr)
+        batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+        m = GCN2(ctx, 2, hidden=256, prec=prec, seed=0, comm=cm, use_graph=use_graph)
+        m.build(hb.f)
+        for k in range(3 + k_burn):                      # eager, capture, replay; then the untimed burn-in (a fixed count:
+            m.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)   # every step holds a collective)
+            drain(ctx, k)
+        if cm is not None:
+            cm.barrier()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for k in range(k_steps):
+            m.train_step(batch, None, lr=lr, global_batch=global_graphs, fetch=False)
+            drain(ctx, k)
+        ctx.sync()
+        if cm is not None:
+            cm.barrier()
+        el = time.perf_counter() - t0
+        loss, acc = m.fetch_metrics(global_graphs)
+        return el, loss, m, batch
+
+    hb, _, global_graphs = make_shard("block1m", rank, world, "strong")
+    el, loss, m_keep, b_keep = timed(hb, global_graphs, comm, burn, steps)
+    el = float(comm.allreduce_host([el], "max")[0])
+    ms = 1e3 * el / steps
+    nodes = comm.allreduce_host([hb.n, hb.nnz], "max")
+    out = {"workload": f"config4: the config-3 batch (1M nodes / 10M entries / F=256, {global_graphs} graphs) sharded over {world} GPUs "
+                       f"(contiguous graph ranges balanced on entries + nodes), hidden=256, weight GEMMs {prec}, fwd + CCE + all "
+                       f"gradients + RCCL all-reduce + SGD", "scaling": "strong", "n_gpus": world, "steps": steps, "burn_in_steps": burn,
+           "ms_per_step": ms, "graphs_per_s": global_graphs / (ms * 1e-3), "nodes_per_s": 1_000_000 / (ms * 1e-3),
+           "largest_shard": {"nodes": int(nodes[0]), "entries": int(nodes[1])}, "final_loss": loss,
+           "all_reduce": "inside the step graph" if m_keep._comm_in_graph() else "eager between two graphs", "hip_graph": use_graph}
+    # the one-GPU step of the same batch, on rank 0, the other GPUs idle
+    one_ms = None
+    if rank == 0:
+        hb1, _, _ = make_shard("block1m", 0, 1, "strong")
+        el1, loss1, m1, b1 = timed(hb1, global_graphs, None, burn, steps)
+        one_ms = 1e3 * el1 / steps
+        out["one_gpu_same_run"] = {"ms_per_step": one_ms, "graphs_per_s": global_graphs / (one_ms * 1e-3), "final_loss": loss1,
+                                   "what": "rank 0 alone on the whole batch, the other ranks waiting at a barrier"}
+        out["speedup_vs_one_gpu_same_run"] = one_ms / ms
+        out["speedup_vs_committed_1gpu"] = CONFIG3_STEP_1GPU_MS["value"] / ms
+        out["committed_1gpu"] = CONFIG3_STEP_1GPU_MS
+    comm.barrier()
+    return out
+
+
 def time_spmm(ctx, D, a, h, bias, out, iters):
     for _ in range(5):
         D.spmm(ctx, a, h, bias, out, act="relu")
@@ -378,6 +450,8 @@ def main():
                          "this one GPU without a communicator; scripts/scaling_proxy.py takes the max over R against the 1-GPU step")
     ap.add_argument("--of", type=int, default=8, metavar="N", help="world size --emulate-rank cuts the workload for")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-config4", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the extra config-4 (strong-scaled 1M-node batch) reading")
     args = ap.parse_args()
     if args.prec is None:
         args.prec = CONFIG_PREC[args.workload]
@@ -392,6 +466,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          f"or plainly as `python bench.py --gpus {args.gpus}`")
     if args.selftest_launcher:
+        sys.exit(launcher_selftest(rank, world))
+    if args.selftest_config4:
+        # CPU-only check (tests/test_host.py) that an N > 1 line carries the config4_step key and what it is cut into: the ranks
+        # meet through the launcher's rendezvous like the real run, rank 0 prints the line's skeleton with the shard plan
+        if rank == 0:
+            plan, b = config4_plan(world)
+            print(json.dumps({"selftest": "config4", "n_gpus": world, "scaling_of_main_line": args.scaling or "weak",
+                              "config4_step": {"scaling": "strong", "n_gpus": world, "global_graphs": b, "shards": plan,
+                                               "ms_per_step": None, "graphs_per_s": None}}), flush=True)
         sys.exit(launcher_selftest(rank, world))
     knobs = env_knobs()
     if knobs and not args.allow_knobs:
@@ -579,6 +662,9 @@ def main():
     gnn_extra = None
     if world == 1 and args.workload == "ecoli" and args.emulate_rank is None and not args.no_generalgnn:
         gnn_extra = generalgnn_extra(ctx)
+    cfg4 = None
+    if world > 1 and args.workload == "ecoli" and not args.no_config4 and not args.no_config3:
+        cfg4 = config4_extra(ctx, comm, rank, world, lr, not args.no_graph)
     if rank == 0:
         small = hb.n < 128 * 1024
         tr, src = pmc_traffic(args.workload)
@@ -628,6 +714,8 @@ def main():
             rec["roofline_step_kernel"] = fused
         if gnn_extra is not None:
             rec["generalgnn"] = gnn_extra
+        if cfg4 is not None:
+            rec["config4_step"] = cfg4
         if big is not None:
             rec["roofline_config3"] = big
             rec["roofline_config3_bf16"] = big_bf16

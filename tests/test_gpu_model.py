@@ -1308,3 +1308,69 @@ def test_general_gnn_captured_step_on_a_batch_with_a_tile_plan(ctx):
     again = g2.gradients()
     for k in ref2:
         assert np.array_equal(again[k], ref2[k]), k
+
+
+def _device_relu_masks(ctx, m, hb, hidden=256):
+    """[Y1 > 0] and [Y2 > 0] of the GCN2 step that just ran, as the device holds them: Y1 as fp32 or (bf16 storage) bfloat16
+    rows; Y2 rows for the graphs taller than a tile, the bit image -- word (slab, row), bit = column -- for the others."""
+    from gcnx import device as _D
+    b = m._bufs
+    m1 = (_D.from_bf16(ctx, b["y1_16"]).numpy() if b.get("act16") else b["y1"].numpy()) > 0
+    m2 = b["y2"].numpy() > 0
+    if b.get("y2bits_ok"):
+        img = b["y2bits"].numpy().view(np.uint32).reshape(hidden // 32, hb.n)
+        from_bits = ((img.T[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(hb.n, hidden)
+        tile = np.repeat(np.diff(hb.graph_ptr) <= 1276, np.diff(hb.graph_ptr))
+        m2 = np.where(tile[:, None], from_bits, m2)
+    return m1, m2
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_config4_shards_of_the_1m_node_batch_sum_to_the_full_batch_step(ctx, prec):
+    """BASELINE config 4 (SURVEY 8(e) acceptance) on the one GPU there is: the config-3 batch (1M nodes,
+    10M entries, F = 256, 1 667 graphs) cut by gcnx.shard for world = 2, 4 and 8, every shard's step -- loss_and_grads with
+    the loss normalised by the GLOBAL batch, exactly what a rank runs before its all-reduce -- executed on device 0 one after
+    the other, the flat gradient buffers and the [loss, #correct] tail summed on the host in fp64 (what the RCCL all-reduce
+    does in fp32), against the single-rank step on the whole batch: <= 2e-5 of each tensor's largest entry.  Every row of a
+    shard is computed exactly as in the whole batch (rows sum in CSR order, a GEMM row does not depend on its tile), so the
+    ReLU masks must be IDENTICAL -- asserted: no kink noise can hide in the bound.  fp32 and config 3's bf16 operands."""
+    from gcnx import shard
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch
+    hb = _full_size_batch("block1m")
+    B = hb.n_graphs
+    m = GCN2(ctx, 2, hidden=256, seed=0, prec=prec, use_graph=False)
+    m.build(hb.f)
+    w0 = m.get_weights()
+
+    def step(part):
+        a = DeviceCSR.from_host_csr(ctx, part.rowptr, part.colidx, part.vals, part.graph_ptr)
+        batch = DeviceBatch(ctx, ctx.to_device(part.x), a, Segments(ctx, part.graph_ptr), ctx.to_device(part.y))
+        m.loss_and_grads(batch, None, global_batch=B)
+        flat = m.flat_g.numpy().astype(np.float64)                    # gradients + [loss sum / B, #correct]
+        masks = _device_relu_masks(ctx, m, part)
+        for arr in (batch.x, batch.y, a.rowptr, a.colidx, a.vals):
+            arr.free()
+        return flat, masks
+
+    full, (f1, f2) = step(hb)
+    assert f1.any() and f2.any()
+    sizes = {k: int(np.prod(w.shape)) for k, w in zip(ORDER, w0)}
+    for world in (2, 4, 8):
+        bounds = shard.partition_graphs(hb.graph_ptr, hb.rowptr, world, hb.f)
+        assert bounds[0] == 0 and bounds[-1] == B and np.all(np.diff(bounds) > 0)
+        cost = (np.diff(hb.rowptr.astype(np.int64)[hb.graph_ptr[bounds]]) + np.diff(hb.graph_ptr[bounds].astype(np.int64)))
+        assert cost.max() <= 1.02 * cost.mean(), (world, cost)         # cost-balanced contiguous ranges
+        total = np.zeros_like(full)
+        for r in range(world):
+            part = hb.slice_graphs(int(bounds[r]), int(bounds[r + 1]))
+            flat, (s1, s2) = step(part)
+            r0, r1 = int(hb.graph_ptr[bounds[r]]), int(hb.graph_ptr[bounds[r + 1]])
+            assert np.array_equal(s1, f1[r0:r1]) and np.array_equal(s2, f2[r0:r1]), (world, r)
+            total += flat
+        off = 0
+        for k in ORDER:
+            assert_close(total[off:off + sizes[k]], full[off:off + sizes[k]], 2e-5, f"config 4, {prec}, {world} shards summed: d{k}")
+            off += sizes[k]
+        assert abs(total[off] - full[off]) <= 2e-5 * abs(full[off]), (world, "loss")
+        assert total[off + 1] == full[off + 1], (world, "#correct")

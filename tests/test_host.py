@@ -259,6 +259,29 @@ def test_bench_launcher_starts_ranks_itself_and_rendezvous_is_keyed_by_the_launc
     assert got.get("raw") == fresh
 
 
+def test_bench_n_gpu_line_carries_the_config4_strong_scaling_key():
+    """`bench.py --gpus N` (N > 1) reports BASELINE config 4 -- the 1M-node batch strong-scaled over the
+    ranks -- as `config4_step` next to the weak-scaled headline.  CPU-side check through the real launcher: the key is emitted
+    and the cut it describes covers the batch in cost-balanced contiguous ranges (timings need GPUs: None here)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GCNX_RUN_ID")}
+    for world in (2, 8):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--selftest-config4"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        recs = [json.loads(l) for l in r.stdout.strip().splitlines()]
+        c4 = [x for x in recs if x.get("selftest") == "config4"][0]["config4_step"]
+        assert c4["scaling"] == "strong" and c4["n_gpus"] == world and len(c4["shards"]) == world
+        assert sum(s["graphs"] for s in c4["shards"]) == c4["global_graphs"]
+        assert sum(s["nodes"] for s in c4["shards"]) == 1_000_000 and sum(s["entries"] for s in c4["shards"]) == 10_000_000
+        cost = np.array([s["nodes"] + s["entries"] for s in c4["shards"]], np.float64)
+        assert cost.max() <= 1.02 * cost.mean()
+        assert [x for x in recs if x.get("selftest") == "launcher"][0]["ok"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'rec["config4_step"] = cfg4' in src and "config4_extra(ctx, comm, rank, world" in src
+
+
 def test_shardable_generators_do_not_depend_on_the_number_of_ranks():
     """bench.py: every rank builds only its own graphs; graph g comes from its own random stream, so the global
     batch is the same for every world size, and the per-graph sizes (all a partition needs) are available without
