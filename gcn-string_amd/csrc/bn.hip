@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256) void bn_moments_small_kernel(const float* __re
 }
 
 __device__ __forceinline__ float prelu(float x, float a) { return x > 0.f ? x : a * x; }
+// The activation's input, ONE expression for the forward and the backward kernels: zb = fma(z - mu, gamma * inv, beta) with
+// the scale rounded to fp32 first.  The backward pass picks the PReLU / ReLU branch from the zb it recomputes, so it must be
+// the very number the forward pass fed the activation -- with two different roundings (gamma * ((z - mu) * inv) + beta
+// there) a pre-activation within an ulp of zero could take one branch forward and the other backward.  It also makes the
+// branch reproducible on the host from (z, mu, inv, gamma, beta): sign(zb) = sign of the exact (z - mu) * sc + beta.
+__device__ __forceinline__ float bn_zb(float z, float mu, float sc, float be) { return __builtin_fmaf(z - mu, sc, be); }
 
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z, int64_t ldz, int64_t n, int32_t f,
                                                      const float* __restrict__ mean, const float* __restrict__ inv,
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z
   if (act == GCNX_ACT_PRELU) al = ld4g(alpha + c, false, valid);
   const float4 sc = make_float4(ga.x * iv.x, ga.y * iv.y, ga.z * iv.z, ga.w * iv.w);
   auto apply = [&](float4 v) {
-    float4 o = make_float4((v.x - mu.x) * sc.x + be.x, (v.y - mu.y) * sc.y + be.y, (v.z - mu.z) * sc.z + be.z,
-                           (v.w - mu.w) * sc.w + be.w);
+    float4 o = make_float4(bn_zb(v.x, mu.x, sc.x, be.x), bn_zb(v.y, mu.y, sc.y, be.y), bn_zb(v.z, mu.z, sc.z, be.z),
+                           bn_zb(v.w, mu.w, sc.w, be.w));
     if (act == GCNX_ACT_RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     else if (act == GCNX_ACT_PRELU) o = make_float4(prelu(o.x, al.x), prelu(o.y, al.y), prelu(o.z, al.z), prelu(o.w, al.w));
     return o;
@@ -293,7 +299,7 @@ __device__ __forceinline__ BnCols bn_cols(const float* mean, const float* inv, c
 __device__ __forceinline__ void bn_bwd_terms(float dy, float z, float mu, float iv, float ga, float be, float al, int act,
                                              float& dzb, float& xhat, float& dalpha) {
   xhat = (z - mu) * iv;
-  const float zb = ga * xhat + be;
+  const float zb = bn_zb(z, mu, ga * iv, be);          // the forward pass's number (bn_act_kernel), not ga * xhat + be
   dalpha = 0.f;
   if (act == GCNX_ACT_RELU) dzb = zb > 0.f ? dy : 0.f;
   else if (act == GCNX_ACT_PRELU) { dzb = zb > 0.f ? dy : al * dy; dalpha = dy * fminf(zb, 0.f); }

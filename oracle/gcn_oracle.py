@@ -481,15 +481,25 @@ def dense_bn_act_fwd(x, p, training, act, final_softmax=False, drop=None):
     return y, {"x": x, "zb": zb, "bn": bnc, "y": y, "drop": drop}, mm, mv
 
 
-def dense_bn_act_bwd(dy, cache, p, act, need_dx=True, dzb=None):
+def dense_bn_act_bwd(dy, cache, p, act, need_dx=True, dzb=None, pos=None):
     """Returns dx and grads {kernel,bias,gamma,beta,alpha?}.  ``dzb`` overrides the
-    activation backward (used for the fused softmax+CCE head)."""
+    activation backward (used for the fused softmax+CCE head).
+    ``pos`` (bool, shape of zb; test infrastructure): which side of the PReLU / ReLU kink every pre-activation is taken to
+    be on, instead of zb > 0.  The gradient of a piecewise-linear activation is discontinuous at zb = 0; an fp32 evaluation
+    whose zb differs from this fp64 one by rounding lands on the other side for the few entries within rounding of zero,
+    and each such entry moves a gradient by a whole term.  Comparing a device run with this backward evaluated on the
+    DEVICE's side of every kink separates arithmetic error from that kink noise (the flips themselves are bounded by the
+    caller: a flipped entry must lie within the precision's reach of zero)."""
     g = {}
     zb = cache["zb"]
     if dzb is None:
+        if pos is None:
+            pos = zb > 0
         if act == "prelu":
-            g["alpha"] = (dy * np.minimum(zb, 0)).sum(0)
-            dzb = act_bwd(dy, zb, "prelu", p["alpha"])
+            g["alpha"] = (dy * np.where(pos, 0.0, zb)).sum(0)
+            dzb = dy * np.where(pos, 1.0, p["alpha"]).astype(dy.dtype)
+        elif act == "relu":
+            dzb = dy * pos
         else:
             dzb = act_bwd(dy, zb, act)
     if cache.get("drop") is not None:
@@ -618,8 +628,12 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
 
 
 def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mode="logits", aggregate="sum", pool="sum",
-                               connectivity="cat", hidden_activation="prelu", drops=None):
+                               connectivity="cat", hidden_activation="prelu", drops=None, masks=None):
+    """masks (optional; see dense_bn_act_bwd's ``pos``): {"pre": [...], "gnn": [...], "post": [...]} boolean arrays, one per
+    layer with a hidden activation (None entries: the layer's own zb > 0) -- the side of every activation kink the backward
+    pass is evaluated on."""
     rowptr, colidx, _ = csr
+    mask = (lambda grp, k: None) if masks is None else (lambda grp, k: masks[grp][k] if k < len(masks[grp]) else None)
     minmax = aggregate in ("max", "min")
     agg = None if minmax else aggregate_vals(rowptr, aggregate, x.dtype)
     act = hidden_activation
@@ -637,7 +651,7 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
         if k == n_post - 1:
             d, grads["post"][k] = dense_bn_act_bwd(None, c, p, None, True, dzb=dlogits)
         else:
-            d, grads["post"][k] = dense_bn_act_bwd(d, c, p, act, True)
+            d, grads["post"][k] = dense_bn_act_bwd(d, c, p, act, True, pos=mask("post", k))
     d = global_pool_bwd(d, graph_ptr, x.shape[0], pool, caches["pool_arg"])
     for k in reversed(range(len(layers["gnn"]))):
         p, c = layers["gnn"][k], caches["gnn"][k]
@@ -649,9 +663,9 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
             dh = spmm_csr(csr_t[0], csr_t[1], None, dz)
         else:
             dh = spmm_csr_T(rowptr, colidx, agg, dz)
-        dx, grads["gnn"][k] = dense_bn_act_bwd(dh, c, p, act, True)
+        dx, grads["gnn"][k] = dense_bn_act_bwd(dh, c, p, act, True, pos=mask("gnn", k))
         d = dx + dskip
     for k in reversed(range(len(layers["pre"]))):
         p, c = layers["pre"][k], caches["pre"][k]
-        d, grads["pre"][k] = dense_bn_act_bwd(d, c, p, act, k > 0)
+        d, grads["pre"][k] = dense_bn_act_bwd(d, c, p, act, k > 0, pos=mask("pre", k))
     return loss, acc, grads, probs, stats

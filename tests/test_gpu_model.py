@@ -5,7 +5,7 @@ import pytest
 
 from gcnx.models import GCN2
 
-from conftest import GOLDEN, assert_close, golden_batch, load_golden, rel_err
+from conftest import GOLDEN, PARITY_REPORT as PARITY_NOTES, assert_close, golden_batch, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -480,7 +480,8 @@ def test_gcn2_world_size_2_large_batch_with_bf16_storage_equals_single_rank():
 def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, pool, connectivity):
     """GeneralGNN(aggregate="mean" | "max" | "min", pool="avg" | "max") (Spektral options beside gcn.py:320's defaults; r3): inference forward,
     training step (loss, probabilities, every gradient) against the fp64 oracle, which torch autograd pins for these options
-    (tests/test_oracle.py).  Gradients get the gross-error bound of the default-option test's larger cases (PReLU kinks)."""
+    (tests/test_oracle.py).  Gradients at 1e-4 against the oracle on the device's side of every PReLU kink, as in the
+    default-option test."""
     from gcnx import synth
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch, GeneralGNN
@@ -496,19 +497,11 @@ def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, poo
     csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
     rprobs, _, _ = O.general_gnn_forward(layers, x64, csr, hb.graph_ptr, False, aggregate=aggregate, pool=pool, connectivity=connectivity)
     assert rel_err(m(batch, training=False), rprobs) < TOL
-    rl, ra, rg, rp, _ = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64, aggregate=aggregate, pool=pool,
-                                                     connectivity=connectivity)
     loss, acc = m.train_step(batch, None, lr=0.01)
+    rl, ra, rp, _ = _assert_gnn_grads_kink_separated(m, m.gradients(), hb, layers, "f32", TOL, f"GeneralGNN {aggregate}/{pool}/{connectivity}",
+                                                     aggregate=aggregate, pool=pool, connectivity=connectivity)
     assert abs(loss - rl) < TOL * max(1, rl) and acc == pytest.approx(ra)
     assert rel_err(m._bufs["probs"].numpy(), rp) < TOL
-    got = m.gradients()
-    li = 0
-    for grp in ("pre", "gnn", "post"):
-        for g in rg[grp]:
-            layer_max = max(np.abs(v).max() for v in g.values())
-            for name, ref in g.items():
-                assert np.max(np.abs(got[li][name] - ref)) < 2e-2 * np.abs(ref).max() + 1e-5 * layer_max, (grp, li, name)
-            li += 1
     with pytest.raises(NotImplementedError):
         GeneralGNN(ctx, 2, activation="softmax", aggregate="prod")
 
@@ -626,6 +619,74 @@ def _kink_free_case(f_in, hidden, mp, n_graphs, margin=5e-5, seeds=200):
     raise AssertionError("no kink-free case found")
 
 
+KINK_REACH = {"f32": 2.0 ** -17, "bf16x3": 2.0 ** -11}     # how far from zero (in rms pre-activations) a flipped entry may lie
+
+
+def _device_kink_masks(m, layers):
+    """Which side of its PReLU / ReLU kink the DEVICE took every pre-activation to be on in the training step that just ran:
+    zb = fma(z - mu, gamma * inv, beta) is the one expression both its forward and its backward kernels evaluate
+    (csrc/bn.hip: bn_zb), from the Dense output z the model keeps per layer, the batch statistics (mu, inv) the step left and
+    the layer's gamma / beta BEFORE the update -- so its sign is reproduced here exactly: the product (z - mu) * sc of two
+    fp32 numbers is exact in fp64 and adding beta cannot change the sign of the exact sum.  None for a layer without a
+    hidden activation."""
+    masks = {"pre": [], "gnn": [], "post": []}
+    i = 0
+    for grp in ("pre", "gnn", "post"):
+        for p in layers[grp]:
+            L = m.layers[i]
+            if L["act"] is None:
+                masks[grp].append(None)
+            else:
+                z, mu, iv = m._bufs[f"z{i}"].numpy(), L["mean"].numpy(), L["inv"].numpy()
+                ga = p["gamma"].astype(np.float32) if "gamma" in p else np.ones_like(iv)      # (batch_norm=False: identity transform)
+                be = p["beta"].astype(np.float32) if "gamma" in p else np.zeros_like(iv)
+                sc, d = ga * iv, z - mu                                                        # fp32, as on the device
+                masks[grp].append(d.astype(np.float64) * sc.astype(np.float64) + be.astype(np.float64) > 0)
+            i += 1
+    return masks
+
+
+def _assert_gnn_grads_kink_separated(m, got, hb, layers, prec, tol, what, drops=None, **okw):
+    """Every gradient of the GeneralGNN step against the fp64 oracle evaluated on the DEVICE's side of every activation kink
+    (oracle: dense_bn_act_bwd(pos=...)), at `tol` -- arithmetic error only; and the kink noise bounded separately: an entry
+    the device and the fp64 reference put on different sides must lie within the precision's reach of zero
+    (KINK_REACH x the layer's rms pre-activation), and such entries must be rare."""
+    from oracle import gcn_oracle as O
+    x64, y64 = hb.x.astype(np.float64), hb.y.astype(np.float64)
+    csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
+    masks = _device_kink_masks(m, layers)
+    _, caches, _ = O.general_gnn_forward(layers, x64, csr, hb.graph_ptr, True, drops=drops, **okw)
+    nflip = ntot = 0
+    for grp in ("pre", "gnn", "post"):
+        for k, pos in enumerate(masks[grp]):
+            if pos is None:
+                continue
+            zb = caches[grp][k]["zb"]                       # (with Dropout: already times the layer's factor; 0 where dropped)
+            if drops is not None:
+                pos = masks[grp][k] = pos & (drops[grp][k] > 0)
+            flip = (zb > 0) != pos
+            if flip.any():
+                assert np.abs(zb[flip]).max() <= KINK_REACH[prec] * np.sqrt((zb ** 2).mean()), (what, grp, k, int(flip.sum()))
+            nflip, ntot = nflip + int(flip.sum()), ntot + flip.size
+    assert nflip <= max(4, 2e-4 * ntot), (what, nflip, ntot)
+    okw = {k: v for k, v in okw.items() if k != "final_activation"}
+    rl, ra, rg, rp, stats = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64, drops=drops, masks=masks, **okw)
+    li = 0
+    for grp in ("pre", "gnn", "post"):
+        for g in rg[grp]:
+            assert set(got[li]) == set(g), (grp, li)
+            # the Dense bias under BN has an analytically zero gradient (the device writes the exact zero, the oracle's sum
+            # leaves fp64 noise): absolute slack relative to the layer's largest gradient
+            layer_max = max(np.abs(v).max() for v in g.values())
+            for name, ref in g.items():
+                err = np.max(np.abs(got[li][name] - ref))
+                assert err < tol * np.abs(ref).max() + 1e-6 * layer_max, (what, grp, li, name, err / max(np.abs(ref).max(), 1e-30))
+                PARITY_NOTES.append({"what": f"{what} {grp}{li} d{name}", "rel_err": float(err / max(np.abs(ref).max(), 1e-30)),
+                                     "tol": tol, "kink_flips": nflip})
+            li += 1
+    return rl, ra, rp, stats
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("f_in,hidden,mp,n_graphs,strict", [(16, 16, 4, 8, True), (16, 32, 2, 6, False), (16, 64, 4, 8, False),
                                                              (16, 256, 4, 3, True)])
@@ -658,28 +719,18 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict, pre
     # inference forward (moving statistics), evaluate() semantics of gcn.py:351
     rprobs, _, _ = O.general_gnn_forward(layers, x64, csr, hb.graph_ptr, False)
     assert rel_err(m(batch, training=False), rprobs) < TOL
-    # training step.  Forward quantities are always held to 1e-4.  Gradients are held to 1e-4 on the strict
-    # (kink-free) case.  On the larger cases a BN output that crosses the PReLU kink between fp32 and fp64
-    # flips one gradient element by O(1) -- the fp32 run of the numpy oracle itself deviates from its fp64
-    # run by up to 2e-3 there -- so gradients only get a gross-error bound of 2 %.
-    rl, ra, rg, rp, stats = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64)
+    # training step.  Forward quantities are held to 1e-4.  Gradients (r4): a BN output that crosses the
+    # PReLU kink between fp32 and fp64 moves a gradient by a whole term -- the fp32 run of the numpy oracle itself deviates
+    # from its fp64 run by up to 2e-3 on the larger cases -- so every gradient is compared with the oracle's backward
+    # evaluated on the DEVICE's side of every kink: 1e-4 (f32) / 2e-4 (bf16x3: 2^-18 per GEMM operand through ten
+    # BatchNorm layers), on EVERY case, and the flipped entries are bounded by themselves (_assert_gnn_grads_kink_separated).
     before = m.get_weights(order="layer")
     loss, acc = m.train_step(batch, None, lr=0.01)
+    got = m.gradients()
+    rl, ra, rp, stats = _assert_gnn_grads_kink_separated(m, got, hb, layers, prec, TOL if prec == "f32" else 2e-4,
+                                                        f"GeneralGNN {f_in}-{hidden}x{mp} B={n_graphs} {prec}")
     assert abs(loss - rl) < TOL * max(1, rl) and acc == pytest.approx(ra)
     assert rel_err(m._bufs["probs"].numpy(), rp) < TOL
-    got = m.gradients()
-    li = 0
-    for grp in ("pre", "gnn", "post"):
-        for g in rg[grp]:
-            for name, ref in g.items():
-                # the Dense bias under BN has an analytically zero gradient: allow fp32 noise relative to
-                # the layer's largest gradient
-                layer_max = max(np.abs(v).max() for v in g.values())
-                # (bf16x3: 2^-18 per GEMM operand, 64 x fp32's rounding, through ten BatchNorm layers that divide by a batch
-                # deviation: forward quantities stay at 1e-4, the strict gradient bar scales by 10)
-                tol = (2 * TOL if prec == "f32" else 2e-3) if strict else 2e-2
-                assert np.max(np.abs(got[li][name] - ref)) < tol * np.abs(ref).max() + 1e-5 * layer_max, (grp, li, name)
-            li += 1
     # moving statistics: m <- 0.99 m + 0.01 batch   (Keras momentum)
     after = m.get_weights(order="layer")
     it_b, it_a = iter(before), iter(after)
@@ -797,19 +848,12 @@ def test_general_gnn_connectivity_batch_norm_activation_dropout_options_match_or
             if step >= 1:
                 assert not np.array_equal(drops["gnn"][0], prev["gnn"][0])          # a new mask every step
             prev = drops
-        rl, ra, rg, rp, _ = O.general_gnn_loss_and_grads(layers, x64, csr, hb.graph_ptr, y64, drops=drops, **kw)
         loss, acc = m.train_step(batch, None, lr=0.0)                                 # lr 0: the same weights in both steps
+        rl, ra, rp, _ = _assert_gnn_grads_kink_separated(m, m.gradients(), hb, layers, prec, tol,
+                                                         f"GeneralGNN {connectivity}/bn={batch_norm}/{act}/drop={rate} {prec} step {step}",
+                                                         drops=drops, **kw)
         assert abs(loss - rl) < tol * max(1, rl) and acc == pytest.approx(ra), step
         assert rel_err(m._bufs["probs"].numpy(), rp) < tol
-        got = m.gradients()
-        li = 0
-        for grp in ("pre", "gnn", "post"):
-            for g in rg[grp]:
-                assert set(got[li]) == set(g), (grp, li)
-                layer_max = max(np.abs(v).max() for v in g.values())
-                for name, ref in g.items():
-                    assert np.max(np.abs(got[li][name] - ref)) < 2e-2 * np.abs(ref).max() + 1e-5 * layer_max, (step, grp, li, name)
-                li += 1
 
 
 
@@ -992,10 +1036,10 @@ def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     nodes, max degree 4096, F=256) as whole train steps -- the tile-plan + side-stream path (config 3), hub rows
     split over waves (config 5), dW with K = 10^6 rows, the pool over 10^6 rows, the weighted aggregation at full size
     -- against the fp32 C restatement (oracle/gcn_oracle.c: blocked summation, so its own rounding stays far below
-    the bar): loss, accuracy, every gradient and the SGD-updated weights at 1e-4 for GCNX_PREC_F32 (north_star's
-    bar); 3e-4 for BF16X3 (hi + lo carries 2^-17 per operand: measured 1.4e-4 on dW1 after two layers and a 10^6-row
-    reduction); plain BF16 against the oracle fed bf16-rounded GEMM operands (same arithmetic model, 3e-4) plus a
-    loose bound against the fp32 oracle.  The first call runs eagerly, the second captures the step into a HIP graph, the third replays."""
+    the bar): loss, accuracy, every gradient and the SGD-updated weights against an INDEPENDENT implementation with its own
+    ReLU masks -- a cross-check whose bounds (3e-4 f32, 6e-4 bf16x3 and plain bf16 against the oracle fed bf16-rounded GEMM
+    operands) leave room for the kink noise of two evaluation orders; the 1e-4 bar itself is held by the kink-separated test.
+    Plus a loose bound of plain bf16 against the fp32 oracle.  The first call runs eagerly, the second captures the step into a HIP graph, the third replays."""
     from oracle import c_oracle
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch
@@ -1015,7 +1059,10 @@ def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
         rl, ra = cpu.step(lr=0.0, bf16_operands=bf, layer1_s_order=bf)
         ref[key] = (rl, ra, cpu.grads.copy())
     lr = np.float32(0.05)
-    for prec, key, tol in (("f32", "f32", TOL), ("bf16x3", "f32", 3e-4), ("bf16", "bf16", 3e-4)):
+    # (r4) These bounds INCLUDE the ReLU-kink noise of comparing two evaluation orders with their own masks -- measured 0.9e-4
+    # (f32) to 2.9e-4 (bf16x3, power-law) on dW1, of which the arithmetic error is 4e-7 / 3e-6: the 1e-4 bar of north_star is
+    # held, for f32 AND bf16x3 and for both workloads, by the kink-separated test below, on the device's side of every kink.
+    for prec, key, tol in (("f32", "f32", 3e-4), ("bf16x3", "f32", 6e-4), ("bf16", "bf16", 6e-4)):
         m.prec = prec
         m._drop_graphs()
         m.set_weights(w0)
@@ -1042,8 +1089,13 @@ def test_config3_and_config5_full_train_step_vs_c_oracle(ctx, workload):
     assert np.array_equal(g1, np.concatenate([m.gradients()[k].ravel() for k in ORDER]))
 
 
-def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
-    """VERDICT r2, next 2.  What the 1.4e-4 on dW1 (bf16x3, full size, round 2) was: not arithmetic but ReLU KINKS.  The
+@pytest.mark.parametrize("workload", ["block1m", "powerlaw"])
+def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx, workload):
+    """(r4: also BASELINE config 5 -- 122 power-law graphs of 8 192 nodes, hub rows of up to 4096 entries -- whose bf16x3 step
+    stood at 2.9e-4 against the C oracle's own masks: the same separation puts it at the 1e-4 bar.  Part (3), plain bf16
+    operands, is config 3's precision and runs there only.)
+
+    VERDICT r2, next 2.  What the 1.4e-4 on dW1 (bf16x3, full size, round 2) was: not arithmetic but ReLU KINKS.  The
     gradient of a ReLU network is discontinuous where a pre-activation is 0; an evaluation whose pre-activations differ
     from the reference's by delta lands on the other side for the ~N F rho(0) 2 delta entries within delta of zero, and
     each such flip moves dW1 = S1^T dZ1 by one whole term -- 1e-4 of max|dW1| here, because with random features dW1 is a
@@ -1066,7 +1118,7 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
     from oracle import gcn_oracle as O
     from gcnx.device import DeviceCSR, Segments
     from gcnx.models import DeviceBatch
-    hb = _full_size_batch("block1m")
+    hb = _full_size_batch(workload)
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, hb.vals, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
     m = GCN2(ctx, 2, hidden=256, seed=0, use_graph=False)
@@ -1105,23 +1157,15 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
     own1, own2 = fw[0] > 0, fw[2] > 0
     loss64, g_own, _ = backward(fw, own1, own2, ident)
     rms1, rms2 = float(np.sqrt((fw[0] ** 2).mean())), float(np.sqrt((fw[2] ** 2).mean()))
-    reach = {"f32": 2.0 ** -20, "bf16x3": 2.0 ** -14}
-    for prec in ("f32", "bf16x3", "bf16"):
+    # (power-law batch: a hub row adds up to 4096 terms, and its pre-activation's rounding error grows with the row)
+    reach = {"f32": 2.0 ** -20, "bf16x3": 2.0 ** -14} if workload == "block1m" else {"f32": 2.0 ** -18, "bf16x3": 2.0 ** -12}
+    for prec in (("f32", "bf16x3", "bf16") if workload == "block1m" else ("f32", "bf16x3")):
         m.prec = prec; m._drop_graphs(); m.set_weights(w0)
         loss, _ = m.train_step(batch, None, lr=0.0)
         got = m.gradients()
-        if m._bufs.get("act16"):        # (r3: with plain bf16 operands Y1 is stored as bfloat16 -- the fp32 buffer is not written)
-            from gcnx import device as _D
-            m1 = _D.from_bf16(ctx, m._bufs["y1_16"]).numpy() > 0
-        else:
-            m1 = m._bufs["y1"].numpy() > 0
-        m2 = m._bufs["y2"].numpy() > 0
-        if m._bufs.get("pool_done"):    # (r3: the pooled layer's launch leaves bits, pooled rows and counts; Y2 rows are written for
-            # the graphs taller than a tile only -- the other rows' signs come from the bit image, word (slab, row), bit = column)
-            img = m._bufs["y2bits"].numpy().view(np.uint32).reshape(256 // 32, hb.n)
-            from_bits = ((img.T[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(hb.n, 256)
-            tile = np.repeat(np.diff(hb.graph_ptr) <= 1276, np.diff(hb.graph_ptr))
-            m2 = np.where(tile[:, None], from_bits, m2)
+        # (r3: with plain bf16 operands Y1 is stored as bfloat16; the pooled layer's launch leaves bits, pooled rows and counts,
+        # Y2 rows are written for the graphs taller than a tile only: _device_relu_masks reads whichever form the step left)
+        m1, m2 = _device_relu_masks(ctx, m, hb)
         if prec != "bf16":
             assert abs(loss - loss64) < TOL * abs(loss64), (prec, loss, loss64)
             f1, f2 = m1 != own1, m2 != own2
@@ -1131,7 +1175,7 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx):
             assert not f2.any() or np.abs(fw[2][f2]).max() <= reach[prec] * rms2, prec
             _, g_dev, _ = backward(fw, m1, m2, ident)
             for k in ORDER:
-                assert_close(got[k], g_dev[k], TOL, f"block1m {prec} d{k} vs fp64 reference on the device's side of the ReLU kinks")
+                assert_close(got[k], g_dev[k], TOL, f"{workload} {prec} d{k} vs fp64 reference on the device's side of the ReLU kinks")
                 assert rel_err(got[k], g_own[k]) < 3e-4, (prec, k)         # with the kink noise in: still there
         else:
             fwb = forward(rb)

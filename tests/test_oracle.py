@@ -419,3 +419,45 @@ def test_bf16_rounding_is_nearest_even():
     assert o.bf16_bits(np.float32([1.0 + 2.0 ** -8]))[0] == 0x3f80 and o.bf16_bits(np.float32([1.0 + 3 * 2.0 ** -8]))[0] == 0x3f82
     back = o.bf16_from_bits(o.bf16_bits(xs))
     assert np.all(np.abs(back - xs) <= np.abs(xs) * 2.0 ** -8)
+
+
+def test_general_gnn_backward_on_a_given_side_of_the_activation_kinks():
+    """general_gnn_loss_and_grads(masks=...) (test infrastructure for the GPU parity tests, r4): with every layer's own mask
+    zb > 0 it is the plain backward; flipping ONE entry of one hidden layer's mask changes that layer's alpha gradient by
+    exactly the entry's term and leaves the loss alone (the forward pass does not depend on the masks)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    graphs = []
+    for _ in range(3):
+        n = int(rng.integers(6, 12))
+        a = (rng.random((n, n)) < 0.3).astype(np.float64)
+        a = np.maximum(a, a.T); np.fill_diagonal(a, 1.0)
+        graphs.append((rng.standard_normal((n, 5)), sp.csr_matrix(a), np.eye(2)[rng.integers(0, 2)]))
+    x, (idx, val, shape), i, y = O.disjoint_collate(graphs)
+    rp, ci = O.coo_to_csr(idx, shape[0])
+    gp = O.graph_ptr_from_ids(i, 3)
+    layers = O.general_gnn_init(rng, 5, 2, hidden=8, message_passing=2)
+    for grp in layers.values():
+        for p in grp:
+            if "alpha" in p:
+                p["alpha"] = 0.25 * rng.random(p["alpha"].shape)
+    csr = (rp, ci, None)
+    l0, a0, g0, p0, _ = O.general_gnn_loss_and_grads(layers, x, csr, gp, y)
+    _, caches, _ = O.general_gnn_forward(layers, x, csr, gp, True)
+    own = {grp: [(c["zb"] > 0) if k < len(layers[grp]) - (grp == "post") else None for k, c in enumerate(caches[grp])]
+           for grp in ("pre", "gnn", "post")}
+    l1, a1, g1, p1, _ = O.general_gnn_loss_and_grads(layers, x, csr, gp, y, masks=own)
+    assert l1 == l0 and a1 == a0 and np.array_equal(p1, p0)
+    for grp in g0:
+        for ga, gb in zip(g0[grp], g1[grp]):
+            for k in ga:
+                assert np.array_equal(ga[k], gb[k]), (grp, k)
+    flipped = {grp: [None if m is None else m.copy() for m in own[grp]] for grp in own}
+    r, c = 2, 3
+    flipped["gnn"][1][r, c] ^= True
+    l2, _, g2, _, _ = O.general_gnn_loss_and_grads(layers, x, csr, gp, y, masks=flipped)
+    assert l2 == l0
+    d_alpha = g2["gnn"][1]["alpha"] - g0["gnn"][1]["alpha"]
+    assert np.count_nonzero(d_alpha) == 1 and d_alpha[c] != 0
+    assert not np.array_equal(g2["gnn"][1]["kernel"], g0["gnn"][1]["kernel"])
+    assert all(np.array_equal(a_[k], b_[k]) for a_, b_ in zip(g2["post"], g0["post"]) for k in a_)    # downstream of nothing
