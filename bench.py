@@ -240,10 +240,15 @@ def cpu_baseline_scipy(hb, hidden, params_flat, budget_s):
             "sample": f"{steps} train steps in {el:.1f} s; scipy.sparse csr @ dense + NumPy BLAS, fp32"}
 
 
-# Under rocprofv3 (LD_PRELOADed tool library, ROCPROF_* variables) a deep queue of hipGraphLaunch calls has crashed the
-# profiled process on this pool -- SIGSEGV inside hipGraphLaunch in the tool's dispatch tracking, once a queue abort -- and the
-# timed loops below never wait for the GPU.  A profiled run therefore drains the queue every 8 steps (the JSON line says
-# "profiled": true; kernel durations, which is what such a run is for, are unaffected).
+# Under rocprofv3 (LD_PRELOADed tool library, ROCPROF_* variables) a deep queue of hipGraphLaunch calls crashes the profiled
+# process: SIGSEGV inside hipGraphLaunch, in the tool's interception of the queue writes.  Cause established in round 4 with a
+# product-free reproducer (scripts/micro/graph_trace_repro.hip, results in profiles/r04/graph_trace_repro_summary.txt): a
+# plain HIP program that captures 150 small kernel nodes and launches the graph 400 times without waiting dies under
+# `rocprofv3 --kernel-trace` with the same frames (same page offsets) as the product's crash of round 3, runs clean without
+# the tracer, clean with a synchronisation every 8 launches, and clean with a 5-node graph launched 8000 times -- a defect of
+# the tool's dispatch tracking for large graphs enqueued deeply, not a lifetime problem of the library's captured graphs.  The
+# timed loops below never wait for the GPU, so a profiled run drains the queue (every 8 steps; every step for the 150-node
+# GeneralGNN graph); the JSON line says "profiled": true; kernel durations, which is what such a run is for, are unaffected.
 PROFILED = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
 
 
@@ -308,10 +313,7 @@ def generalgnn_extra(ctx, steps=60):
                        f"N={hb.n}, nnz={hb.nnz}"}
     keep = []
     for prec in ("f32", "bf16x3"):
-        # (under a profiler the 150-node step graph is not captured: replaying it has crashed rocprofv3's kernel trace here --
-        # SIGSEGV inside hipGraphLaunch -- while the stand-alone `--model generalgnn` run traces fine; the eager step's
-        # kernels are the same, its wall time is not the product's and the entry says so)
-        model = GeneralGNN(ctx, 2, activation="softmax", prec=prec, use_graph=not PROFILED)
+        model = GeneralGNN(ctx, 2, activation="softmax", prec=prec)     # (captured step, also under a profiler: see PROFILED)
         for _ in range(5):
             model.train_step(batch, None, lr=0.0002, fetch=False)
         ctx.sync()
@@ -322,7 +324,7 @@ def generalgnn_extra(ctx, steps=60):
         t0 = time.perf_counter()
         for k in range(steps):
             model.train_step(batch, None, lr=0.0002, fetch=False)
-            drain(ctx, k, 1)      # (profiled runs only: see PROFILED -- this 150-node graph must not be enqueued again while in flight)
+            drain(ctx, k, 1)      # (profiled runs only: see PROFILED -- a 150-node graph is not enqueued deeply under the tracer)
         ctx.sync()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         flops = 0
@@ -332,9 +334,7 @@ def generalgnn_extra(ctx, steps=60):
         peak = 157.3e12 if prec == "f32" else 2.5e15 / 3.0   # fp32 MFMA; bf16 MFMA at three products per multiply
         out[prec] = {"ms_per_step": ms, "graphs_per_s": hb.n_graphs / (ms * 1e-3), "flops": flops,
                      "frac_of_mfma_peak": flops / (ms * 1e-3) / peak, "params": model.n_params}
-        if PROFILED:
-            out[prec]["eager_under_profiler"] = True
-        keep.append(model)          # (captured graphs are destroyed with the process, not in the middle of a profiled run)
+        keep.append(model)          # (captured graphs are destroyed with the process)
     return out
 
 

@@ -202,13 +202,24 @@ def _disjoint_coo(a_list):
 
 
 def collate_disjoint(graphs, node_level=False):
-    """DisjointLoader.collate: the same ((x, a, i), y) as to_disjoint + sp_matrix_to_sp_tensor, built directly."""
+    """DisjointLoader.collate: the same ((x, a, i), y) as to_disjoint + sp_matrix_to_sp_tensor, built directly.
+    Graphs that carry edge features (Graph(e=...): the reference computes them either way and attaches them only with
+    use_edge_data, gcn.py:173-180) yield ((x, a, e, i), y) as Spektral does -- e = vstack of the graphs' [n_edges, S]
+    arrays, a dense [n, n, S] array reduced to the adjacency's stored entries first (to_disjoint).  The models of this
+    package take (x, a, i), like spektral.models.GeneralGNN: a batch with e is for the caller's own layers."""
     x_list = [g.x for g in graphs]
     x = np.vstack(x_list)
     n_nodes = np.array([x_.shape[0] for x_ in x_list], dtype=np.int64)
     i = np.repeat(np.arange(len(n_nodes), dtype=np.int64), n_nodes)
     y = np.vstack([g.y for g in graphs]) if node_level else np.array([g.y for g in graphs])
-    return (x, _disjoint_coo([g.a for g in graphs]), i), y
+    a = _disjoint_coo([g.a for g in graphs])
+    if graphs and all(getattr(g, "e", None) is not None for g in graphs):
+        import scipy.sparse as sp
+        e_list = [np.asarray(g.e) for g in graphs]
+        if e_list[0].ndim == 3:                  # dense [n, n, S] -> the rows of the stored entries (sp.find order, as upstream)
+            e_list = [e[sp.find(g.a)[:-1]] for e, g in zip(e_list, graphs)]
+        return (x, a, np.vstack(e_list), i), y
+    return (x, a, i), y
 
 
 class DisjointLoader:
@@ -258,5 +269,8 @@ class DisjointLoader:
         gcn.py:328); plain tuples here since there is no TensorFlow."""
         g = self.dataset[0]
         f = g.n_node_features
-        return ((("x", (None, f), np.float64), ("a", (None, None), "sparse"), ("i", (None,), np.int64)),
-                ("y", (None, g.n_labels), np.asarray(g.y).dtype))
+        inputs = [("x", (None, f), np.float64), ("a", (None, None), "sparse")]
+        if getattr(g, "e", None) is not None:
+            inputs.append(("e", (None, np.asarray(g.e).shape[-1]), np.asarray(g.e).dtype))
+        inputs.append(("i", (None,), np.int64))
+        return (tuple(inputs), ("y", (None, g.n_labels), np.asarray(g.y).dtype))

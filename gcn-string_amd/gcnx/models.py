@@ -678,8 +678,8 @@ class GeneralGNN(_GraphRunner):
 
     MLP layer = Dense -> BatchNormalization -> Dropout(0) -> PReLU (last post layer: softmax);
     GeneralConv = Dense -> BN -> PReLU -> sum-aggregation over a.indices (values ignored).
-    Same constructor signature; only the defaults the reference uses are implemented (anything
-    else raises).  The skip concatenation is never materialised: every layer reads / writes a
+    Same constructor signature (activation "softmax" as gcn.py:320 passes it, or Spektral's default None = linear head); of
+    the other options those listed in __init__ are built, anything else raises.  The skip concatenation is never materialised: every layer reads / writes a
     column slice of one [N, hidden*(message_passing+1)] buffer through leading-dimension views.
     Weights are exposed in Keras order per layer: kernel, bias, gamma, beta, moving_mean,
     moving_variance, alpha.  With a communicator (one process per GPU, a graph shard each) BatchNormalization is
@@ -693,8 +693,18 @@ class GeneralGNN(_GraphRunner):
         self.use_graph, self._graphs = use_graph, {}
         self.cce_train, self.cce_eval = cce_train, cce_eval     # see GCN2.__init__
         self.comm = comm                                  # gcnx.comm.Communicator: sync-BN + gradient all-reduce
-        if activation != "softmax":
-            raise NotImplementedError(f"GeneralGNN(activation={activation!r}): only 'softmax' (what gcn.py:320 uses) is built")
+        # activation: "softmax" (gcn.py:320) or None / "linear" (Spektral's own default: the last post layer ends with its
+        # BatchNormalization, model(inputs) returns those logits).  A linear head is trained on the from-logits cross-entropy
+        # -- CategoricalCrossentropy(from_logits=True), the only form defined on unnormalised outputs -- which is also what
+        # tf.function makes of the softmax head (see GCN2.__init__), so the training step is the same launch sequence and
+        # only what the model RETURNS differs.
+        if activation == "linear":
+            activation = None
+        if activation not in ("softmax", None):
+            raise NotImplementedError(f"GeneralGNN(activation={activation!r}): 'softmax' (gcn.py:320) and None are built")
+        self.activation = activation
+        if activation is None:
+            self.cce_train = self.cce_eval = "logits"
         # Spektral's other options that map onto kernels that exist (r3; PARITY UNPINNED like the rest, the
         # oracle's restatement of them is checked against torch autograd): connectivity "sum" (out = z + out), batch_norm False
         # (no BatchNormalization layers), hidden_activation "relu" / None, dropout > 0 (the Dropout layer between
@@ -1093,6 +1103,8 @@ class GeneralGNN(_GraphRunner):
         bufs = self._ensure(batch)
         self._prepare_images()
         logits = self._forward(batch, bufs, training)
+        if self.activation is None:                        # linear head: the last BatchNormalization's output
+            return logits.numpy()
         la = self._tmp(bufs, "la_scratch", (2,))
         la.fill_zero()
         D.softmax_cce(self.ctx, logits, bufs["zy"], bufs["probs"], la, None, None)
@@ -1173,7 +1185,7 @@ class GeneralGNN(_GraphRunner):
         self.loss_acc.fill_zero()
         D.softmax_cce(self.ctx, logits, batch.y, bufs["probs"], self.loss_acc, None, batch.n_graphs, cce=self.cce_eval)
         la = self.loss_acc.numpy()
-        return float(la[0]), float(la[1]) / batch.n_graphs, bufs["probs"].numpy()
+        return float(la[0]), float(la[1]) / batch.n_graphs, (logits if self.activation is None else bufs["probs"]).numpy()
 
     def gradients(self):
         return [{k[2:]: L[k].numpy() for k in L if k.startswith("g_")} for L in self.layers]
