@@ -99,6 +99,7 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   if (const char* k = getenv("GCNX_SPMM_SORT_WIN")) ctx->knob_spmm_sort_win = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_CAP1")) ctx->knob_spmm_cap1 = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_BAL")) ctx->knob_spmm_bal = atoi(k);
+  if (const char* k = getenv("GCNX_SPMM_CB")) ctx->knob_spmm_cb = atoi(k);
   if (const char* k = getenv("GCNX_ROCTX")) {
     if (atoi(k)) {                        // tracing aid: named ranges around the kernel classes (rocprofv3 --marker-trace)
       void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
@@ -167,6 +168,7 @@ int gcnx_set_tuning(gcnx_ctx* ctx, const char* key, int value) {
   else if (k == "spmm_sort_win") ctx->knob_spmm_sort_win = value;
   else if (k == "spmm_cap1") ctx->knob_spmm_cap1 = value;
   else if (k == "spmm_bal") ctx->knob_spmm_bal = value;
+  else if (k == "spmm_cb") ctx->knob_spmm_cb = value;
   else return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_set_tuning: unknown key '%s'", key);
   return GCNX_OK;
 }

@@ -1276,6 +1276,137 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Column-block row gather (r4; BASELINE config 5).  A graph whose feature rows do not fit an XCD's L2 -- 8 192 nodes x
+// 1 KiB = 8 MiB against 4 MiB -- is gathered ~degree times out of a working set that keeps falling out of the cache (r3 PMC:
+// L2 hit rate 0.52, 1.88 x the compulsory HBM traffic).  Here such a graph is walked one 64-COLUMN block at a time: all its
+// rows for columns [0, 64), then [64, 128), ... -- consecutive work items, which the workgroup-id remap hands to ONE XCD -- so
+// the block's source rows (8 192 x 256 B = 2 MiB) stay in that XCD's L2 while they are gathered, and the graph's index
+// arrays (re-read once per block) stay there too (r4 PMC: 1.31 x the compulsory traffic).
+// A 64-column block is 16 lanes x float4, so a wave holds four lane groups, and in a power-law batch 83 % of the rows have at
+// most three entries while a third of the ENTRIES sit in rows of hundreds.  The first version gave the four groups four
+// rows in row order: the traffic fell as planned and the launch got slower (895 us against 705), because a wave walked
+// max(length of its 8 rows) trips with most lanes idle and the long rows ran one after the other behind barriers.  So the
+// rows of such a graph are taken in DEGREE order (the plan's RowRec list, as for the tile kernels) and an item is one of:
+//   kind 2  32 rows of at most kCbLong entries: a lane group per row, two rows per group, two entries of each per trip --
+//           neighbours in the order have (nearly) the same length, so a wave's trips are all useful;
+//   kind 1  4 rows of kCbLong + 1 .. kCbHub entries: a wave per row, 16 entries per trip (4 groups x 4);
+//   kind 0  1 row of more than kCbHub entries: the four waves take a quarter each (fixed combination order).
+// Heaviest first inside every (graph, block).  Index loads run one trip ahead of the gathers that need them (range-checked
+// buffer loads throughout: a missing entry costs no fetch and adds an exact zero), so a trip is one dependent round trip.
+// A row of kind 2 adds its entries in CSR order -- the row gather's order at f = 256, bit for bit.
+// ----------------------------------------------------------------------------------------------
+constexpr int kCbCols = 64;          // columns per block
+constexpr int kCbMinRows = 4096;     // graphs of at least this many rows are walked this way (and fewer than 65 536: RowRec)
+constexpr int kCbLong = 32;          // kind 2 up to here
+constexpr int kCbHub = 512;          // kind 1 up to here
+constexpr int kCbMinF = 128;         // narrower features: the whole graph fits L2 anyway
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256, 8) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
+                                                         const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
+                                                         int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items) {
+  __shared__ float4 s_long[4][16];
+  const int4 it = items[gcnx_xcd_remap(blockIdx.x, nitems)];
+  const int p0 = it.x, cnt = it.y & 0xFFFF, kind = it.y >> 16, col0 = it.z, row0 = it.w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, sub = lane & 15;
+  const int c = col0 + sub * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = *reinterpret_cast<const float4*>(bias + c);
+  // (the host checks that byte offsets into h fit 32 bits)
+  const __amdgpu_buffer_rsrc_t hbuf = __builtin_amdgcn_make_buffer_rsrc((void*)h, (short)0, (int)((uint64_t)n * (uint64_t)ldh * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t cbuf = __builtin_amdgcn_make_buffer_rsrc((void*)colidx, (short)0, nnz * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vbuf =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(WEIGHTED ? (const void*)vals : (const void*)colidx), (short)0, nnz * 4, 0x00020000);
+  const unsigned ld32 = (unsigned)ldh;
+  constexpr unsigned kOob = 0xFFFFFFF0u;
+  auto epilogue = [&](float4 acc, int r) {
+    acc = f4_add(acc, bv);
+    if (act == GCNX_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
+  };
+  auto ld_col = [&](unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(cbuf, off, 0, 0); };
+  auto ld_val = [&](unsigned off) { return WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f; };
+  auto h_off = [&](bool ok, int col) { return ok ? ((unsigned)col * ld32 + (unsigned)c) * 4u : kOob; };
+  if (kind == 2) {
+    const int posA = wave * 8 + g, posB = posA + 4;
+    const RowRec rrA = rowrec[p0 + min(posA, cnt - 1)], rrB = rowrec[p0 + min(posB, cnt - 1)];
+    const int aA = rrA.a, aB = rrB.a;
+    const int bA = aA + (posA < cnt ? (int)(rrA.w >> 16) : 0), bB = aB + (posB < cnt ? (int)(rrB.w >> 16) : 0);
+    float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+    int eA = aA, eB = aB;
+    // indices one trip ahead
+    int cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob), cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+    int cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob), cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+    float wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob), wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+    float wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob), wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+    while (__builtin_amdgcn_ballot_w64(eA < bA || eB < bB) != 0) {
+      const float4 hA0 = buf4(hbuf, h_off(eA < bA, cA0)), hA1 = buf4(hbuf, h_off(eA + 1 < bA, cA1));
+      const float4 hB0 = buf4(hbuf, h_off(eB < bB, cB0)), hB1 = buf4(hbuf, h_off(eB + 1 < bB, cB1));
+      const float uA0 = wA0, uA1 = wA1, uB0 = wB0, uB1 = wB1;
+      eA += 2; eB += 2;
+      cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob); cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+      cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob); cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+      wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob); wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+      wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob); wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+      // (a missing entry loaded zeros and its weight is 0 or 1: fma(w, 0, acc) = acc, acc + 0 = acc -- every row is its CSR-order sum)
+      if (WEIGHTED) {
+        accA = f4_fma(uA0, hA0, accA); accB = f4_fma(uB0, hB0, accB);
+        accA = f4_fma(uA1, hA1, accA); accB = f4_fma(uB1, hB1, accB);
+      } else {
+        accA = f4_add(accA, hA0); accB = f4_add(accB, hB0);
+        accA = f4_add(accA, hA1); accB = f4_add(accB, hB1);
+      }
+    }
+    if (posA < cnt) epilogue(accA, row0 + (int)(rrA.w & 0xFFFFu));
+    if (posB < cnt) epilogue(accB, row0 + (int)(rrB.w & 0xFFFFu));
+    return;
+  }
+  // kinds 1 and 0: a wave walks entries [wa, wb) of one row, its four lane groups taking every fourth entry, 4 per group and trip
+  const RowRec rr = rowrec[p0 + (kind == 1 ? min(wave, cnt - 1) : 0)];
+  const int deg = (int)(rr.w >> 16);
+  int wa = rr.a, wb = rr.a + (kind == 1 && wave >= cnt ? 0 : deg);
+  if (kind == 0) { const int per = (deg + 3) / 4; wa = rr.a + wave * per; wb = min(rr.a + deg, wa + per); }
+  constexpr int HU = 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int ci[HU];
+  float wv[HU];
+  int e = wa + g;
+#pragma unroll
+  for (int u = 0; u < HU; ++u) {
+    const unsigned off = e + 4 * u < wb ? (unsigned)(e + 4 * u) * 4u : kOob;
+    ci[u] = ld_col(off); wv[u] = ld_val(off);
+  }
+  while (__builtin_amdgcn_ballot_w64(e < wb) != 0) {
+    float4 hv[HU];
+    float uv[HU];
+#pragma unroll
+    for (int u = 0; u < HU; ++u) { hv[u] = buf4(hbuf, h_off(e + 4 * u < wb, ci[u])); uv[u] = wv[u]; }
+    e += 4 * HU;
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const unsigned off = e + 4 * u < wb ? (unsigned)(e + 4 * u) * 4u : kOob;
+      ci[u] = ld_col(off); wv[u] = ld_val(off);
+    }
+#pragma unroll
+    for (int u = 0; u < HU; ++u) acc = WEIGHTED ? f4_fma(uv[u], hv[u], acc) : f4_add(acc, hv[u]);
+  }
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {          // the wave's four groups, fixed order
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+  }
+  const int row = row0 + (int)(rr.w & 0xFFFFu);
+  if (kind == 1) {
+    if (g == 0 && wave < cnt) epilogue(acc, row);
+    return;
+  }
+  if (g == 0) s_long[wave][sub] = acc;                // kind 0: the four waves' quarters, in wave order
+  __syncthreads();
+  if (wave == 0 && g == 0) epilogue(f4_add(f4_add(s_long[0][sub], s_long[1][sub]), f4_add(s_long[2][sub], s_long[3][sub])), row);
+}
+
 // Fallback for widths / strides that are not multiples of 4 floats: one lane per column.
 __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ colidx,
@@ -1443,6 +1574,9 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
 // What the diagonal-block structure of a disjoint batch buys: which graphs fit an LDS tile (and
 // at which slab width), largest first so the work queue ends on small items; 32-row chunks of
 // the graphs that do not, for the rows kernel.  Built once per batch; owned by the caller.
+// A column-block graph (spmm_cb_kernel): too tall for a tile, at least kCbMinRows rows, local rows in 16 bits (RowRec)
+static inline bool cb_graph(int ng, int cap2) { return ng >= kCbMinRows && ng > cap2 && ng < 65536; }
+
 struct RowOrder {                       // the tile kernels' degree order of one rowptr (device pointer): see RowRec
   const int32_t* rowptr = nullptr;
   RowRec* dev = nullptr;
@@ -1451,7 +1585,12 @@ struct RowOrder {                       // the tile kernels' degree order of one
   HubSeg* hub_segs = nullptr;
   HubRow* hub_rows = nullptr;
   int nhubs = 0, nsegs = 0, nhubs_tall = 0, nsegs_tall = 0;
+  int nhubs_cb = 0, nsegs_cb = 0;       // ... and among those, first, the hub rows of the column-block graphs (>= kCbMinRows rows)
   int nnz = 0;
+  // work items of spmm_cb_kernel, per column-block count (f / 64), built on first use from the host copy of the degrees
+  struct CbItems { int nblocks = 0, nitems = 0; int4* dev = nullptr; } cb_items[2];
+  int ncb_sets = 0;
+  std::vector<int> cb_deg;              // degrees of the column-block graphs' rows in RowRec order (host; empty: none)
 };
 struct gcnx_spmm_plan {
   std::vector<int32_t> bp;              // host copy of block_ptr
@@ -1470,6 +1609,13 @@ struct gcnx_spmm_plan {
   int nitems = 0, n16 = 0;
   int2* pipe_chunks = nullptr;          // ... and the 32-row chunks of the graphs too tall for it (> 1248 rows), for the rows kernel
   int npipe_chunks = 0;
+  // column-block graphs (>= kCbMinRows rows; spmm_cb_kernel): their row chunks come FIRST in the row-chunk list
+  // [dev + n1 + n2, + nchunks) -- nchunks_cb of them -- so that every user of that list keeps working; `rest` lists the
+  // rows of all OTHER graphs as chunks (what the row gather takes when no tile kernel runs and the cb graphs go their own way)
+  int ncb_graphs = 0, nchunks_cb = 0;
+  long long cb_rows = 0;
+  int2* rest = nullptr;
+  int nrest = 0, rest_rpc = kRowsPerChunk;
 };
 
 #ifdef GCNX_TUNING
@@ -1490,7 +1636,9 @@ static void plan_free(gcnx_spmm_plan* p) {
   if (p->tall_gids) (void)hipFree(p->tall_gids);
   if (p->items) (void)hipFree(p->items);
   if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
+  if (p->rest) (void)hipFree(p->rest);
   for (int i = 0; i < p->norders; ++i) {
+    for (int k = 0; k < p->orders[i].ncb_sets; ++k) if (p->orders[i].cb_items[k].dev) (void)hipFree(p->orders[i].cb_items[k].dev);
     if (p->orders[i].dev) (void)hipFree(p->orders[i].dev);
     if (p->orders[i].hub_segs) (void)hipFree(p->orders[i].hub_segs);
     if (p->orders[i].hub_rows) (void)hipFree(p->orders[i].hub_rows);
@@ -1523,13 +1671,14 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
       const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
       if (ng <= 0) continue;
       if (r0 < 0 || r0 + ng > n) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_bind: block %d leaves the %d rows of this operator", g, n);
-      if (ng > p->cap2) {                          // not a tile graph: identity (never read by the tile kernels)
+      const bool cbg = cb_graph(ng, p->cap2);
+      if (ng > p->cap2 && !cbg) {                  // neither a tile graph nor a column-block graph: identity (never read)
         for (int i = 0; i < ng; ++i) rec[(size_t)r0 + i] = RowRec{rp[r0 + i], (unsigned)0};
         continue;
       }
-      // degree order inside windows of `win` consecutive rows (win >= ng: the whole graph)
+      // degree order inside windows of `win` consecutive rows (win >= ng: the whole graph; always for a column-block graph)
       const int span = ng <= p->cap1 ? 128 : 256;             // rows per row group of the tier that takes this graph
-      const int win = ctx->knob_spmm_sort_win > 0 ? ctx->knob_spmm_sort_win * span : ng;
+      const int win = ctx->knob_spmm_sort_win > 0 && !cbg ? ctx->knob_spmm_sort_win * span : ng;
       for (int w0 = 0; w0 < ng; w0 += win) {
         const int wn = std::min(win, ng - w0);
         int dmax = 0;
@@ -1550,14 +1699,22 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
         }
       }
     }
+    // the column-block graphs' degrees in RowRec order (what their work lists are cut from, per feature width)
+    std::vector<int> cb_deg;
+    for (int g = 0; g < p->nblocks; ++g) {
+      const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
+      if (!cb_graph(ng, p->cap2)) continue;
+      for (int i = 0; i < ng; ++i) cb_deg.push_back((int)(rec[(size_t)r0 + i].w >> 16));
+    }
     // hub rows as segments: rows of graphs too tall for a tile first (the tile kernels walk their own long rows)
     std::vector<HubSeg> segs;
     std::vector<HubRow> hubs;
-    int nh_tall = 0, ns_tall = 0;
-    for (int pass = 0; pass < 2; ++pass) {
+    int nh_tall = 0, ns_tall = 0, nh_cb = 0, ns_cb = 0;
+    for (int pass = 0; pass < 3; ++pass) {         // column-block graphs, other graphs too tall for a tile, tile graphs
       for (int g = 0; g < p->nblocks; ++g) {
         const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
-        if ((ng > p->cap2) != (pass == 0)) continue;
+        const int cls = cb_graph(ng, p->cap2) ? 0 : (ng > p->cap2 ? 1 : 2);
+        if (cls != pass) continue;
         for (int i = 0; i < ng; ++i) {
           const int a = rp[r0 + i], b = rp[r0 + i + 1];
           if (b - a <= kHubDeg) continue;
@@ -1566,7 +1723,8 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
           for (int k = 0; k < ns; ++k) segs.push_back(HubSeg{r0 + i, a + k * kHubSeg, std::min(b, a + (k + 1) * kHubSeg), (int)segs.size()});
         }
       }
-      if (pass == 0) { nh_tall = (int)hubs.size(); ns_tall = (int)segs.size(); }
+      if (pass == 0) { nh_cb = (int)hubs.size(); ns_cb = (int)segs.size(); }
+      if (pass == 1) { nh_tall = (int)hubs.size(); ns_tall = (int)segs.size(); }
     }
     RowRec* dev = nullptr;
     HubSeg* dsegs = nullptr;
@@ -1590,6 +1748,14 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
     slot->rowptr = rowptr; slot->dev = dev; slot->n = n;
     slot->hub_segs = dsegs; slot->hub_rows = dhubs;
     slot->nhubs = (int)hubs.size(); slot->nsegs = (int)segs.size(); slot->nhubs_tall = nh_tall; slot->nsegs_tall = ns_tall;
+    slot->nhubs_cb = nh_cb; slot->nsegs_cb = ns_cb;
+    for (int k = 0; k < slot->ncb_sets; ++k) {       // work lists cut from the old degrees go (retired under live graphs)
+      if (!slot->cb_items[k].dev) continue;
+      if (ctx->live_graphs > 0) ctx->retired_ws.push_back(slot->cb_items[k].dev); else (void)hipFree(slot->cb_items[k].dev);
+      slot->cb_items[k] = RowOrder::CbItems();
+    }
+    slot->ncb_sets = 0;
+    slot->cb_deg.swap(cb_deg);
     slot->nnz = rp[n];
   } catch (const std::bad_alloc&) {
     return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_plan_bind: out of host memory");
@@ -1622,20 +1788,89 @@ static int plan_order(gcnx_ctx* ctx, const gcnx_spmm_plan* cplan, const int32_t*
 // The hub rows of a bound plan (all of them, or only those of graphs too tall for a tile): segments -> partial rows in the
 // ctx workspace -> combine + epilogue.
 static int launch_hubs(gcnx_ctx* ctx, const RowOrder* od, bool tall_only, const int32_t* colidx, const float* vals, const float* h,
-                       int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act, const FoldArgs* fold) {
-  const int nsegs = tall_only ? od->nsegs_tall : od->nsegs, nhubs = tall_only ? od->nhubs_tall : od->nhubs;
-  if (nsegs == 0) return GCNX_OK;
-  int rc = gcnx_ws_reserve(ctx, (size_t)nsegs * f * sizeof(float));
+                       int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act, const FoldArgs* fold,
+                       bool skip_cb = false /* the column-block graphs' hub rows are computed elsewhere */) {
+  const int seg0 = skip_cb ? od->nsegs_cb : 0, hub0 = skip_cb ? od->nhubs_cb : 0;
+  const int nsegs = (tall_only ? od->nsegs_tall : od->nsegs) - seg0, nhubs = (tall_only ? od->nhubs_tall : od->nhubs) - hub0;
+  if (nsegs <= 0) return GCNX_OK;
+  int rc = gcnx_ws_reserve(ctx, (size_t)(seg0 + nsegs) * f * sizeof(float));       // (slots are absolute list positions)
   if (rc) return rc;
   float* part = (float*)ctx->ws;
   const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
-#define GCNX_HUB_SEG(W, F) hipLaunchKernelGGL((spmm_hub_seg_kernel<W, F>), dim3(nsegs), dim3(256), 0, ctx->stream, od->hub_segs, colidx, vals, h, ldh, part, n, f, od->nnz)
+#define GCNX_HUB_SEG(W, F) hipLaunchKernelGGL((spmm_hub_seg_kernel<W, F>), dim3(nsegs), dim3(256), 0, ctx->stream, od->hub_segs + seg0, colidx, vals, h, ldh, part, n, f, od->nnz)
   if (vals) { if (fold) GCNX_HUB_SEG(true, true); else GCNX_HUB_SEG(true, false); }
   else { if (fold) GCNX_HUB_SEG(false, true); else GCNX_HUB_SEG(false, false); }
 #undef GCNX_HUB_SEG
   GCNX_LAUNCH_OK(ctx);
-  if (fold) hipLaunchKernelGGL((spmm_hub_combine_kernel<true>), dim3(nhubs), dim3(64), 0, ctx->stream, od->hub_rows, (const float*)part, bias, out, ldo, f, act, fo);
-  else hipLaunchKernelGGL((spmm_hub_combine_kernel<false>), dim3(nhubs), dim3(64), 0, ctx->stream, od->hub_rows, (const float*)part, bias, out, ldo, f, act, fo);
+  if (fold) hipLaunchKernelGGL((spmm_hub_combine_kernel<true>), dim3(nhubs), dim3(64), 0, ctx->stream, od->hub_rows + hub0, (const float*)part, bias, out, ldo, f, act, fo);
+  else hipLaunchKernelGGL((spmm_hub_combine_kernel<false>), dim3(nhubs), dim3(64), 0, ctx->stream, od->hub_rows + hub0, (const float*)part, bias, out, ldo, f, act, fo);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+// Work items of spmm_cb_kernel for f = 64 * nblk columns: per column-block graph, per column block, its rows in degree order
+// cut into kind-0 / kind-1 / kind-2 items (see the kernel) -- in that order, so that one XCD (a contiguous range of the list)
+// walks a graph block by block, heaviest rows first.  Built on first use per block count (uploads: not inside a capture),
+// two counts kept per bound row order.
+static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder* corder, int nblk, const int4** out, int* count) {
+  RowOrder* od = const_cast<RowOrder*>(corder);
+  for (int i = 0; i < od->ncb_sets; ++i)
+    if (od->cb_items[i].nblocks == nblk) { *out = od->cb_items[i].dev; *count = od->cb_items[i].nitems; return GCNX_OK; }
+  if (ctx->capturing)
+    return gcnx_fail(ctx, GCNX_ERR_INVALID, "gcnx_spmm_csr: the plan has no column-block work list for this width yet and building one "
+                     "uploads: run the call once before capturing");
+  try {
+    std::vector<int4> items;
+    size_t at = 0;                                             // position in od->cb_deg
+    for (int g = 0; g < p->nblocks; ++g) {
+      const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
+      if (!cb_graph(ng, p->cap2)) continue;
+      const int* deg = od->cb_deg.data() + at;                 // descending
+      at += (size_t)ng;
+      int n0 = 0, n1 = 0;                                      // rows of kind 0, of kind 0 or 1
+      while (n0 < ng && deg[n0] > kCbHub) ++n0;
+      n1 = n0;
+      while (n1 < ng && deg[n1] > kCbLong) ++n1;
+      int kinds = 7;
+#ifdef GCNX_TUNING   // timing only: GCNX_SPMM_CB = 8 + mask launches only the kinds in mask (results are then incomplete)
+      if (ctx->knob_spmm_cb >= 8) kinds = ctx->knob_spmm_cb & 7;
+#endif
+      for (int b = 0; b < nblk; ++b) {
+        if (kinds & 1) for (int q = 0; q < n0; ++q) items.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols, r0));
+        if (kinds & 2) for (int q = n0; q < n1; q += 4) items.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols, r0));
+        if (kinds & 4) for (int q = n1; q < ng; q += 32) items.push_back(make_int4(r0 + q, std::min(32, ng - q) | (2 << 16), b * kCbCols, r0));
+      }
+    }
+    int4* dev = nullptr;
+    const hipError_t e = plan_upload(ctx, &dev, items);
+    if (e != hipSuccess) return gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_csr (column-block list): %s", hipGetErrorString(e));
+    RowOrder::CbItems* set = od->ncb_sets < 2 ? &od->cb_items[od->ncb_sets++] : &od->cb_items[0];
+    if (set->dev) {                                            // (a third width: the first set goes -- retired under live graphs)
+      if (ctx->live_graphs > 0) ctx->retired_ws.push_back(set->dev); else (void)hipFree(set->dev);
+    }
+    set->nblocks = nblk; set->nitems = (int)items.size(); set->dev = dev;
+    *out = dev; *count = set->nitems;
+  } catch (const std::bad_alloc&) {
+    return gcnx_fail(ctx, GCNX_ERR_NOMEM, "gcnx_spmm_csr: out of host memory");
+  }
+  return GCNX_OK;
+}
+
+// Whether the column-block graphs of `plan` go through spmm_cb_kernel for this call (else: the row gather + hub segments).
+static bool cb_path_ok(const gcnx_ctx* ctx, const gcnx_spmm_plan* plan, int32_t n, int32_t f, int64_t ldh, int out16) {
+  return plan && plan->ncb_graphs > 0 && ctx->knob_spmm_cb != 0 && !out16 && f >= kCbMinF && f % kCbCols == 0 &&
+         (uint64_t)n * (uint64_t)ldh * 4u < 0xFFFFFF00ull;
+}
+
+static int launch_cb(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const RowOrder* order, const int32_t* colidx, const float* vals, const float* h,
+                     int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act) {
+  const int4* items = nullptr;
+  int nitems = 0;
+  const int rc = plan_cb_items(ctx, plan, order, f / kCbCols, &items, &nitems);
+  if (rc) return rc;
+  if (nitems == 0) return GCNX_OK;
+  if (vals) hipLaunchKernelGGL((spmm_cb_kernel<true>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items);
+  else hipLaunchKernelGGL((spmm_cb_kernel<false>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -1731,14 +1966,28 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     // (r2 PMC: 496 MB fetched for 116 MB of rows); 8-row chunks keep it to about one graph.
     const int rpc = ctx->knob_spmm_tall_rpc == 32 ? kRowsPerChunk : kRowsPerChunkSmall;
     p->chunk_rpc = rpc;
+    std::vector<int2> ch_cb, rest;
+    long long rest_rows = 0;
+    for (int g = 0; g < nblocks; ++g) {
+      const int ng = bp[g + 1] - bp[g];
+      if (ng < 0) { plan_free(p); return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g); }
+      if (!cb_graph(ng, cap2)) rest_rows += ng;
+    }
+    p->rest_rpc = rest_rows < 16 * 1024 * kRowsPerChunk / 4 ? kRowsPerChunkSmall : kRowsPerChunk;   // (launch_rows' own rule)
     for (int g = 0; g < nblocks; ++g) {
       const int r0 = bp[g], ng = bp[g + 1] - bp[g];
-      if (ng < 0) { plan_free(p); return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_create: block_ptr is not non-decreasing at %d", g); }
       if (ng == 0) continue;
+      const bool cbg = cb_graph(ng, cap2);                      // a column-block graph (spmm_cb_kernel)
       if (ng <= cap1) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
       else if (ng <= cap2) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
-      else for (int r = r0; r < r0 + ng; r += rpc) ch.push_back(make_int2(r, std::min(r + rpc, r0 + ng)));
+      else for (int r = r0; r < r0 + ng; r += rpc) (cbg ? ch_cb : ch).push_back(make_int2(r, std::min(r + rpc, r0 + ng)));
+      if (cbg) { p->ncb_graphs++; p->cb_rows += ng; }
+      else for (int r = r0; r < r0 + ng; r += p->rest_rpc) rest.push_back(make_int2(r, std::min(r + p->rest_rpc, r0 + ng)));
     }
+    p->nchunks_cb = (int)ch_cb.size();
+    ch.insert(ch.begin(), ch_cb.begin(), ch_cb.end());           // the column-block graphs' chunks first
+    if (p->ncb_graphs == 0) rest.clear();                        // (only read next to spmm_cb_kernel)
+    p->nrest = (int)rest.size();
     auto by_size = [](const int2& x, const int2& y) { return x.y != y.y ? x.y > y.y : x.x < y.x; };
     std::sort(t1.begin(), t1.end(), by_size);
     std::sort(t2.begin(), t2.end(), by_size);
@@ -1783,6 +2032,7 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     if (e == hipSuccess) e = plan_upload(ctx, &p->tall_gids, tall_gids);
     if (e == hipSuccess) e = plan_upload(ctx, &p->pipe_chunks, tall);
     if (e == hipSuccess) e = plan_upload(ctx, &p->items, items);
+    if (e == hipSuccess) e = plan_upload(ctx, &p->rest, rest);
     if (e != hipSuccess) {
       plan_free(p);
       return gcnx_fail(ctx, e == hipErrorOutOfMemory ? GCNX_ERR_NOMEM : GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e));
@@ -1819,7 +2069,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
 // The conditions of the bf16-result forms (gcnx_spmm_csr_bf16out / _pool_bwd_bf16out): weighted operator, every tile
 // graph on the 1024-thread shape, taller graphs as 8-row chunks, no hub rows.
 static bool out16_shape_ok(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const float* vals, int32_t f, int64_t ldo, const void* out) {
-  return plan && vals && f % kSlab == 0 && f > 128 && ldo % 4 == 0 && aligned16(out) && plan->n1 == 0 && plan->n2 > 0 &&
+  return plan && vals && f % kSlab == 0 && f > 128 && ldo % 4 == 0 && aligned16(out) && plan->n1 == 0 && plan->n2 > 0 && plan->ncb_graphs == 0 &&
          (plan->nchunks == 0 || plan->chunk_rpc == kRowsPerChunkSmall) && ctx->knob_spmm_kernel != 1 && ctx->knob_spmm_kernel != 3 &&
          (long long)(2 * plan->n2) * (f / kSlab) >= 4LL * ctx->num_cus;
 }
@@ -1953,7 +2203,19 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   const RowOrder* order = nullptr;
   if (plan && force != 3) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
   if (out16 && (!tiles || (order && order->nsegs_tall > 0))) return GCNX_ERR_UNSUPPORTED;     // (checked by the caller; hub rows: fp32 only)
+  const bool cb = cb_path_ok(ctx, plan, n, f, ldh, out16) && order != nullptr;
   if (!tiles) {
+    if (cb) {
+      // graphs too large for an XCD's L2: column blocks (spmm_cb_kernel, hub rows included); every other graph's rows
+      // as plan-listed chunks on the row gather, their hub rows as segments
+      if (plan->nrest > 0) {
+        const bool hubs = order->nsegs > order->nsegs_cb;
+        dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->rest, plan->nrest, nullptr, plan->rest_rpc, hubs ? kHubDeg : 0);
+        GCNX_LAUNCH_OK(ctx);
+        if (hubs) { const int rh = launch_hubs(ctx, order, false, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, true); if (rh) return rh; }
+      }
+      return launch_cb(ctx, plan, order, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
+    }
     // (with a bound plan: the rows of more than kHubDeg entries go to the hub kernels)
     const bool hubs = order && order->nsegs > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, 0, nullptr, kRowsPerChunk, hubs ? kHubDeg : 0);
@@ -2045,13 +2307,19 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
     rc = launch_duo<512, 32, 4>(ctx, rowptr, rowrec, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev, plan->n1, &bo, dmode);
     ctx->stream = home;
   }
-  if (!rc && plan->nchunks > 0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
+  const int ch0 = cb ? plan->nchunks_cb : 0;         // (column-block graphs' chunks come first in the list)
+  if (!rc && plan->nchunks > ch0) {   // graphs taller than any tile: plan-listed 32-row chunks on the rows kernel
     if (conc) ctx->stream = aux[1];
-    const bool hubs = order && order->nsegs_tall > 0;
-    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2,
-                  plan->nchunks, nullptr, plan->chunk_rpc, hubs ? kHubDeg : 0, out16);
+    const bool hubs = order && order->nsegs_tall > (cb ? order->nsegs_cb : 0);
+    dispatch_rows(ctx, rowptr, colidx, vals, h, ldh, bias, out, ldo, n, f, act, plan->dev + plan->n1 + plan->n2 + ch0,
+                  plan->nchunks - ch0, nullptr, plan->chunk_rpc, hubs ? kHubDeg : 0, out16);
     if (hipGetLastError() != hipSuccess) rc = gcnx_fail(ctx, GCNX_ERR_HIP, "gcnx_spmm_csr: row-chunk launch failed");
-    if (!rc && hubs) rc = launch_hubs(ctx, order, true, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr);
+    if (!rc && hubs) rc = launch_hubs(ctx, order, true, colidx, vals, h, ldh, bias, out, ldo, n, f, act, nullptr, cb);
+    ctx->stream = home;
+  }
+  if (!rc && cb) {
+    if (conc) ctx->stream = aux[1];
+    rc = launch_cb(ctx, plan, order, colidx, vals, h, ldh, bias, out, ldo, n, f, act);
     ctx->stream = home;
   }
   if (conc) { const int rj = gcnx_aux_join(ctx); if (!rc) rc = rj; }

@@ -250,8 +250,9 @@ class DeviceCSR:
     graph_ptr block (what the tile plan and the folded pool backward assume); a batch that fails it is refused.
     """
 
-    def __init__(self, ctx, n, nnz, rowptr, colidx, vals=None, block_ptr=None, n_blocks=0, symmetric=None):
+    def __init__(self, ctx, n, nnz, rowptr, colidx, vals=None, block_ptr=None, n_blocks=0, symmetric=None, max_block_rows=0):
         self.ctx, self.n, self.nnz = ctx, int(n), int(nnz)
+        self.max_block_rows = int(max_block_rows)     # rows of the largest graph, where the constructor knew graph_ptr on the host (0: unknown)
         self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
         self.block_ptr, self.n_blocks = block_ptr, int(n_blocks)
         self._t = None
@@ -286,7 +287,9 @@ class DeviceCSR:
         # width reaches that, and building a plan (a D2H copy, a host sort, an upload) per streamed batch is wasted.
         # (r3: a large batch of FEW graphs -- config 5: 122 power-law graphs of 8 192 nodes -- gets a plan too: it lists the hub
         # rows, which then run as segments on workgroups of their own)
-        if self.n_blocks < 128 and self.n < 131072 and not getattr(self.ctx, "_force_plan", False):
+        # (r4: and a batch that holds a graph of >= 4096 rows, whatever its size -- the plan lists the column-block work of such
+        # graphs, whose feature rows do not fit an XCD's L2: spmm_cb_kernel)
+        if self.n_blocks < 128 and self.n < 131072 and self.max_block_rows < 4096 and not getattr(self.ctx, "_force_plan", False):
             return None
         holder = self.block_ptr
         p = getattr(holder, "_spmm_plan", None)
@@ -322,7 +325,8 @@ class DeviceCSR:
         d_ci = ctx.to_device(colidx, np.int32)
         d_v = ctx.to_device(vals, np.float32) if vals is not None else None
         d_gp = ctx.to_device(graph_ptr, np.int32) if graph_ptr is not None else None
-        return cls(ctx, n, len(colidx), d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric)
+        return cls(ctx, n, len(colidx), d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric,
+                   _max_block(graph_ptr))
 
     @classmethod
     def from_coo(cls, ctx, indices, values, n, graph_ptr=None, symmetric=None, weighted=True):
@@ -338,7 +342,7 @@ class DeviceCSR:
         rows.free(); cols.free()
         d_v = ctx.to_device(values, np.float32) if (weighted and values is not None) else None
         d_gp = ctx.to_device(graph_ptr, np.int32) if graph_ptr is not None else None
-        return cls(ctx, n, nnz, d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric)
+        return cls(ctx, n, nnz, d_rp, d_ci, d_v, d_gp, 0 if graph_ptr is None else len(graph_ptr) - 1, symmetric, _max_block(graph_ptr))
 
     def gcn_norm(self, mode="spektral"):
         """Device gcn_filter: returns a CSR sharing structure with self, values = A^."""
@@ -347,7 +351,7 @@ class DeviceCSR:
                                                  self.vals.ptr if self.vals is not None else None, self.n,
                                                  L.NORM_SPEKTRAL if mode == "spektral" else L.NORM_PYG, out.ptr))
         return DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, out, self.block_ptr, self.n_blocks,
-                         self.symmetric)
+                         self.symmetric, self.max_block_rows)
 
     def transpose(self):
         if self.symmetric:
@@ -360,7 +364,7 @@ class DeviceCSR:
             ctx._ck(ctx.lib.gcnx_csr_transpose(ctx.h, self.rowptr.ptr, self.colidx.ptr,
                                                self.vals.ptr if self.vals is not None else None, self.n, self.nnz,
                                                rp.ptr, ci.ptr, v.ptr if v is not None else None))
-            self._t = DeviceCSR(ctx, self.n, self.nnz, rp, ci, v, self.block_ptr, self.n_blocks, False)
+            self._t = DeviceCSR(ctx, self.n, self.nnz, rp, ci, v, self.block_ptr, self.n_blocks, False, self.max_block_rows)
         return self._t
 
     def row_mean(self):
@@ -370,7 +374,7 @@ class DeviceCSR:
             deg = np.diff(self.rowptr.numpy()).astype(np.int64)
             vals = np.repeat(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0).astype(np.float32), deg)
             self._row_mean = DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, self.ctx.to_device(vals), self.block_ptr,
-                                       self.n_blocks, False)
+                                       self.n_blocks, False, self.max_block_rows)
         return self._row_mean
 
     def unweighted(self):
@@ -380,8 +384,13 @@ class DeviceCSR:
             return self
         if getattr(self, "_unweighted", None) is None:
             self._unweighted = DeviceCSR(self.ctx, self.n, self.nnz, self.rowptr, self.colidx, None, self.block_ptr, self.n_blocks,
-                                         self.symmetric)
+                                         self.symmetric, self.max_block_rows)
         return self._unweighted
+
+
+def _max_block(graph_ptr):
+    gp = np.asarray(graph_ptr) if graph_ptr is not None else None
+    return int(np.diff(gp).max()) if gp is not None and gp.size > 1 else 0
 
 
 class _Plan:

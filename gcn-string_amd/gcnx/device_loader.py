@@ -91,7 +91,8 @@ def collate_on_device(ds, indices, bufs=None):
     seg = D.Segments.from_device(ctx, V(bufs.gp, 0, (b + 1,)), bn)
     seg._ids = V(bufs.ids, 0, (max(n, 1),))              # (otherwise built on the host on first use and uploaded)
     a = D.DeviceCSR(ctx, n, nnz, V(bufs.rowptr, 0, (n + 1,)), V(bufs.colidx, 0, (max(nnz, 1),)),
-                    V(bufs.vals, 0, (max(nnz, 1),)) if bufs.vals is not None else None, seg.dev, b, ds.symmetric)
+                    V(bufs.vals, 0, (max(nnz, 1),)) if bufs.vals is not None else None, seg.dev, b, ds.symmetric,
+                    int(ds.sizes[sel].max()) if b else 0)
     batch = DeviceBatch(ctx, V(bufs.x, 0, (n, f)), a, seg, V(bufs.y, 0, (b, c)))
     batch._bufs = bufs                                   # keeps the capacity buffers alive with the batch
     return batch

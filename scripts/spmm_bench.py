@@ -19,6 +19,7 @@ ap.add_argument("--shard", default="", help="r,w: rank r's shard of w (block1m; 
 ap.add_argument("--pads", default="", help="comma list of MiB: re-time with h and out re-allocated that far apart (HBM channel phase of the two streams)")
 ap.add_argument("--hog", type=int, default=0, help="GiB allocated (and kept) before anything else: does where the arrays land matter?")
 ap.add_argument("--hog-after-csr", type=int, default=0)
+ap.add_argument("--cb", type=int, default=-1, help="spmm_cb knob for the whole process (tuning build: 8 + mask = only those kinds of column-block items)")
 ap.add_argument("--conc", type=int, default=-1, help="1 / 0: the plan path's launches as concurrent branches or not (spmm_conc)")
 args = ap.parse_args()
 if args.workload == "block1m":       # the batches bench.py times (per-graph-seeded generators)
@@ -59,7 +60,9 @@ for rnd in range(args.rounds):
         # variants: "0" = what the library picks; "rows" / "tile" / "pipe" = that kernel; a number = rows kernel, that slab width
         if "GCNX_SPMM_KERNEL" not in os.environ:
             ctx.set_tuning("spmm_slab", 0)
-            if slab in ("rows", "tile", "pipe"): ctx.set_tuning("spmm_kernel", slab)
+            ctx.set_tuning("spmm_cb", 0 if slab == "cb0" else (args.cb if args.cb >= 0 else 1))      # "cb0": graphs of >= 4096 rows on the row gather + hub segments (r3)
+            if slab == "cb0": ctx.set_tuning("spmm_kernel", "auto")
+            elif slab in ("rows", "tile", "pipe"): ctx.set_tuning("spmm_kernel", slab)
             elif slab[0] == "t": ctx.set_tuning("spmm_slab", int(slab[1:])); ctx.set_tuning("spmm_kernel", "auto")   # tiers, tall graphs' row chunks in slabs
             elif slab != "0": ctx.set_tuning("spmm_slab", int(slab)); ctx.set_tuning("spmm_kernel", "rows")
             else: ctx.set_tuning("spmm_kernel", "auto")

@@ -1823,3 +1823,77 @@ def test_spmm_double_buffered_tiles_with_rows_past_the_register_held_entries(ctx
     assert np.array_equal(outs["tile"], outs["rows"])
     assert np.array_equal(outs["bits"], outs["rows"])
     assert rel_err(outs["tile"], _ref_spmm(hb, vals, hb.x, bias, True)) < TIGHT
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("f", [128, 256])
+def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
+    """BASELINE config 5 in small (r4): power-law graphs of 8 192 nodes (degrees up to 4096) are walked by spmm_cb_kernel one
+    64-column block at a time -- short rows four to a wave, rows of more than 32 entries (hub rows included) by all four
+    waves -- next to graphs of ordinary size, which keep the row gather (this batch) or the tile kernels (the next test).
+    Against scipy in fp64; at f = 256 the rows of at most 32 entries bit for bit against the row gather + hub segments of
+    round 3 (GCNX_SPMM_CB=0: same CSR-order sums); bit-reproducible; bias + ReLU and plain."""
+    import scipy.sparse as sp
+    from gcnx import device as D, synth
+    big = synth.power_law_batch(3, 8192, f, seed=3)
+    small = synth.ecoli_batch(5, f, seed=8)
+    hb = synth.concat_batches([small.slice_graphs(0, 2), big, small.slice_graphs(2, 5)])     # cb graphs in the middle
+    deg = np.diff(hb.rowptr)
+    assert deg.max() >= 2048 and (deg > 256).sum() >= 3 and (np.diff(hb.graph_ptr) >= 4096).sum() == 3
+    csr, vals = _csr(ctx, hb, weighted)
+    assert csr.plan is not None
+    rng = np.random.default_rng(7)
+    a64 = sp.csr_matrix((np.ones(hb.nnz) if vals is None else vals.astype(np.float64), hb.colidx, hb.rowptr), shape=(hb.n, hb.n))
+    h = rng.standard_normal((hb.n, f), dtype=np.float32); bias = rng.standard_normal(f).astype(np.float32)
+    dh, db = ctx.to_device(h), ctx.to_device(bias)
+    outs = {}
+    try:
+        for cb in (1, 0):
+            ctx.set_tuning("spmm_cb", cb)
+            o = ctx.zeros((hb.n, f))
+            D.spmm(ctx, csr, dh, db, o, act="relu")
+            outs[cb] = o.numpy()
+        ctx.set_tuning("spmm_cb", 1)
+        o2 = ctx.zeros((hb.n, f)); D.spmm(ctx, csr, dh, db, o2, act="relu")
+        assert np.array_equal(o2.numpy(), outs[1])                                  # bit-reproducible
+        o3 = ctx.zeros((hb.n, f)); D.spmm(ctx, csr, dh, None, o3)
+        assert rel_err(o3.numpy(), a64 @ h.astype(np.float64)) < TIGHT              # no bias, no activation
+    finally:
+        ctx.set_tuning("spmm_cb", 0)
+    ref = np.maximum(a64 @ h.astype(np.float64) + bias, 0)
+    assert rel_err(outs[1], ref) < TIGHT and rel_err(outs[0], ref) < TIGHT
+    hubs = np.nonzero(deg > 256)[0]
+    assert rel_err(outs[1][hubs], ref[hubs]) < TIGHT
+    if f == 256:       # (at f = 256 the row gather walks a row with ONE lane group, in CSR order like the column blocks; at 128 with two)
+        short = deg <= 32
+        assert np.array_equal(outs[1][short], outs[0][short])
+
+
+def test_spmm_column_blocks_next_to_the_tile_kernels(ctx):
+    """A batch with enough small graphs for the tile kernels AND two graphs of >= 4096 rows: tiles for the former, column
+    blocks for the latter, one call -- against scipy, and the captured form replays (the work list is built by the eager run)."""
+    import scipy.sparse as sp
+    from gcnx import device as D, synth
+    f = 256
+    big = synth.power_law_batch(2, 4608, f, seed=5, max_deg=1024)
+    small = synth.block_diag_batch(60000, 600000, f, seed=4, mean_size=300)
+    hb = synth.concat_batches([small, big])
+    assert small.n_graphs >= 128 and (np.diff(hb.graph_ptr) >= 4096).sum() == 2
+    csr, vals = _csr(ctx, hb, True)
+    a64 = sp.csr_matrix((vals.astype(np.float64), hb.colidx, hb.rowptr), shape=(hb.n, hb.n))
+    rng = np.random.default_rng(9)
+    h = rng.standard_normal((hb.n, f), dtype=np.float32); bias = rng.standard_normal(f).astype(np.float32)
+    dh, db = ctx.to_device(h), ctx.to_device(bias)
+    o = ctx.zeros((hb.n, f))
+    ctx.set_tuning("spmm_cb", 1)                       # (opt-in: GCNX_SPMM_CB=1)
+    try:
+        D.spmm(ctx, csr, dh, db, o, act="relu")
+        ref = np.maximum(a64 @ h.astype(np.float64) + bias, 0)
+        assert rel_err(o.numpy(), ref) < TIGHT
+        o.fill_zero()
+        g = ctx.capture(lambda: D.spmm(ctx, csr, dh, db, o, act="relu"))
+        g.launch(); ctx.sync()
+        assert rel_err(o.numpy(), ref) < TIGHT
+        g.destroy()
+    finally:
+        ctx.set_tuning("spmm_cb", 0)

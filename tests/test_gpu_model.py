@@ -823,15 +823,15 @@ def test_general_gnn_linear_head_is_spektrals_default_activation(ctx):
     out = lin(batch, training=False)
     assert rel_err(out, rlog) < TOL and not np.allclose(out.sum(1), 1.0)                   # logits, not probabilities
     assert rel_err(soft(batch, training=False), O.softmax(rlog)) < TOL
+    le, ae, oute = lin.evaluate_batch(batch, None)                 # (before any training step moves the moving statistics)
+    assert rel_err(oute, rlog) < TOL
+    assert abs(le - O.cce_loss_from_logits(hb.y.astype(np.float64), rlog)) < TOL * max(1.0, le)
     l1, a1 = lin.train_step(batch, None, lr=0.0)
     l2, a2 = soft.train_step(batch, None, lr=0.0)
     assert l1 == l2 and a1 == a2
     for ga, gb in zip(lin.gradients(), soft.gradients()):
         for k in ga:
             assert np.array_equal(ga[k], gb[k]), k
-    le, ae, oute = lin.evaluate_batch(batch, None)
-    assert rel_err(oute, rlog) < TOL
-    assert abs(le - O.cce_loss_from_logits(hb.y.astype(np.float64), rlog)) < TOL * max(1.0, le)
 
 
 def _dropout_factors(ctx, model, rows_n, rows_b, step):
