@@ -298,7 +298,51 @@ def bench_generalgnn(ctx, args):
     ctx.close()
 
 
-def generalgnn_extra(ctx, steps=60):
+def generalgnn_bytes(layers, n, b, nnz, hidden, mp):
+    """Per-op compulsory HBM bytes of one GeneralGNN training step: every launchable operation of the step reads
+    each of its operands once and writes its result once, fp32, perfect reuse INSIDE an operation and none across -- the
+    figure `generalgnn.*.hbm_frac` is taken on.  Dense: x, W in, z out; BatchNorm + activation: z in, y out; aggregation:
+    CSR + h in, rows out; pool; backward: the transposed aggregation, BatchNorm backward (dy, z in, dz out -- one read of
+    each although the batch statistics of the gradient need two), dW (x, dz in), dX (dz, W in, dx accumulated: read +
+    write, first contribution write only)."""
+    tot = 0
+    wcat = hidden * (mp + 1)
+    for i, L in enumerate(layers):
+        r = b if L["group"] == "post" else n
+        fi, fo = L["fi"], L["fo"]
+        tot += 4 * (r * fi + fi * fo + r * fo)            # forward product
+        tot += 8 * r * fo                                 # BatchNorm + activation
+        tot += 12 * r * fo                                # ... backward
+        tot += 4 * (r * fi + r * fo + fi * fo)            # dW
+        if i > 0:
+            tot += 4 * (r * fo + fi * fo) + (8 if L["group"] == "gnn" else 4) * r * fi     # dX (accumulated into the skip slices)
+        if L["group"] == "gnn":
+            tot += 2 * (4 * (n + 1) + 4 * nnz + 8 * n * hidden)                              # aggregation, forward and transposed
+    tot += 2 * 4 * (n * wcat + b * wcat)                  # pool forward / backward
+    return tot
+
+
+def generalgnn_cpu_baseline(hb, budget_s):
+    """The fp32 NumPy restatement (oracle/gcn_oracle.py: general_gnn_loss_and_grads -- BLAS products, np.add.at aggregation)
+    of the same GeneralGNN step on the same batch, on this box's host cores: a reported baseline, "port", bounded sample."""
+    from oracle import gcn_oracle as O
+    rng = np.random.default_rng(0)
+    layers = O.general_gnn_init(rng, hb.f, 2, dtype=np.float32)
+    x, y = hb.x.astype(np.float32), hb.y.astype(np.float32)
+    csr = (hb.rowptr.astype(np.int64), hb.colidx.astype(np.int64), None)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        O.general_gnn_loss_and_grads(layers, x, csr, hb.graph_ptr, y)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 50:
+            break
+    return {"value": hb.n_graphs * steps / el, "unit": "graphs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{steps} forward + loss + gradient evaluations (no update) of the same batch in {el:.1f} s; NumPy fp32 restatement "
+                      f"(BLAS threads as NumPy finds them), not Spektral/TF (absent)"}
+
+
+def generalgnn_extra(ctx, steps=60, cpu_seconds=6.0):
     """Extra key of the default line: the reference's LIVE model -- GeneralGNN(2, activation="softmax"),
     gcn.py:320, NetSurfP-width inputs (F_in = 16, gcn_utills.py:293-300) -- on the same E. coli-shaped batch: forward + CCE +
     every gradient + SGD from one captured HIP graph, in exact fp32 and with the Dense products on the split-bf16 panel
@@ -332,9 +376,14 @@ def generalgnn_extra(ctx, steps=60):
             rows = hb.n_graphs if L["group"] == "post" else hb.n
             flops += 2 * rows * L["fi"] * L["fo"] * (2 if i == 0 else 3)
         peak = 157.3e12 if prec == "f32" else 2.5e15 / 3.0   # fp32 MFMA; bf16 MFMA at three products per multiply
+        nbytes = generalgnn_bytes(model.layers, hb.n, hb.n_graphs, hb.nnz, model.hidden, model.mp)
         out[prec] = {"ms_per_step": ms, "graphs_per_s": hb.n_graphs / (ms * 1e-3), "flops": flops,
-                     "frac_of_mfma_peak": flops / (ms * 1e-3) / peak, "params": model.n_params}
+                     "frac_of_mfma_peak": flops / (ms * 1e-3) / peak, "params": model.n_params,
+                     "compulsory_bytes": nbytes, "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "bound": "hbm (per-op compulsory bytes, generalgnn_bytes(); the products are far below the MFMA peak)"}
         keep.append(model)          # (captured graphs are destroyed with the process)
+    if cpu_seconds > 0:
+        out["cpu_baseline"] = generalgnn_cpu_baseline(hb, cpu_seconds)
     return out
 
 
@@ -661,7 +710,7 @@ def main():
 
     gnn_extra = None
     if world == 1 and args.workload == "ecoli" and args.emulate_rank is None and not args.no_generalgnn:
-        gnn_extra = generalgnn_extra(ctx)
+        gnn_extra = generalgnn_extra(ctx, cpu_seconds=min(args.cpu_seconds, 6.0))
     cfg4 = None
     if world > 1 and args.workload == "ecoli" and not args.no_config4 and not args.no_config3:
         cfg4 = config4_extra(ctx, comm, rank, world, lr, not args.no_graph)
