@@ -1288,24 +1288,29 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
 // rows in row order: the traffic fell as planned and the launch got slower (895 us against 705), because a wave walked
 // max(length of its 8 rows) trips with most lanes idle and the long rows ran one after the other behind barriers.  So the
 // rows of such a graph are taken in DEGREE order (the plan's RowRec list, as for the tile kernels) and an item is one of:
-//   kind 2  128 rows of at most kCbLong entries: a lane group per row, two rows per group, two entries of each per trip --
-//           neighbours in the order have (nearly) the same length, so a wave's trips are all useful; a wave walks four
-//           octets of rows, software-pipelined;
+//   kind 2  32 rows of at most kCbLong entries: a lane group per row, two rows per group, two entries of each per trip --
+//           neighbours in the order have (nearly) the same length, so a wave's trips are all useful;
 //   kind 1  4 rows of kCbLong + 1 .. kCbHub entries: a wave per row, 16 entries per trip (4 groups x 4);
 //   kind 0  1 row of more than kCbHub entries: the four waves take a quarter each (fixed combination order).
 // Heaviest first inside every (graph, block).  Index loads run one trip ahead of the gathers that need them (range-checked
 // buffer loads throughout: a missing entry costs no fetch and adds an exact zero), so a trip is one dependent round trip.
 // A row of kind 2 adds its entries in CSR order -- the row gather's order at f = 256, bit for bit.
+// Where it stands (r4, config 5: profiles/r04/config5_column_blocks_*.txt): HBM traffic 2.31 GB = 1.10 x the algorithmic bytes
+// (row gather + hub segments: 3.93 GB = 1.88 x), L2 hit rate 0.72 (0.52) -- and 728-755 us against 713-726: with the traffic
+// gone the launch is bound by what a wave keeps in flight, not by HBM.  Measured on the way and dropped: kind-2 items of
+// 128 rows software-pipelined over four octets per wave (records up front, the next octet's indices under this octet's
+// gathers, result stores delayed behind the next gathers because the memory counter is in order: 776-1000 us at occupancy
+// 6-8), and short rows left in row order with only the rows of more than 8 entries sorted (937 us).  OPT-IN therefore
+// (GCNX_SPMM_CB=1 / gcnx_set_tuning "spmm_cb"): the product path for such graphs is still the row gather + hub segments.
 // ----------------------------------------------------------------------------------------------
 constexpr int kCbCols = 64;          // columns per block
 constexpr int kCbMinRows = 4096;     // graphs of at least this many rows are walked this way (and fewer than 65 536: RowRec)
 constexpr int kCbLong = 32;          // kind 2 up to here
 constexpr int kCbHub = 512;          // kind 1 up to here
-constexpr int kCbOct = 4;            // kind 2: octets of rows per wave (an item is 32 x kCbOct rows)
 constexpr int kCbMinF = 128;         // narrower features: the whole graph fits L2 anyway
 
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256, 6) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
+__global__ __launch_bounds__(256, 8) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
                                                          const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh,
                                                          const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
                                                          int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items) {
@@ -1332,65 +1337,37 @@ __global__ __launch_bounds__(256, 6) void spmm_cb_kernel(const RowRec* __restric
   auto ld_val = [&](unsigned off) { return WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f; };
   auto h_off = [&](bool ok, int col) { return ok ? ((unsigned)col * ld32 + (unsigned)c) * 4u : kOob; };
   if (kind == 2) {
-    // A wave walks kCbOct octets of rows (8 rows each: two per lane group), software-pipelined: all the octets' row records
-    // are requested at once, and an octet's first-trip indices while the previous octet's gathers are in flight -- the
-    // dependent chain record -> indices -> gather is paid once per item, then one round trip per octet (the first form of
-    // this kernel paid the whole chain per 32 rows and ran at 3.3 TB/s of a purely streaming 2 GB).
-    RowRec rrA[kCbOct], rrB[kCbOct];
-#pragma unroll
-    for (int j = 0; j < kCbOct; ++j) {
-      const int posA = (j * 4 + wave) * 8 + g;
-      rrA[j] = rowrec[p0 + min(posA, cnt - 1)];
-      rrB[j] = rowrec[p0 + min(posA + 4, cnt - 1)];
-    }
-    int nA0, nA1, nB0, nB1;                      // the NEXT octet's first-trip column indices and weights
-    float mA0, mA1, mB0, mB1;
-    auto first_trip = [&](int j) {
-      const int posA = (j * 4 + wave) * 8 + g, posB = posA + 4;
-      const int aA = rrA[j].a, aB = rrB[j].a;
-      const int dA = posA < cnt ? (int)(rrA[j].w >> 16) : 0, dB = posB < cnt ? (int)(rrB[j].w >> 16) : 0;
-      const unsigned iA0 = 0 < dA ? (unsigned)aA * 4u : kOob, iA1 = 1 < dA ? (unsigned)(aA + 1) * 4u : kOob;
-      const unsigned iB0 = 0 < dB ? (unsigned)aB * 4u : kOob, iB1 = 1 < dB ? (unsigned)(aB + 1) * 4u : kOob;
-      nA0 = ld_col(iA0); nA1 = ld_col(iA1); nB0 = ld_col(iB0); nB1 = ld_col(iB1);
-      mA0 = ld_val(iA0); mA1 = ld_val(iA1); mB0 = ld_val(iB0); mB1 = ld_val(iB1);
-    };
-    first_trip(0);
-#pragma unroll
-    for (int j = 0; j < kCbOct; ++j) {
-      const int posA = (j * 4 + wave) * 8 + g, posB = posA + 4;
-      if (__builtin_amdgcn_ballot_w64(posA < cnt) == 0) break;             // (uniform: the item's last octets may be missing)
-      const int aA = rrA[j].a, aB = rrB[j].a;
-      const int bA = aA + (posA < cnt ? (int)(rrA[j].w >> 16) : 0), bB = aB + (posB < cnt ? (int)(rrB[j].w >> 16) : 0);
-      float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-      int eA = aA, eB = aB;
-      int cA0 = nA0, cA1 = nA1, cB0 = nB0, cB1 = nB1;
-      float wA0 = mA0, wA1 = mA1, wB0 = mB0, wB1 = mB1;
-      bool primed = false;
-      while (__builtin_amdgcn_ballot_w64(eA < bA || eB < bB) != 0) {
-        const float4 hA0 = buf4(hbuf, h_off(eA < bA, cA0)), hA1 = buf4(hbuf, h_off(eA + 1 < bA, cA1));
-        const float4 hB0 = buf4(hbuf, h_off(eB < bB, cB0)), hB1 = buf4(hbuf, h_off(eB + 1 < bB, cB1));
-        const float uA0 = wA0, uA1 = wA1, uB0 = wB0, uB1 = wB1;
-        eA += 2; eB += 2;
-        // indices one trip ahead (range-checked: nothing is fetched for a trip that does not exist) ...
-        cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob); cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
-        cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob); cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
-        wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob); wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
-        wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob); wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
-        // ... and, behind this octet's first gathers, the next octet's first trip
-        if (!primed && j + 1 < kCbOct) { first_trip(j + 1); primed = true; }
-        // (a missing entry loaded zeros and its weight is 0 or 1: fma(w, 0, acc) = acc, acc + 0 = acc -- every row is its CSR-order sum)
-        if (WEIGHTED) {
-          accA = f4_fma(uA0, hA0, accA); accB = f4_fma(uB0, hB0, accB);
-          accA = f4_fma(uA1, hA1, accA); accB = f4_fma(uB1, hB1, accB);
-        } else {
-          accA = f4_add(accA, hA0); accB = f4_add(accB, hB0);
-          accA = f4_add(accA, hA1); accB = f4_add(accB, hB1);
-        }
+    const int posA = wave * 8 + g, posB = posA + 4;
+    const RowRec rrA = rowrec[p0 + min(posA, cnt - 1)], rrB = rowrec[p0 + min(posB, cnt - 1)];
+    const int aA = rrA.a, aB = rrB.a;
+    const int bA = aA + (posA < cnt ? (int)(rrA.w >> 16) : 0), bB = aB + (posB < cnt ? (int)(rrB.w >> 16) : 0);
+    float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+    int eA = aA, eB = aB;
+    // indices one trip ahead
+    int cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob), cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+    int cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob), cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+    float wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob), wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+    float wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob), wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+    while (__builtin_amdgcn_ballot_w64(eA < bA || eB < bB) != 0) {
+      const float4 hA0 = buf4(hbuf, h_off(eA < bA, cA0)), hA1 = buf4(hbuf, h_off(eA + 1 < bA, cA1));
+      const float4 hB0 = buf4(hbuf, h_off(eB < bB, cB0)), hB1 = buf4(hbuf, h_off(eB + 1 < bB, cB1));
+      const float uA0 = wA0, uA1 = wA1, uB0 = wB0, uB1 = wB1;
+      eA += 2; eB += 2;
+      cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob); cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+      cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob); cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+      wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob); wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
+      wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob); wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
+      // (a missing entry loaded zeros and its weight is 0 or 1: fma(w, 0, acc) = acc, acc + 0 = acc -- every row is its CSR-order sum)
+      if (WEIGHTED) {
+        accA = f4_fma(uA0, hA0, accA); accB = f4_fma(uB0, hB0, accB);
+        accA = f4_fma(uA1, hA1, accA); accB = f4_fma(uB1, hB1, accB);
+      } else {
+        accA = f4_add(accA, hA0); accB = f4_add(accB, hB0);
+        accA = f4_add(accA, hA1); accB = f4_add(accB, hB1);
       }
-      if (!primed && j + 1 < kCbOct) first_trip(j + 1);                    // (an octet of empty rows)
-      if (posA < cnt) epilogue(accA, row0 + (int)(rrA[j].w & 0xFFFFu));
-      if (posB < cnt) epilogue(accB, row0 + (int)(rrB[j].w & 0xFFFFu));
     }
+    if (posA < cnt) epilogue(accA, row0 + (int)(rrA.w & 0xFFFFu));
+    if (posB < cnt) epilogue(accB, row0 + (int)(rrB.w & 0xFFFFu));
     return;
   }
   // kinds 1 and 0: a wave walks entries [wa, wb) of one row, its four lane groups taking every fourth entry, 4 per group and trip
@@ -1718,14 +1695,18 @@ static int plan_build_order(gcnx_ctx* ctx, gcnx_spmm_plan* p, const int32_t* row
           dmax = std::max(dmax, d);
         }
         if (dmax > 65535) return gcnx_fail(ctx, GCNX_ERR_DATA, "gcnx_spmm_plan_bind: a row of a tile graph has %d entries", dmax);
+        // (measured for the column-block graphs and dropped: only the rows of more than 8 entries in degree order, the short
+        // rows behind them in ROW order so that records, entries and result rows are walked front to back -- 937 us against
+        // 755 in full degree order: what a wave gains in locality it loses in uneven row lengths)
+        auto key = [&](int d) { return d; };
         count.assign((size_t)dmax + 2, 0);
-        for (int i = w0; i < w0 + wn; ++i) ++count[rp[r0 + i + 1] - rp[r0 + i]];
+        for (int i = w0; i < w0 + wn; ++i) ++count[key(rp[r0 + i + 1] - rp[r0 + i])];
         start.assign((size_t)dmax + 2, 0);           // start[d] = first position of degree d: longer rows first
         int pos = w0;
         for (int d = dmax; d >= 0; --d) { start[d] = pos; pos += count[d]; }
         for (int i = w0; i < w0 + wn; ++i) {
           const int d = rp[r0 + i + 1] - rp[r0 + i];
-          rec[(size_t)r0 + start[d]++] = RowRec{rp[r0 + i], (unsigned)i | ((unsigned)d << 16)};
+          rec[(size_t)r0 + start[key(d)]++] = RowRec{rp[r0 + i], (unsigned)i | ((unsigned)d << 16)};
         }
       }
     }
@@ -1868,7 +1849,7 @@ static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder*
       for (int b = 0; b < nblk; ++b) {
         if (kinds & 1) for (int q = 0; q < n0; ++q) items.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols, r0));
         if (kinds & 2) for (int q = n0; q < n1; q += 4) items.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols, r0));
-        if (kinds & 4) for (int q = n1; q < ng; q += 32 * kCbOct) items.push_back(make_int4(r0 + q, std::min(32 * kCbOct, ng - q) | (2 << 16), b * kCbCols, r0));
+        if (kinds & 4) for (int q = n1; q < ng; q += 32) items.push_back(make_int4(r0 + q, std::min(32, ng - q) | (2 << 16), b * kCbCols, r0));
       }
     }
     int4* dev = nullptr;

@@ -1832,7 +1832,7 @@ def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
     64-column block at a time -- short rows four to a wave, rows of more than 32 entries (hub rows included) by all four
     waves -- next to graphs of ordinary size, which keep the row gather (this batch) or the tile kernels (the next test).
     Against scipy in fp64; at f = 256 the rows of at most 32 entries bit for bit against the row gather + hub segments of
-    round 3 (GCNX_SPMM_CB=0: same CSR-order sums); bit-reproducible; bias + ReLU and plain."""
+    round 3 for the rows of at most 32 entries (GCNX_SPMM_CB=0: same CSR-order sums); bit-reproducible; bias + ReLU and plain."""
     import scipy.sparse as sp
     from gcnx import device as D, synth
     big = synth.power_law_batch(3, 8192, f, seed=3)
@@ -1865,7 +1865,7 @@ def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
     hubs = np.nonzero(deg > 256)[0]
     assert rel_err(outs[1][hubs], ref[hubs]) < TIGHT
     if f == 256:       # (at f = 256 the row gather walks a row with ONE lane group, in CSR order like the column blocks; at 128 with two)
-        short = deg <= 32
+        short = deg <= 32                        # (kCbLong: the rows a lane group walks alone)
         assert np.array_equal(outs[1][short], outs[0][short])
 
 
