@@ -58,9 +58,9 @@ struct gcnx_ctx {
   int knob_spmm_bal = 1;     // GCNX_SPMM_BAL=0: tile graphs in plain size order (the snake deal of r2); c0 + 1000 * big%: cost model of the balanced deal
   int knob_spmm_cap1 = 0;    // GCNX_SPMM_CAP1: tallest graph of the two-workgroups-per-CU tile tier (-1: the kernel's capacity, 632;
                              // 0, the default since r3: every tile graph on the one-workgroup-per-CU tier -- measured faster at every size)
-  int knob_spmm_cb = 0;      // GCNX_SPMM_CB=1: graphs of >= 4096 rows in 64-column blocks (spmm_cb_kernel, r4).  Off by default: it cuts the
-                             // HBM traffic of config 5 from 1.88 x to 1.31 x the compulsory bytes and is still 4 % slower (latency chain of its
-                             // short-row items) -- the row gather + hub segments of r3 stay the product path
+  int knob_spmm_cb = 1;      // graphs of >= 4096 rows in 64-column blocks (spmm_cb_kernel, r4): 1.10 x the compulsory HBM bytes at config 5 against
+                             // 1.88 x for the row gather + hub segments, and 7-10 % faster since its index loads are few and wide.  GCNX_SPMM_CB=0:
+                             // the r3 path; 2: the long rows' items first instead of dealt among the short rows' (no difference measured)
   int knob_pool_split = 0;   // GCNX_POOL_SPLIT=2..16: row slices per graph of the split global pool (0: the library's choice)
   // gcnx_h2d_async: a ring of pinned staging slots (allocated on first use), one event per slot -- a slot is reused only
   // after the copy out of it has completed

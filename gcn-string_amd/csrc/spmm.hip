@@ -112,6 +112,16 @@ __device__ __forceinline__ void store4_bf16(float* out, int64_t elem, const floa
   *reinterpret_cast<b16x4*>(reinterpret_cast<unsigned short*>(out) + elem) = o;
 }
 
+// Result rows of the row gather.  NT (the HUBS instances: power-law batches, whose graphs do not fit an XCD's L2): stored with
+// the non-temporal policy -- the rows are not read again by this launch and should not push the gathered rows out of L2
+// (r4, config 5, same box: 730 -> 709 us; no effect at config 3, and measured SLOWER on the tile kernels' stores: 520 -> 560 us,
+// as was the nt policy on their LDS-DMA reads: no change -- scripts/r04/nt_ab.sh, profiles/r04/cache_policy_ab.txt).
+template <bool NT>
+__device__ __forceinline__ void rows_store4(float* p, const float4& v) {
+  if constexpr (NT) __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v*>(p));
+  else *reinterpret_cast<float4*>(p) = v;
+}
+
 template <int LPR, bool WEIGHTED, int RPC, bool FOLD = false, bool HUBS = false, bool OUT16 = false>
 __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   // 8 waves per SIMD = at most 64 VGPRs (latency regime)
    const int32_t* __restrict__ rowptr,
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256, (LPR == 64 ? 7 : 8)) void spmm_rows_kernel(   
         }
       }
       if constexpr (OUT16) store4_bf16(out, (int64_t)r * ldo + c, acc);
-      else *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
+      else rows_store4<HUBS>(out + (int64_t)r * ldo + c, acc);
     }
   };
   constexpr int kLongRow = RPC <= 8 ? kLongRowSmall : kLongRowLarge;
@@ -1305,18 +1315,65 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
 // ----------------------------------------------------------------------------------------------
 constexpr int kCbCols = 64;          // columns per block
 constexpr int kCbMinRows = 4096;     // graphs of at least this many rows are walked this way (and fewer than 65 536: RowRec)
-constexpr int kCbLong = 32;          // kind 2 up to here
-constexpr int kCbHub = 512;          // kind 1 up to here
+constexpr int kCbShort = 32;         // kind 3 (short rows) up to here
+#ifndef GCNX_CB_HUB
+#define GCNX_CB_HUB 512
+#endif
+constexpr int kCbHub = GCNX_CB_HUB;  // kind 1 up to here
 constexpr int kCbMinF = 128;         // narrower features: the whole graph fits L2 anyway
+
+// Lane N of every 16-lane row, to all lanes of that row (DPP row_newbcast: one VALU move, no LDS).
+template <int N>
+__device__ __forceinline__ int row_bcast16(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false); }
+
+template <bool WEIGHTED, int S, int K>
+__device__ __forceinline__ void cb_slot_row(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, int ci, float wv,
+                                            int deg, float4& acc) {
+  const int col = row_bcast16<K + 4 * (S & 3)>(ci);
+  const unsigned off = (S < deg && !no_gather) ? ((unsigned)col * ld32 + c) * 4u : 0xFFFFFFF0u;
+  const float4 hv = buf4(hbuf, off);
+  if (WEIGHTED) acc = f4_fma(__int_as_float(row_bcast16<K + 4 * (S & 3)>(__float_as_int(wv))), hv, acc);
+  else acc = f4_add(acc, hv);
+}
+
+// Entry slots [J0, J) of four rows (spmm_cb_kernel, kind 3): slot s of row k is held by lane k + 4 (s & 3) of the lane group, in
+// register set s >> 2.
+template <bool WEIGHTED, int J, int J0, int T>
+__device__ __forceinline__ void cb_slots(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, const int (&ci)[T],
+                                         const float (&wv)[T], const int (&deg)[4], float4 (&acc)[4]) {
+  if constexpr (J0 < J) {
+    cb_slot_row<WEIGHTED, J0, 0>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[0], acc[0]);
+    cb_slot_row<WEIGHTED, J0, 1>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[1], acc[1]);
+    cb_slot_row<WEIGHTED, J0, 2>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[2], acc[2]);
+    cb_slot_row<WEIGHTED, J0, 3>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[3], acc[3]);
+    if constexpr ((J0 & 1) == 1 && J0 + 1 < J) __builtin_amdgcn_sched_barrier(0);   // (eight gathers in flight: more hoisted together spill)
+    cb_slots<WEIGHTED, J, J0 + 1, T>(hbuf, ld32, c, no_gather, ci, wv, deg, acc);
+  }
+}
+
+// The same for ONE row walked by a whole wave (kinds 0 and 1): slot j of lane group g is entry 4 j + g of the current 64-entry step.
+template <bool WEIGHTED, int J, int J0>
+__device__ __forceinline__ void cb_slots1(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, int ci, float wv,
+                                          int left, float4& acc) {
+  if constexpr (J0 < J) {
+    const int col = row_bcast16<J0>(ci);
+    const unsigned off = (J0 < left && !no_gather) ? ((unsigned)col * ld32 + c) * 4u : 0xFFFFFFF0u;
+    const float4 hv = buf4(hbuf, off);
+    if (WEIGHTED) acc = f4_fma(__int_as_float(row_bcast16<J0>(__float_as_int(wv))), hv, acc);
+    else acc = f4_add(acc, hv);
+    cb_slots1<WEIGHTED, J, J0 + 1>(hbuf, ld32, c, no_gather, ci, wv, left, acc);
+  }
+}
 
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256, 8) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
                                                          const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh,
                                                          const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-                                                         int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items) {
+                                                         int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items, int dbg) {
   __shared__ float4 s_long[4][16];
   const int4 it = items[gcnx_xcd_remap(blockIdx.x, nitems)];
   const int p0 = it.x, cnt = it.y & 0xFFFF, kind = it.y >> 16, col0 = it.z, row0 = it.w;
+  if (dbg & 16) { if (dbg == 0x7fffffff) out[0] = (float)p0; return; }      // (tuning: launch + item load only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, sub = lane & 15;
   const int c = col0 + sub * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1331,43 +1388,68 @@ __global__ __launch_bounds__(256, 8) void spmm_cb_kernel(const RowRec* __restric
   auto epilogue = [&](float4 acc, int r) {
     acc = f4_add(acc, bv);
     if (act == GCNX_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
+    if (dbg & 1) return;
+    // non-temporal: a result row is not read again by this launch and should not push the block's source rows out of L2
+    if (!(dbg & 8)) __builtin_nontemporal_store(f32x4v{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4v*>(out + (int64_t)r * ldo + c));
+    else *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = acc;
   };
   auto ld_col = [&](unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(cbuf, off, 0, 0); };
   auto ld_val = [&](unsigned off) { return WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f; };
-  auto h_off = [&](bool ok, int col) { return ok ? ((unsigned)col * ld32 + (unsigned)c) * 4u : kOob; };
-  if (kind == 2) {
-    const int posA = wave * 8 + g, posB = posA + 4;
-    const RowRec rrA = rowrec[p0 + min(posA, cnt - 1)], rrB = rowrec[p0 + min(posB, cnt - 1)];
-    const int aA = rrA.a, aB = rrB.a;
-    const int bA = aA + (posA < cnt ? (int)(rrA.w >> 16) : 0), bB = aB + (posB < cnt ? (int)(rrB.w >> 16) : 0);
-    float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-    int eA = aA, eB = aB;
-    // indices one trip ahead
-    int cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob), cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
-    int cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob), cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
-    float wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob), wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
-    float wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob), wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
-    while (__builtin_amdgcn_ballot_w64(eA < bA || eB < bB) != 0) {
-      const float4 hA0 = buf4(hbuf, h_off(eA < bA, cA0)), hA1 = buf4(hbuf, h_off(eA + 1 < bA, cA1));
-      const float4 hB0 = buf4(hbuf, h_off(eB < bB, cB0)), hB1 = buf4(hbuf, h_off(eB + 1 < bB, cB1));
-      const float uA0 = wA0, uA1 = wA1, uB0 = wB0, uB1 = wB1;
-      eA += 2; eB += 2;
-      cA0 = ld_col(eA < bA ? (unsigned)eA * 4u : kOob); cA1 = ld_col(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
-      cB0 = ld_col(eB < bB ? (unsigned)eB * 4u : kOob); cB1 = ld_col(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
-      wA0 = ld_val(eA < bA ? (unsigned)eA * 4u : kOob); wA1 = ld_val(eA + 1 < bA ? (unsigned)(eA + 1) * 4u : kOob);
-      wB0 = ld_val(eB < bB ? (unsigned)eB * 4u : kOob); wB1 = ld_val(eB + 1 < bB ? (unsigned)(eB + 1) * 4u : kOob);
-      // (a missing entry loaded zeros and its weight is 0 or 1: fma(w, 0, acc) = acc, acc + 0 = acc -- every row is its CSR-order sum)
-      if (WEIGHTED) {
-        accA = f4_fma(uA0, hA0, accA); accB = f4_fma(uB0, hB0, accB);
-        accA = f4_fma(uA1, hA1, accA); accB = f4_fma(uB1, hB1, accB);
-      } else {
-        accA = f4_add(accA, hA0); accB = f4_add(accB, hB0);
-        accA = f4_add(accA, hA1); accB = f4_add(accB, hB1);
+  auto h_off = [&](bool ok, int col) { return (ok && !(dbg & 4)) ? ((unsigned)col * ld32 + (unsigned)c) * 4u : kOob; };
+  if (kind == 3) {
+    // 64 rows of at most kCbShort entries, 16 per wave: lane group g owns positions wave * 16 + g + 4 k (k = 0 .. 3).  A row's
+    // entries arrive with ONE load per array -- lane `sub` of the group takes entry a + sub, 64 contiguous bytes -- and reach the
+    // group's lanes by DPP row broadcasts; the gathers of the J entry slots x 4 rows are straight-line code (a slot past a row's
+    // end is an out-of-range buffer offset: no fetch, an exact zero), so a wave has one dependent round trip per stage -- records,
+    // entries, gathers, stores -- whatever the row lengths.  (The kind-2 form below loads every entry as its own 4-byte
+    // broadcast load, two per row and trip: with the gathers and stores compiled out its index loads alone took 210 of the
+    // launch's 607 us.)  A row's sum is still its CSR-order fma chain.
+    // Few, wide index instructions (the vector-memory pipeline of a CU takes one instruction at a time, and a 4- or 8-byte
+    // broadcast load occupies it like a 1-KiB gather does): lane j of a group stands for (row k = j & 3, entry slot j >> 2) --
+    // ONE record load per wave, and one load per array fetches slots [4 t, 4 t + 4) of all four rows of every group; rows of at
+    // most 4 entries (79 % of a power-law graph's rows) need t = 0 only.  Slot s of row k then lives in lane k + 4 (s & 3) of
+    // register set s >> 2.
+    const int kq = sub & 3, sq = sub >> 2;
+    const int posq = wave * 16 + g + 4 * kq;
+    const RowRec rq = rowrec[p0 + min(posq, cnt - 1)];
+    const int aq = rq.a, dq = posq < cnt ? (int)(rq.w >> 16) : 0, rlq = posq < cnt ? (int)(rq.w & 0xFFFFu) : -1;
+    if (dbg & 32) { if (aq == 0x7fffffff) out[0] = 1.f; return; }
+    int deg[4];
+    deg[0] = row_bcast16<0>(dq); deg[1] = row_bcast16<1>(dq); deg[2] = row_bcast16<2>(dq); deg[3] = row_bcast16<3>(dq);
+    const int maxd = __builtin_amdgcn_readfirstlane(dq);          // degree order: the wave's first position holds its longest row
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // entry slots [base, base + J) of the group's four rows: J <= 8, two register sets of four slots each
+    auto slots = [&](auto jt, int base) {
+      constexpr int J = decltype(jt)::value;
+      constexpr int T = (J + 3) / 4;
+      int ci[T];
+      float wv[T];
+      int dg[4];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const unsigned off = (base + 4 * t + sq < dq && !(dbg & 64)) ? (unsigned)(aq + base + 4 * t + sq) * 4u : kOob;
+        ci[t] = ld_col(off); wv[t] = ld_val(off);
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dg[k] = deg[k] - base;
+      cb_slots<WEIGHTED, J, 0, T>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci, wv, dg, acc);
+    };
+    if (maxd <= 1) slots(std::integral_constant<int, 1>{}, 0);
+    else if (maxd <= 2) slots(std::integral_constant<int, 2>{}, 0);
+    else if (maxd <= 3) slots(std::integral_constant<int, 3>{}, 0);
+    else if (maxd <= 4) slots(std::integral_constant<int, 4>{}, 0);
+    else if (maxd <= 6) slots(std::integral_constant<int, 6>{}, 0);
+    else if (maxd <= 8) slots(std::integral_constant<int, 8>{}, 0);
+    else for (int base = 0; base < maxd; base += 8) {           // (6.6 % of the rows; uniform trip count)
+      slots(std::integral_constant<int, 8>{}, base);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (posA < cnt) epilogue(accA, row0 + (int)(rrA.w & 0xFFFFu));
-    if (posB < cnt) epilogue(accB, row0 + (int)(rrB.w & 0xFFFFu));
+    { const int r = row_bcast16<0>(rlq); if (r >= 0) epilogue(acc[0], row0 + r); }
+    { const int r = row_bcast16<1>(rlq); if (r >= 0) epilogue(acc[1], row0 + r); }
+    { const int r = row_bcast16<2>(rlq); if (r >= 0) epilogue(acc[2], row0 + r); }
+    { const int r = row_bcast16<3>(rlq); if (r >= 0) epilogue(acc[3], row0 + r); }
     return;
   }
   // kinds 1 and 0: a wave walks entries [wa, wb) of one row, its four lane groups taking every fourth entry, 4 per group and trip
@@ -1375,29 +1457,31 @@ __global__ __launch_bounds__(256, 8) void spmm_cb_kernel(const RowRec* __restric
   const int deg = (int)(rr.w >> 16);
   int wa = rr.a, wb = rr.a + (kind == 1 && wave >= cnt ? 0 : deg);
   if (kind == 0) { const int per = (deg + 3) / 4; wa = rr.a + wave * per; wb = min(rr.a + deg, wa + per); }
-  constexpr int HU = 4;
+  // 64 entries per step: lane 16 g + j takes entry 4 j + g of the step -- ONE 256-byte load per array and step, where the first
+  // version issued a 4-byte broadcast load per entry and lane group (its index loads were 112 of the long rows' 202 us) -- and
+  // slot j of a lane group is a DPP row broadcast of lane j.  Group g still adds the entries = g (mod 4) in CSR order: the
+  // same association as before, bit for bit.  The next step's entries load under this step's gathers.
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int ci[HU];
-  float wv[HU];
-  int e = wa + g;
-#pragma unroll
-  for (int u = 0; u < HU; ++u) {
-    const unsigned off = e + 4 * u < wb ? (unsigned)(e + 4 * u) * 4u : kOob;
-    ci[u] = ld_col(off); wv[u] = ld_val(off);
-  }
-  while (__builtin_amdgcn_ballot_w64(e < wb) != 0) {
-    float4 hv[HU];
-    float uv[HU];
-#pragma unroll
-    for (int u = 0; u < HU; ++u) { hv[u] = buf4(hbuf, h_off(e + 4 * u < wb, ci[u])); uv[u] = wv[u]; }
-    e += 4 * HU;
-#pragma unroll
-    for (int u = 0; u < HU; ++u) {
-      const unsigned off = e + 4 * u < wb ? (unsigned)(e + 4 * u) * 4u : kOob;
-      ci[u] = ld_col(off); wv[u] = ld_val(off);
+  auto ent_off = [&](int e0) { const int my = e0 + 4 * sub + g; return my < wb ? (unsigned)my * 4u : kOob; };
+  int cn = ld_col(ent_off(wa));
+  float wn = ld_val(ent_off(wa));
+  for (int e0 = wa; e0 < wb; e0 += 64) {                 // (uniform per wave)
+    const int ci1 = cn;
+    const float wv1 = wn;
+    cn = ld_col(ent_off(e0 + 64)); wn = ld_val(ent_off(e0 + 64));
+    const int left = (wb - e0 - g + 3) >> 2;            // this group's entries from here on: slot j exists while j < left
+    // (four slots at a time, more only where the step has them: all 16 gathers hoisted together spilled 8 registers)
+    cb_slots1<WEIGHTED, 4, 0>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+    if (wb - e0 > 16) {
+      __builtin_amdgcn_sched_barrier(0);
+      cb_slots1<WEIGHTED, 8, 4>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+      if (wb - e0 > 32) {
+        __builtin_amdgcn_sched_barrier(0);
+        cb_slots1<WEIGHTED, 12, 8>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        cb_slots1<WEIGHTED, 16, 12>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < HU; ++u) acc = WEIGHTED ? f4_fma(uv[u], hv[u], acc) : f4_add(acc, hv[u]);
   }
 #pragma unroll
   for (int off = 16; off < 64; off <<= 1) {          // the wave's four groups, fixed order
@@ -1841,15 +1925,31 @@ static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder*
       int n0 = 0, n1 = 0;                                      // rows of kind 0, of kind 0 or 1
       while (n0 < ng && deg[n0] > kCbHub) ++n0;
       n1 = n0;
-      while (n1 < ng && deg[n1] > kCbLong) ++n1;
-      int kinds = 7;
-#ifdef GCNX_TUNING   // timing only: GCNX_SPMM_CB = 8 + mask launches only the kinds in mask (results are then incomplete)
-      if (ctx->knob_spmm_cb >= 8) kinds = ctx->knob_spmm_cb & 7;
+      while (n1 < ng && deg[n1] > kCbShort) ++n1;
+      int kinds = 15;
+#ifdef GCNX_TUNING   // timing only: GCNX_SPMM_CB = 16 + mask launches only the kinds in mask (results are then incomplete)
+      if (ctx->knob_spmm_cb >= 16) kinds = ctx->knob_spmm_cb & 15;
 #endif
+      std::vector<int4> heavy, light;
       for (int b = 0; b < nblk; ++b) {
-        if (kinds & 1) for (int q = 0; q < n0; ++q) items.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols, r0));
-        if (kinds & 2) for (int q = n0; q < n1; q += 4) items.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols, r0));
-        if (kinds & 4) for (int q = n1; q < ng; q += 32) items.push_back(make_int4(r0 + q, std::min(32, ng - q) | (2 << 16), b * kCbCols, r0));
+        heavy.clear(); light.clear();
+        if (kinds & 1) for (int q = 0; q < n0; ++q) heavy.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols, r0));
+        if (kinds & 2) for (int q = n0; q < n1; q += 4) heavy.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols, r0));
+        if (kinds & 8) for (int q = n1; q < ng; q += 64) light.push_back(make_int4(r0 + q, std::min(64, ng - q) | (3 << 16), b * kCbCols, r0));
+        // The long rows' items gather out of L2 (the block's source rows are re-read ~degree times), the short rows' items stream
+        // from HBM: dealt evenly among each other (heaviest first on either side) the two kinds of traffic run side by side.
+        if (ctx->knob_spmm_cb == 2 || heavy.empty() || light.empty()) {      // (2: heaviest first, as the first version had it)
+          items.insert(items.end(), heavy.begin(), heavy.end());
+          items.insert(items.end(), light.begin(), light.end());
+        } else {
+          size_t hi = 0, li = 0;
+          const size_t nh = heavy.size(), nl = light.size();
+          while (hi < nh || li < nl) {
+            // next heavy item when its share of the list is behind the light items' share
+            if (hi < nh && (li >= nl || hi * nl <= li * nh)) items.push_back(heavy[hi++]);
+            else items.push_back(light[li++]);
+          }
+        }
       }
     }
     int4* dev = nullptr;
@@ -1880,8 +1980,12 @@ static int launch_cb(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const RowOrder* 
   const int rc = plan_cb_items(ctx, plan, order, f / kCbCols, &items, &nitems);
   if (rc) return rc;
   if (nitems == 0) return GCNX_OK;
-  if (vals) hipLaunchKernelGGL((spmm_cb_kernel<true>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items);
-  else hipLaunchKernelGGL((spmm_cb_kernel<false>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items);
+  int dbg = 0;
+#ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set): 1 no stores, 4 no gathers, 8 nt stores
+  if (const char* e = getenv("GCNX_CB_DBG")) dbg = atoi(e);
+#endif
+  if (vals) hipLaunchKernelGGL((spmm_cb_kernel<true>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
+  else hipLaunchKernelGGL((spmm_cb_kernel<false>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

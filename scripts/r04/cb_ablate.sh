@@ -1,0 +1,10 @@
+#!/bin/bash
+# Ablation of the column-block kernel's short-row items (tuning build; results are wrong by design when a bit is set)
+cd "$GRAFT_REPO_ROOT"
+export GCNX_LIB=$PWD/scripts/variants/libgcnx_tuning.so
+for cb in ${CBS:-12}; do
+for d in ${DBGS:-0 1 4 5 8}; do
+  echo "== cb=$cb dbg=$d"
+  GCNX_CB_DBG=$d timeout -k 10 200 python scripts/spmm_bench.py --workload powerlaw --iters 20 --rounds 1 --slabs 0 --cb $cb 2>&1 | tail -1
+done
+done

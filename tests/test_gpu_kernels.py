@@ -1829,8 +1829,8 @@ def test_spmm_double_buffered_tiles_with_rows_past_the_register_held_entries(ctx
 @pytest.mark.parametrize("f", [128, 256])
 def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
     """BASELINE config 5 in small (r4): power-law graphs of 8 192 nodes (degrees up to 4096) are walked by spmm_cb_kernel one
-    64-column block at a time -- short rows four to a wave, rows of more than 32 entries (hub rows included) by all four
-    waves -- next to graphs of ordinary size, which keep the row gather (this batch) or the tile kernels (the next test).
+    64-column block at a time -- rows of at most 32 entries sixteen to a wave (four per lane group), longer rows a wave each,
+    hub rows by all four waves -- next to graphs of ordinary size, which keep the row gather (this batch) or the tile kernels (the next test).
     Against scipy in fp64; at f = 256 the rows of at most 32 entries bit for bit against the row gather + hub segments of
     round 3 for the rows of at most 32 entries (GCNX_SPMM_CB=0: same CSR-order sums); bit-reproducible; bias + ReLU and plain."""
     import scipy.sparse as sp
@@ -1859,13 +1859,13 @@ def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
         o3 = ctx.zeros((hb.n, f)); D.spmm(ctx, csr, dh, None, o3)
         assert rel_err(o3.numpy(), a64 @ h.astype(np.float64)) < TIGHT              # no bias, no activation
     finally:
-        ctx.set_tuning("spmm_cb", 0)
+        ctx.set_tuning("spmm_cb", 1)
     ref = np.maximum(a64 @ h.astype(np.float64) + bias, 0)
     assert rel_err(outs[1], ref) < TIGHT and rel_err(outs[0], ref) < TIGHT
     hubs = np.nonzero(deg > 256)[0]
     assert rel_err(outs[1][hubs], ref[hubs]) < TIGHT
     if f == 256:       # (at f = 256 the row gather walks a row with ONE lane group, in CSR order like the column blocks; at 128 with two)
-        short = deg <= 32                        # (kCbLong: the rows a lane group walks alone)
+        short = deg <= 32                        # (kCbShort: the rows a lane group walks alone)
         assert np.array_equal(outs[1][short], outs[0][short])
 
 
@@ -1885,7 +1885,7 @@ def test_spmm_column_blocks_next_to_the_tile_kernels(ctx):
     h = rng.standard_normal((hb.n, f), dtype=np.float32); bias = rng.standard_normal(f).astype(np.float32)
     dh, db = ctx.to_device(h), ctx.to_device(bias)
     o = ctx.zeros((hb.n, f))
-    ctx.set_tuning("spmm_cb", 1)                       # (opt-in: GCNX_SPMM_CB=1)
+    ctx.set_tuning("spmm_cb", 1)                       # (the default since the index loads of the kernel became few and wide)
     try:
         D.spmm(ctx, csr, dh, db, o, act="relu")
         ref = np.maximum(a64 @ h.astype(np.float64) + bias, 0)
@@ -1896,4 +1896,4 @@ def test_spmm_column_blocks_next_to_the_tile_kernels(ctx):
         assert rel_err(o.numpy(), ref) < TIGHT
         g.destroy()
     finally:
-        ctx.set_tuning("spmm_cb", 0)
+        ctx.set_tuning("spmm_cb", 1)
