@@ -527,8 +527,15 @@ int gcnx_pool_graph_list(gcnx_ctx* ctx, const int32_t* graph_ptr, const int32_t*
                          int32_t f, int mode, float* pooled, int64_t ldp, float* cnt) {
   if (nlist <= 0) return GCNX_OK;
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0;
-  hipLaunchKernelGGL(pool_fwd_kernel<16>, dim3(gcnx_cdiv(f, 64), nlist), dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode,
-                     (int32_t*)nullptr, vec, 1, cnt, glist, ldp);
+  // 1024-thread workgroups (SUM / AVG only; the callers' case): the listed graphs are the tall ones -- 1 300 to 3 000 rows each, a
+  // few per shard of an 8-rank run -- and a thread of the 256-thread shape walks 80-190 rows four at a time: a chain of
+  // dependent round trips (17 us for nine graphs; r4 shard trace), a quarter of it with 64 row groups
+  if (mode != GCNX_POOL_MAX)
+    hipLaunchKernelGGL(pool_fwd_kernel<64>, dim3(gcnx_cdiv(f, 64), nlist), dim3(1024), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode,
+                       (int32_t*)nullptr, vec, 1, cnt, glist, ldp);
+  else
+    hipLaunchKernelGGL(pool_fwd_kernel<16>, dim3(gcnx_cdiv(f, 64), nlist), dim3(256), 0, ctx->stream, graph_ptr, x, ldx, pooled, f, mode,
+                       (int32_t*)nullptr, vec, 1, cnt, glist, ldp);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
