@@ -2339,7 +2339,7 @@ static int spmm_csr_impl(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* co
   }
   // The pipelined kernel: any graph size, one 1024-thread workgroup per CU with two source buffers.  Opt-in
   // (GCNX_SPMM_KERNEL=pipe / gcnx_set_tuning): correct on every case the tier kernels are tested on, but at config 3 it
-  // measures 690-750 us against 646 for the tiers, so the tier kernels stay the default.
+  // measures 690-750 us against 646 for the tiers (LOG.md 4.1), so the tier kernels stay the default.
   auto launch_pipe = [&](const PipeItem* list, int count, int ft) -> int {
     static bool attr_set = false;
     if (!attr_set) {
