@@ -53,6 +53,8 @@ struct gcnx_ctx {
   hipEvent_t aux_ev[kAuxEvents][3] = {};
   int aux_next = 0;
   int knob_spmm_conc = 0;    // GCNX_SPMM_CONC=1: the plan path's three launches as concurrent branches
+  int knob_spmm_tile_wgs = 0; // GCNX_SPMM_TILE_WGS=n: the 1024-thread tile launch on n workgroups (= n CUs) instead of one per CU (0), so that a
+                             // concurrent branch (GCNX_SPMM_CONC=1: the tall graphs' row chunks) finds CUs to run on
   int knob_spmm_tall_rpc = 8; // GCNX_SPMM_TALL_RPC=32: 32-row chunks for graphs taller than a tile (r2 behaviour; default 8)
   int knob_spmm_sort_win = 0; // GCNX_SPMM_SORT_WIN: degree order inside windows of this many row groups (0: whole graph)
   int knob_spmm_bal = 1;     // GCNX_SPMM_BAL=0: tile graphs in plain size order (the snake deal of r2); c0 + 1000 * big%: cost model of the balanced deal

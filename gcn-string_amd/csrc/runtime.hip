@@ -94,6 +94,7 @@ int gcnx_ctx_create(int device, gcnx_ctx** out) {
   if (const char* k = getenv("GCNX_SPMM_SG")) ctx->knob_spmm_sg = atoi(k);
   if (const char* k = getenv("GCNX_GEMM_STREAM")) ctx->knob_gemm_stream = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_CONC")) ctx->knob_spmm_conc = atoi(k);
+  if (const char* k = getenv("GCNX_SPMM_TILE_WGS")) ctx->knob_spmm_tile_wgs = atoi(k);
   if (const char* k = getenv("GCNX_POOL_SPLIT")) ctx->knob_pool_split = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_TALL_RPC")) ctx->knob_spmm_tall_rpc = atoi(k);
   if (const char* k = getenv("GCNX_SPMM_SORT_WIN")) ctx->knob_spmm_sort_win = atoi(k);
@@ -163,6 +164,7 @@ int gcnx_set_tuning(gcnx_ctx* ctx, const char* key, int value) {
   else if (k == "spmm_sg") ctx->knob_spmm_sg = value;
   else if (k == "gemm_stream") ctx->knob_gemm_stream = value;
   else if (k == "spmm_conc") ctx->knob_spmm_conc = value;
+  else if (k == "spmm_tile_wgs") ctx->knob_spmm_tile_wgs = value;
   else if (k == "pool_split") ctx->knob_pool_split = value;
   else if (k == "spmm_tall_rpc") ctx->knob_spmm_tall_rpc = value;
   else if (k == "spmm_sort_win") ctx->knob_spmm_sort_win = value;

@@ -1605,7 +1605,8 @@ int launch_duo(gcnx_ctx* ctx, const int32_t* rowptr, const RowRec* rowrec, const
 #ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set, bit 16 excepted): only in a tuning build (make TUNING=1)
   if (const char* e = getenv("GCNX_SPMM_DBG")) dbg = atoi(e);
 #endif
-  const int full = (THREADS == 512 ? 2 : 1) * ctx->num_cus;   // resident workgroups
+  int full = (THREADS == 512 ? 2 : 1) * ctx->num_cus;   // resident workgroups
+  if (THREADS == 1024 && ctx->knob_spmm_tile_wgs > 0 && ctx->knob_spmm_tile_wgs < full) full = ctx->knob_spmm_tile_wgs;
   // column slabs per unit share one index burst; keep >= 3 units per workgroup so the static deal stays balanced
   // (config 3, measured per shape: 4 slabs per unit = 3.9 units per workgroup beats 2 slabs by 5 % and, on the
   // 1024-thread shape, 8 slabs = 1.9 units by 10 %)
@@ -2109,7 +2110,8 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     if (ctx->knob_spmm_bal > 0 && 2 * (long long)t2.size() >= 3LL * ctx->num_cus) {
       const int c0 = ctx->knob_spmm_bal == 1 ? 60 : ctx->knob_spmm_bal % 1000;
       const int big = ctx->knob_spmm_bal == 1 ? 110 : 100 + ctx->knob_spmm_bal / 1000;
-      balance_tile_list(t2, ctx->num_cus, c0, big, 624);
+      const int wgs = ctx->knob_spmm_tile_wgs > 0 && ctx->knob_spmm_tile_wgs < ctx->num_cus ? ctx->knob_spmm_tile_wgs : ctx->num_cus;
+      balance_tile_list(t2, wgs, c0, big, 624);
     }
     std::vector<int32_t> gids;                     // by_row is sorted by row0 (graphs come in row order): look the records up
     gids.reserve(t1.size() + t2.size());

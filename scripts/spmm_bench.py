@@ -20,6 +20,7 @@ ap.add_argument("--pads", default="", help="comma list of MiB: re-time with h an
 ap.add_argument("--hog", type=int, default=0, help="GiB allocated (and kept) before anything else: does where the arrays land matter?")
 ap.add_argument("--hog-after-csr", type=int, default=0)
 ap.add_argument("--cb", type=int, default=-1, help="spmm_cb knob for the whole process (tuning build: 8 + mask = only those kinds of column-block items)")
+ap.add_argument("--tile-wgs", type=int, default=0, help="workgroups of the 1024-thread tile launch (spmm_tile_wgs; 0: one per CU)")
 ap.add_argument("--conc", type=int, default=-1, help="1 / 0: the plan path's launches as concurrent branches or not (spmm_conc)")
 args = ap.parse_args()
 if args.workload == "block1m":       # the batches bench.py times (per-graph-seeded generators)
@@ -39,6 +40,7 @@ vals = None if args.unweighted else synth.gcn_norm_host(hb.rowptr, hb.colidx)
 ctx = gcnx.Context(0)
 _hog = [ctx.empty((1 << 28,)) for _ in range(args.hog)]
 if args.conc >= 0: ctx.set_tuning("spmm_conc", args.conc)
+if args.tile_wgs > 0: ctx.set_tuning("spmm_tile_wgs", args.tile_wgs)
 a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
 _hog2 = [ctx.empty((1 << 28,)) for _ in range(args.hog_after_csr)]
 h = ctx.to_device(np.random.default_rng(0).standard_normal((hb.n, f), dtype=np.float32))
