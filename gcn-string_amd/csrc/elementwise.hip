@@ -101,6 +101,54 @@ __global__ __launch_bounds__(256) void spmm_minmax_bwd_kernel(const int32_t* __r
   }
 }
 
+// GeneralConv(aggregate = "prod") (tf.math.unsorted_segment_prod over a row's messages): one wave per output row, lanes over the
+// columns, entries in CSR order; a row without entries gets 1 (TensorFlow's value for an empty segment).  aux (needed for the
+// gradient): the product of the row's NON-ZERO messages where exactly one message is zero (then out = 0 and that message's
+// derivative is this product), out itself where none is, 0 where two or more are (every derivative vanishes).
+__global__ __launch_bounds__(256) void spmm_prod_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                        const float* __restrict__ h, int64_t ldh, float* __restrict__ out, int64_t ldo,
+                                                        float* __restrict__ aux, int64_t lda, int32_t n, int32_t f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  for (int c = lane; c < f; c += 64) {
+    float p = 1.f, pnz = 1.f;
+    int nz = 0;
+    for (int e = e0; e < e1; ++e) {
+      const float v = h[(int64_t)colidx[e] * ldh + c];
+      p *= v;
+      if (v == 0.f) ++nz; else pnz *= v;
+    }
+    out[row * ldo + c] = p;
+    if (aux) aux[row * lda + c] = nz >= 2 ? 0.f : pnz;
+  }
+}
+
+// Its gradient (TensorFlow's _UnsortedSegmentProdGrad): d out[t] / d h[s] = out[t] / h[s] for a non-zero message (0 when another
+// message of the row is zero: out[t] is), the product of the other messages for THE zero message of a row (aux), 0 where a row holds
+// two or more zeros.  Walked from the source side over the transposed operator, CSR order: deterministic.
+__global__ __launch_bounds__(256) void spmm_prod_bwd_kernel(const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ colidx_t,
+                                                            const float* __restrict__ h, int64_t ldh, const float* __restrict__ out,
+                                                            int64_t ldo, const float* __restrict__ aux, int64_t lda,
+                                                            const float* __restrict__ dy, int64_t lddy, float* __restrict__ dh,
+                                                            int64_t lddh, int32_t n, int32_t f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr_t[row], e1 = rowptr_t[row + 1];
+  for (int c = lane; c < f; c += 64) {
+    const float hv = h[row * ldh + c];
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int64_t t = colidx_t[e];
+      const float part = hv == 0.f ? aux[t * lda + c] : out[t * ldo + c] / hv;
+      acc += dy[t * lddy + c] * part;
+    }
+    dh[row * lddh + c] = acc;
+  }
+}
+
 int grid_for(gcnx_ctx* ctx, int64_t total) {
   int64_t g = (total + 255) / 256;
   const int64_t cap = 16LL * ctx->num_cus;
@@ -178,6 +226,36 @@ int gcnx_spmm_csr_minmax_bwd(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32
   GCNX_REQUIRE(ctx, dh != dy && dh != h, "gcnx_spmm_csr_minmax_bwd: in-place is not supported");
   hipLaunchKernelGGL(spmm_minmax_bwd_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, rowptr_t, colidx_t, h, ldh, out, ldo, cnt,
                      ldc, dy, lddy, dh, lddh, n, f);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_spmm_csr_prod(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* h, int64_t ldh, float* out,
+                       int64_t ldo, float* aux, int64_t lda, int32_t n, int32_t f) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation (prod)");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr_prod: negative size");
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, rowptr && colidx && h && out, "gcnx_spmm_csr_prod: NULL pointer");
+  GCNX_REQUIRE(ctx, ldh >= f && ldo >= f && (!aux || lda >= f), "gcnx_spmm_csr_prod: leading dimension too small");
+  GCNX_REQUIRE(ctx, h != out, "gcnx_spmm_csr_prod: in-place aggregation is not supported");
+  hipLaunchKernelGGL(spmm_prod_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, rowptr, colidx, h, ldh, out, ldo, aux, lda, n, f);
+  GCNX_LAUNCH_OK(ctx);
+  return GCNX_OK;
+}
+
+int gcnx_spmm_csr_prod_bwd(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* h, int64_t ldh,
+                           const float* out, int64_t ldo, const float* aux, int64_t lda, const float* dy, int64_t lddy, float* dh,
+                           int64_t lddh, int32_t n, int32_t f) {
+  GCNX_CHECK_CTX(ctx);
+  GCNX_RANGE(ctx, "aggregation backward (prod)");
+  GCNX_REQUIRE(ctx, n >= 0 && f >= 0, "gcnx_spmm_csr_prod_bwd: negative size");
+  if (n == 0 || f == 0) return GCNX_OK;
+  GCNX_REQUIRE(ctx, rowptr_t && colidx_t && h && out && aux && dy && dh, "gcnx_spmm_csr_prod_bwd: NULL pointer");
+  GCNX_REQUIRE(ctx, ldh >= f && ldo >= f && lda >= f && lddy >= f && lddh >= f, "gcnx_spmm_csr_prod_bwd: leading dimension too small");
+  GCNX_REQUIRE(ctx, dh != dy && dh != h, "gcnx_spmm_csr_prod_bwd: in-place is not supported");
+  hipLaunchKernelGGL(spmm_prod_bwd_kernel, dim3(gcnx_cdiv(n, 4)), dim3(256), 0, ctx->stream, rowptr_t, colidx_t, h, ldh, out, ldo, aux,
+                     lda, dy, lddy, dh, lddh, n, f);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -46,7 +46,7 @@ int gcnx_ws_reserve(gcnx_ctx* ctx, size_t bytes) {
 
 extern "C" {
 
-int gcnx_version(void) { return 311; }   // round 3: + plan_bind, wimage *, bf16 storage, stream images, relu_bits_pool, pooled head; 310: dropout, counter_add, add; 311: spmm_csr_minmax(_bwd)
+int gcnx_version(void) { return 400; }   // round 3: + plan_bind, wimage *, bf16 storage, stream images, relu_bits_pool, pooled head; 310: dropout, counter_add, add; 311: spmm_csr_minmax(_bwd); 400 (r4): spmm_csr_prod(_bwd)
 
 int gcnx_device_count(int* n) {
   if (!n) return gcnx_fail(nullptr, GCNX_ERR_INVALID, "gcnx_device_count: n is NULL");

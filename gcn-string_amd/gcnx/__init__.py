@@ -10,14 +10,14 @@ from .io import best_epoch, load_weights_npz, save_to_npz
 from .loader import Dataset, DisjointLoader, Graph, ListDataset, NetworkxDataset, SparseTensor, format_graph, from_networkx
 from .train import PiecewiseConstantDecay, auc, fit, roc_curve
 
-__all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "NetworkxDataset", "from_networkx", "format_graph", "SparseTensor", "Context", "GCNConv", "GeneralConv",
+__all__ = ["Dataset", "DisjointLoader", "Graph", "ListDataset", "NetworkxDataset", "from_networkx", "format_graph", "SparseTensor", "Context", "default_context", "GCNConv", "GeneralConv",
            "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense", "GCN2", "GeneralGNN", "DeviceBatch",
            "save_to_npz", "load_weights_npz", "best_epoch", "DeviceDataset", "DeviceDisjointLoader",
            "PiecewiseConstantDecay", "fit", "roc_curve", "auc"]
 
 
 def __getattr__(name):  # device-side names load libgcnx lazily, host-only use needs no .so
-    if name in ("Context", "DeviceArray", "DeviceCSR", "Segments"):
+    if name in ("Context", "default_context", "DeviceArray", "DeviceCSR", "Segments"):
         from . import device
         return getattr(device, name)
     if name in ("GCNConv", "GeneralConv", "GlobalSumPool", "GlobalAvgPool", "GlobalMaxPool", "Dense"):

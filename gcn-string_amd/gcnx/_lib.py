@@ -113,6 +113,8 @@ SIGNATURES = {
     "gcnx_add": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32],
     "gcnx_spmm_csr_minmax": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int],
     "gcnx_spmm_csr_minmax_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32],
+    "gcnx_spmm_csr_prod": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32],
+    "gcnx_spmm_csr_prod_bwd": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32],
     "gcnx_gemm_dw_sgd": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _vp, _i64, _f32, _vp],
     "gcnx_dense_bwd_scratch_floats": [_vp, _i64, _i32, _i32],
     "gcnx_dense_bwd_deferred": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _int, _vp, _i64, _vp, _i64, _vp, _vp, _vp,

@@ -22,6 +22,30 @@ class _Side:
         return False
 
 
+_DEFAULT_CTX = None
+
+
+def default_context():
+    """The process-wide Context the models use when none is passed (``GeneralGNN(n_labels, activation="softmax")`` -- Spektral's
+    own signature, gcn.py:320): device LOCAL_RANK (one process per GPU), created on first use; raises without a GPU."""
+    global _DEFAULT_CTX
+    if _DEFAULT_CTX is None or not _DEFAULT_CTX._live:
+        _DEFAULT_CTX = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _DEFAULT_CTX
+
+
+def with_default_context(init):
+    """Constructor decorator: the leading ``ctx`` may be left out (then it is default_context())."""
+    import functools
+
+    @functools.wraps(init)
+    def wrapper(self, *args, **kw):
+        if "ctx" in kw or (args and isinstance(args[0], Context)):
+            return init(self, *args, **kw)
+        return init(self, default_context(), *args, **kw)
+    return wrapper
+
+
 class Context:
     """One GPU + one HIP stream (gcnx_ctx).  Not thread-safe; one per process per GPU."""
 
@@ -989,19 +1013,28 @@ def add(ctx, a, b, out):
 
 
 def spmm_minmax(ctx, a, h, out, cnt=None, mode="max"):
-    """GeneralConv(aggregate="max" | "min") (gcnx_spmm_csr_minmax): out[t] = max / min over the entries (t, s) of h[s]
-    (values ignored); cnt = the number of entries attaining it (for the gradient)."""
+    """GeneralConv(aggregate="max" | "min" | "prod") (gcnx_spmm_csr_minmax / gcnx_spmm_csr_prod): out[t] = max / min / product over
+    the entries (t, s) of h[s] (values ignored); cnt = what the gradient needs -- the number of entries attaining the extremum, or
+    for "prod" the product of the row's non-zero messages (0 where two or more are zero)."""
     n, f = h.shape
-    assert a.n == n and out.shape == (n, f) and mode in ("max", "min")
+    assert a.n == n and out.shape == (n, f) and mode in ("max", "min", "prod")
+    if mode == "prod":
+        ctx._ck(ctx.lib.gcnx_spmm_csr_prod(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(h), h.ld, _p(out), out.ld, _p(cnt),
+                                           cnt.ld if cnt is not None else 0, n, f))
+        return out
     ctx._ck(ctx.lib.gcnx_spmm_csr_minmax(ctx.h, a.rowptr.ptr, a.colidx.ptr, _p(h), h.ld, _p(out), out.ld, _p(cnt),
                                          cnt.ld if cnt is not None else 0, n, f, 1 if mode == "min" else 0))
     return out
 
 
-def spmm_minmax_bwd(ctx, at, h, out, cnt, dy, dh):
-    """Gradient of spmm_minmax wrt h (gcnx_spmm_csr_minmax_bwd); ``at`` is the transposed operator."""
+def spmm_minmax_bwd(ctx, at, h, out, cnt, dy, dh, mode="max"):
+    """Gradient of spmm_minmax wrt h (gcnx_spmm_csr_minmax_bwd / gcnx_spmm_csr_prod_bwd); ``at`` is the transposed operator."""
     n, f = h.shape
     assert at.n == n and out.shape == (n, f) and cnt.shape == (n, f) and dy.shape == (n, f) and dh.shape == (n, f)
+    if mode == "prod":
+        ctx._ck(ctx.lib.gcnx_spmm_csr_prod_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(h), h.ld, _p(out), out.ld, _p(cnt), cnt.ld,
+                                               _p(dy), dy.ld, _p(dh), dh.ld, n, f))
+        return dh
     ctx._ck(ctx.lib.gcnx_spmm_csr_minmax_bwd(ctx.h, at.rowptr.ptr, at.colidx.ptr, _p(h), h.ld, _p(out), out.ld, _p(cnt), cnt.ld,
                                              _p(dy), dy.ld, _p(dh), dh.ld, n, f))
     return dh

@@ -189,8 +189,8 @@ class GeneralConv(Layer):
     def __init__(self, channels=256, batch_norm=True, dropout=0.0, aggregate="sum", activation="prelu", use_bias=True,
                  prec="f32", **kw):
         super().__init__(**kw)
-        if aggregate not in ("sum", "mean", "max", "min"):
-            raise NotImplementedError(f"GeneralConv(aggregate={aggregate!r}): 'sum' (what gcn.py:320 uses), 'mean', 'max' and 'min' are built")
+        if aggregate not in ("sum", "mean", "max", "min", "prod"):
+            raise ValueError(f"GeneralConv(aggregate={aggregate!r}): Spektral's aggregations are 'sum' (what gcn.py:320 uses), 'mean', 'max', 'min', 'prod'")
         self.aggregate = aggregate
         if not 0.0 <= float(dropout) < 1.0:
             raise ValueError(f"GeneralConv(dropout={dropout!r}): a rate in [0, 1)")
@@ -261,7 +261,7 @@ class GeneralConv(Layer):
         y = out if out is not None else self._buf("y", (n, c))
         au = a.row_mean() if self.aggregate == "mean" else a.unweighted()  # values ignored (8.A.4); "mean": 1 / row length
         cnt = None
-        if self.aggregate in ("max", "min"):                # unsorted_segment_max / _min; the tie counts for the gradient
+        if self.aggregate in ("max", "min", "prod"):        # unsorted_segment_max / _min / _prod; + what their gradients need
             cnt = self._buf("aggcnt", (n, c))
             D.spmm_minmax(ctx, au, h, y, cnt, self.aggregate)
         else:
@@ -274,7 +274,7 @@ class GeneralConv(Layer):
         ctx = self.ctx
         dh = self._buf("dh", dy.shape)
         if cnt is not None:
-            D.spmm_minmax_bwd(ctx, au.transpose(), h, y, cnt, dy, dh)
+            D.spmm_minmax_bwd(ctx, au.transpose(), h, y, cnt, dy, dh, self.aggregate)
         else:
             D.spmm(ctx, au.transpose(), dy, None, dh)        # dH = S^T dY
         if drop_id is not None:

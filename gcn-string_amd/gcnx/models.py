@@ -164,6 +164,7 @@ class _GraphRunner:
 class GCN2(_GraphRunner):
     PARAM_ORDER = ("w1", "b1", "w2", "b2", "w3", "b3")
 
+    @D.with_default_context
     def __init__(self, ctx, n_labels=2, hidden=None, pool="sum", prec="f32", seed=0, comm=None, use_graph=True,
                  cce_train="logits", cce_eval="probs"):
         """cce_train / cce_eval: which branch of keras.backend.categorical_crossentropy the loss follows (see
@@ -687,6 +688,7 @@ class GeneralGNN(_GraphRunner):
     normalises with the statistics of the GLOBAL batch, and the step equals the single-GPU step on the whole batch.
     """
 
+    @D.with_default_context
     def __init__(self, ctx, output, activation=None, hidden=256, message_passing=4, pre_process=2, post_process=2,
                  connectivity="cat", batch_norm=True, dropout=0.0, aggregate="sum", hidden_activation="prelu", pool="sum",
                  prec="f32", seed=0, use_graph=True, comm=None, cce_train="logits", cce_eval="probs"):
@@ -721,8 +723,9 @@ class GeneralGNN(_GraphRunner):
         self.hidden_activation, self.seed = hidden_activation, int(seed)
         # Spektral's other aggregations / pools that map onto kernels that exist (r3): aggregate "mean" is the same gather with
         # the weight 1 / (entries of the row) per entry, pool "avg" / "max" are modes of the segment pool and its backward
-        if aggregate not in ("sum", "mean", "max", "min"):
-            raise NotImplementedError(f"GeneralGNN(aggregate={aggregate!r}): 'sum' (gcn.py:320), 'mean', 'max' and 'min' are built")
+        # ("prod", r4: tf.math.unsorted_segment_prod and its zero-aware gradient -- every aggregation Spektral names is built)
+        if aggregate not in ("sum", "mean", "max", "min", "prod"):
+            raise ValueError(f"GeneralGNN(aggregate={aggregate!r}): Spektral's aggregations are 'sum' (gcn.py:320), 'mean', 'max', 'min', 'prod'")
         if pool not in ("sum", "avg", "max"):
             raise NotImplementedError(f"GeneralGNN(pool={pool!r}): 'sum' (gcn.py:320), 'avg' and 'max' are built")
         self.aggregate, self.pool = aggregate, pool
@@ -937,7 +940,7 @@ class GeneralGNN(_GraphRunner):
         for k in range(mp):
             L = self.layers[li]
             inp = cat.cols((mp - k) * h, (mp - k + 1) * h if sumc else (mp + 1) * h)
-            minmax = self.aggregate in ("max", "min")
+            minmax = self.aggregate in ("max", "min", "prod")
             # ("max" / "min": the layer's messages, its aggregate and the tie counts are kept for the gradient in per-layer
             # buffers -- `h` is reused by the next layer, the `cat` slice summed over with connectivity "sum")
             hk = self._tmp(bufs, f"msg{li}", (batch.n, h)) if minmax else bufs["h"]
@@ -1036,9 +1039,9 @@ class GeneralGNN(_GraphRunner):
         for k in reversed(range(mp)):
             L = self.layers[li]
             dout = dcat.cols((mp - k - 1) * h, (mp - k) * h)
-            if self.aggregate in ("max", "min"):
+            if self.aggregate in ("max", "min", "prod"):
                 zk = bufs[f"agg{li}"] if sumc else cat.cols((mp - k - 1) * h, (mp - k) * h)
-                D.spmm_minmax_bwd(self.ctx, at, bufs[f"msg{li}"], zk, bufs[f"aggcnt{li}"], dout, bufs["dh"])
+                D.spmm_minmax_bwd(self.ctx, at, bufs[f"msg{li}"], zk, bufs[f"aggcnt{li}"], dout, bufs["dh"], self.aggregate)
             else:
                 D.spmm(self.ctx, at, dout, None, bufs["dh"])
             if sumc:                                       # d out_(k-1) = d out_k (the skip) + dz W^T

@@ -460,6 +460,19 @@ GCNX_API int gcnx_spmm_csr_minmax_bwd(gcnx_ctx* ctx, const int32_t* rowptr_t, co
                                       const float* out, int64_t ldo, const float* cnt, int64_t ldc, const float* dy, int64_t lddy,
                                       float* dh, int64_t lddh, int32_t n, int32_t f);
 
+/* GeneralConv(aggregate = "prod") (tf.math.unsorted_segment_prod over the messages gather(h, a.indices[:,1]) of every target row,
+ * SURVEY 8.A.4; adjacency values ignored): out[t, c] = product over the entries (t, s) of h[s, c], 1 for a row without entries
+ * (TensorFlow's value for an empty segment).  aux (may be NULL; needed for the gradient): out where no message of the row is zero,
+ * the product of the non-zero messages where exactly one is, 0 where two or more are. */
+GCNX_API int gcnx_spmm_csr_prod(gcnx_ctx* ctx, const int32_t* rowptr, const int32_t* colidx, const float* h, int64_t ldh, float* out,
+                                int64_t ldo, float* aux, int64_t lda, int32_t n, int32_t f);
+/* Its gradient wrt h (TensorFlow's _UnsortedSegmentProdGrad: out / h for a non-zero message, the product of the others for the only
+ * zero message of a row, 0 where a row holds two or more zeros), from the source side: rowptr_t / colidx_t is the TRANSPOSED
+ * operator; dh[s, c] = sum over targets t of dy[t, c] * (h[s, c] == 0 ? aux[t, c] : out[t, c] / h[s, c]).  Deterministic. */
+GCNX_API int gcnx_spmm_csr_prod_bwd(gcnx_ctx* ctx, const int32_t* rowptr_t, const int32_t* colidx_t, const float* h, int64_t ldh,
+                                    const float* out, int64_t ldo, const float* aux, int64_t lda, const float* dy, int64_t lddy,
+                                    float* dh, int64_t lddh, int32_t n, int32_t f);
+
 /* ---- optimiser --------------------------------------------------------------------------- */
 /* K9 Keras SGD without momentum (gcn.py:325,338): params -= lr * grads over a flat buffer. */
 GCNX_API int gcnx_sgd(gcnx_ctx* ctx, float* params, const float* grads, int64_t n, float lr);

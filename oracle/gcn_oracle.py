@@ -587,6 +587,37 @@ def aggregate_minmax_bwd(rowptr, colidx, h, out, cnt, dy):
     return dh
 
 
+def aggregate_prod(rowptr, colidx, h):
+    """GeneralConv(aggregate="prod") (A.4): tf.math.unsorted_segment_prod over the messages of every target row; a row without
+    messages gets 1.  Returns (out, aux): aux = the product of the row's non-zero messages where at most one message is zero
+    (= out where none is), 0 where two or more are -- what TensorFlow's _UnsortedSegmentProdGrad works from."""
+    n = len(rowptr) - 1
+    out = np.ones((n, h.shape[1]), h.dtype)
+    aux = np.ones((n, h.shape[1]), h.dtype)
+    for t in range(n):
+        idx = colidx[rowptr[t]:rowptr[t + 1]]
+        if len(idx):
+            m = h[idx]
+            zero = m == 0
+            out[t] = np.prod(m, axis=0)
+            aux[t] = np.where(zero.sum(0) >= 2, 0.0, np.prod(np.where(zero, 1.0, m), axis=0))
+    return out, aux
+
+
+def aggregate_prod_bwd(rowptr, colidx, h, out, aux, dy):
+    """_UnsortedSegmentProdGrad: grad is zeroed where a segment holds more than one zero; the partial derivative of the product wrt
+    a message is prod / message for a non-zero message and the product of the non-zero messages for a zero one."""
+    dh = np.zeros_like(h)
+    for t in range(len(rowptr) - 1):
+        idx = colidx[rowptr[t]:rowptr[t + 1]]
+        if len(idx):
+            m = h[idx]
+            zero = m == 0
+            part = np.where(zero, aux[t], out[t] / np.where(zero, 1.0, m))
+            np.add.at(dh, idx, part * dy[t])
+    return dh
+
+
 def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="softmax", aggregate="sum", pool="sum",
                         connectivity="cat", hidden_activation="prelu", drops=None):
     """A.3: pre-MLP -> 4x [z=GeneralConv(out); out=concat([z,out])] -> global pool -> post-MLP.
@@ -596,7 +627,7 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
     (keep / (1 - rate), one array per layer, {"pre": [...], "gnn": [...], "post": [...]}; training only).
     Returns probs, caches, list of (moving_mean, moving_var) updates in layer order."""
     rowptr, colidx, _ = csr
-    minmax = aggregate in ("max", "min")
+    minmax = aggregate in ("max", "min", "prod")
     agg = None if minmax else aggregate_vals(rowptr, aggregate, x.dtype)
     caches = {"pre": [], "gnn": [], "post": []}
     stats = []
@@ -608,7 +639,7 @@ def general_gnn_forward(layers, x, csr, graph_ptr, training, final_activation="s
     for k, p in enumerate(layers["gnn"]):
         h, c, mm, mv = dense_bn_act_fwd(out, p, training, act, drop=drop("gnn", k)); stats.append((mm, mv))
         if minmax:
-            z, c["agg_cnt"] = aggregate_minmax(rowptr, colidx, h, aggregate)
+            z, c["agg_cnt"] = aggregate_prod(rowptr, colidx, h) if aggregate == "prod" else aggregate_minmax(rowptr, colidx, h, aggregate)
             c["agg_out"] = z
         else:
             z = spmm_csr(rowptr, colidx, agg, h)
@@ -634,7 +665,7 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
     pass is evaluated on."""
     rowptr, colidx, _ = csr
     mask = (lambda grp, k: None) if masks is None else (lambda grp, k: masks[grp][k] if k < len(masks[grp]) else None)
-    minmax = aggregate in ("max", "min")
+    minmax = aggregate in ("max", "min", "prod")
     agg = None if minmax else aggregate_vals(rowptr, aggregate, x.dtype)
     act = hidden_activation
     probs, caches, stats = general_gnn_forward(layers, x, csr, graph_ptr, True, aggregate=aggregate, pool=pool,
@@ -658,7 +689,7 @@ def general_gnn_loss_and_grads(layers, x, csr, graph_ptr, y, csr_t=None, cce_mod
         hid = p["kernel"].shape[1]
         dz, dskip = (d[:, :hid], d[:, hid:]) if connectivity == "cat" else (d, d)
         if minmax:
-            dh = aggregate_minmax_bwd(rowptr, colidx, c["y"], c["agg_out"], c["agg_cnt"], dz)
+            dh = (aggregate_prod_bwd if aggregate == "prod" else aggregate_minmax_bwd)(rowptr, colidx, c["y"], c["agg_out"], c["agg_cnt"], dz)
         elif csr_t is not None and agg is None:
             dh = spmm_csr(csr_t[0], csr_t[1], None, dz)
         else:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): bench lines, rocprofv3 kernel stats of the same command, and the
 # separate --pmc passes for HBM traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950).
-#   usage: bash scripts/profile_round.sh r01 [bench|pmc|gemm|all]   (stages, so that one gpurun call stays inside its limit)
+#   usage: bash scripts/profile_round.sh r01 [bench|pmc|gemm|mfma|all]   (stages, so that one gpurun call stays inside its limit)
 set -o pipefail
 R=${1:-r01}
 STAGE=${2:-all}
@@ -39,6 +39,16 @@ for p in f32 bf16x3 bf16; do
   python3 scripts/gemm_bench.py --n 1000000 --shapes 256x256 --prec $p --iters 10 > $O/gemm_bench_$p.txt 2>&1
 done
 python3 scripts/mfma_util.py $O > $O/gemm_mfma_util.txt 2>&1
+fi
+if [ $STAGE = all ] || [ $STAGE = mfma ]; then
+# MFMA utilisation of the GEMM kernels INSIDE the steps (the panel GEMMs of GeneralGNN, the bf16-storage streaming GEMMs of config 3)
+for w in "generalgnn:--model generalgnn --prec bf16x3 --steps 30 --warmup 5" "block1m:--workload block1m --steps 10 --warmup 3"; do
+  tag=${w%%:*}; args="${w#*:} --cpu-seconds 0 --no-config3 --no-generalgnn"
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_step_a_$tag -- python3 bench.py $args > $O/pmc_step_a_$tag.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_step_b_$tag -- python3 bench.py $args > $O/pmc_step_b_$tag.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_step_$tag -- python3 bench.py $args > $O/trace_step_$tag.log 2>&1
+  python3 scripts/mfma_util_step.py $O/pmc_step_a_$tag $O/pmc_step_b_$tag $O/trace_step_$tag > $O/gemm_mfma_util_step_$tag.txt 2>&1
+done
 fi
 # keep the summaries, drop the per-dispatch traces (large)
 find $O -name "*kernel_trace.csv" -delete

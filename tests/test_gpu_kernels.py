@@ -399,6 +399,37 @@ def test_spmm_minmax_aggregation_and_its_gradient_with_ties(ctx, mode):
     assert np.array_equal(dh.numpy(), dh2.numpy())                                    # deterministic
 
 
+def test_spmm_prod_aggregation_and_its_zero_aware_gradient(ctx):
+    """gcnx_spmm_csr_prod / _bwd (GeneralConv(aggregate="prod"), tf.math.unsorted_segment_prod; r4): products, the auxiliary
+    array and the gradient -- prod / message, the product of the others for the only zero of a row, nothing with two or more zeros --
+    on integer-valued messages (exact zeros, exact products), a ragged width, rows without entries (1, no gradient), against the
+    oracle's restatement (which torch.prod pins, tests/test_oracle.py); the gradient runs over the transposed operator of a
+    DIRECTED pattern; bit-reproducible."""
+    import scipy.sparse as sp
+    from gcnx import device as D
+    from gcnx.device import DeviceCSR
+    o = O()
+    rng = np.random.default_rng(19)
+    n, f = 301, 37
+    m = sp.random(n, n, density=0.02, random_state=5, format="csr"); m.data[:] = 1.0
+    m = m.tolil(); m[7, :] = 0; m[200, :] = 0; m = m.tocsr(); m.eliminate_zeros(); m.sort_indices()
+    rp, ci = m.indptr.astype(np.int32), m.indices.astype(np.int32)
+    a = DeviceCSR.from_host_csr(ctx, rp, ci, None, None)
+    h = rng.integers(-2, 3, (n, f)).astype(np.float32)
+    dy = rng.standard_normal((n, f), dtype=np.float32)
+    out, aux, dh = ctx.empty((n, f)), ctx.empty((n, f)), ctx.empty((n, f))
+    dh_ = ctx.to_device(h)
+    D.spmm_minmax(ctx, a, dh_, out, aux, "prod")
+    rout, raux = o.aggregate_prod(rp.astype(np.int64), ci.astype(np.int64), h.astype(np.float64))
+    assert np.array_equal(out.numpy(), rout.astype(np.float32)) and np.array_equal(aux.numpy(), raux.astype(np.float32))
+    assert np.all(out.numpy()[7] == 1.0) and (rout == 0).any() and (raux != rout).any()
+    D.spmm_minmax_bwd(ctx, a.transpose(), dh_, out, aux, ctx.to_device(dy), dh, "prod")
+    rdh = o.aggregate_prod_bwd(rp.astype(np.int64), ci.astype(np.int64), h.astype(np.float64), rout, raux, dy.astype(np.float64))
+    assert rel_err(dh.numpy(), rdh) < TIGHT
+    dh2 = ctx.empty((n, f)); D.spmm_minmax_bwd(ctx, a.transpose(), dh_, out, aux, ctx.to_device(dy), dh2, "prod")
+    assert np.array_equal(dh.numpy(), dh2.numpy())                                    # deterministic
+
+
 def test_spmm_balanced_deal_of_the_tile_graphs_changes_no_bit(ctx):
     """The plan's balanced deal (r3, csrc/spmm.hip balance_tile_list; knob spmm_bal): with >= 1.5 tile graphs per CU the
     graph list is laid out so that the kernel's static snake deal gives every workgroup about the same cost instead of the

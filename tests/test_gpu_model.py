@@ -476,9 +476,10 @@ def test_gcn2_world_size_2_large_batch_with_bf16_storage_equals_single_rank():
 
 
 @pytest.mark.parametrize("aggregate,pool,connectivity", [("mean", "avg", "cat"), ("sum", "max", "cat"), ("mean", "sum", "cat"),
-                                                         ("max", "sum", "cat"), ("min", "avg", "sum"), ("max", "max", "sum")])
+                                                         ("max", "sum", "cat"), ("min", "avg", "sum"), ("max", "max", "sum"),
+                                                         ("prod", "sum", "cat")])
 def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, pool, connectivity):
-    """GeneralGNN(aggregate="mean" | "max" | "min", pool="avg" | "max") (Spektral options beside gcn.py:320's defaults; r3): inference forward,
+    """GeneralGNN(aggregate="mean" | "max" | "min" | "prod", pool="avg" | "max") (Spektral options beside gcn.py:320's defaults; r3, "prod" r4): inference forward,
     training step (loss, probabilities, every gradient) against the fp64 oracle, which torch autograd pins for these options
     (tests/test_oracle.py).  Gradients at 1e-4 against the oracle on the device's side of every PReLU kink, as in the
     default-option test."""
@@ -506,8 +507,8 @@ def test_general_gnn_aggregate_and_pool_options_match_oracle(ctx, aggregate, poo
                                                      aggregate=aggregate, pool=pool, connectivity=connectivity)
     assert abs(loss - rl) < TOL * max(1, rl) and acc == pytest.approx(ra)
     assert rel_err(m._bufs["probs"].numpy(), rp) < TOL
-    with pytest.raises(NotImplementedError):
-        GeneralGNN(ctx, 2, activation="softmax", aggregate="prod")
+    with pytest.raises(ValueError):
+        GeneralGNN(ctx, 2, activation="softmax", aggregate="median")          # (not one of Spektral's five)
 
 
 def test_general_gnn_sync_bn_world_size_2_equals_single_rank():
@@ -753,6 +754,27 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict, pre
                 assert np.allclose(wa, wb - np.float32(0.01) * got[m.layers.index(L)]["kernel"], rtol=0, atol=1e-6)
 
 
+def test_general_gnn_with_spektrals_own_signature(ctx):
+    """gcn.py:320 verbatim: `GeneralGNN(dataset.n_labels, activation="softmax")` -- no ctx: the process-wide default context --
+    builds the same model as the explicit-ctx form and returns the same probabilities for the loader's host tuple."""
+    import gcnx
+    from gcnx import synth
+    from gcnx.models import GeneralGNN
+    hb = synth.ecoli_batch(3, 16, seed=5)
+    m0 = GeneralGNN(2, activation="softmax", hidden=16, message_passing=2, seed=3)
+    assert m0.ctx is gcnx.default_context() and m0.ctx is not ctx
+    m1 = GeneralGNN(ctx, 2, activation="softmax", hidden=16, message_passing=2, seed=3)
+    from gcnx.models import DeviceBatch
+    from gcnx.device import DeviceCSR, Segments
+    outs = []
+    for m in (m0, m1):
+        c = m.ctx
+        a = DeviceCSR.from_host_csr(c, hb.rowptr, hb.colidx, None, hb.graph_ptr)
+        b = DeviceBatch(c, c.to_device(hb.x), a, Segments(c, hb.graph_ptr), c.to_device(hb.y))
+        outs.append(m(b, training=False))
+    assert outs[0].shape == (3, 2) and np.array_equal(outs[0], outs[1])
+
+
 def test_general_gnn_weight_orders(ctx):
     """get_weights() / set_weights() orders (model.get_weights(), gcn.py:383): "layer" lists every layer as Dense, BN,
     PReLU would; "keras" (default) differs for the four GeneralConv layers only -- one Keras Layer whose own kernel and
@@ -790,8 +812,8 @@ def test_general_gnn_weight_orders(ctx):
 
 def test_general_gnn_rejects_unbuilt_options(ctx):
     from gcnx.models import GeneralGNN
-    with pytest.raises(NotImplementedError):
-        GeneralGNN(ctx, 2, activation="softmax", aggregate="prod")
+    with pytest.raises(ValueError):
+        GeneralGNN(ctx, 2, activation="softmax", aggregate="median")
     with pytest.raises(NotImplementedError):
         GeneralGNN(ctx, 2, activation="sigmoid")
     with pytest.raises(NotImplementedError):
@@ -1227,7 +1249,7 @@ def test_config3_full_step_vs_fp64_reference_with_the_relu_kinks_separated(ctx, 
 
 
 @pytest.mark.parametrize("batch_norm,activation", [(True, "prelu"), (True, "relu"), (False, "relu"), (False, None), (False, "prelu")])
-@pytest.mark.parametrize("aggregate", ["sum", "mean", "max"])
+@pytest.mark.parametrize("aggregate", ["sum", "mean", "max", "prod"])
 def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     """spektral.layers.GeneralConv as a layer of its own (SURVEY 8(b) surface list; inside GeneralGNN at gcn.py:320):
     layer([x, a], training=) = sum-aggregation over a.indices of activation(BN(x W + b)) -- adjacency values ignored --
@@ -1243,7 +1265,7 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
     x = ctx.to_device(hb.x)
     conv = GeneralConv(20, batch_norm=batch_norm, activation=activation, aggregate=aggregate, seed=4)
     conv([x, a], training=True)                                  # builds
-    minmax = aggregate in ("max", "min")
+    minmax = aggregate in ("max", "min", "prod")
     agg = None if minmax else O.aggregate_vals(hb.rowptr, aggregate)   # None ("sum") / 1 / row length per entry ("mean", r3)
     rng = np.random.default_rng(1)
     names = list(conv.params) + list(conv.state)
@@ -1264,13 +1286,13 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
         y = conv([x, a], training=training)
         h, cache, mm, mv = O.dense_bn_act_fwd(x64, p, training, activation)
         if minmax:
-            ry, rcnt = O.aggregate_minmax(rp, ci, h, aggregate)
+            ry, rcnt = O.aggregate_prod(rp, ci, h) if aggregate == "prod" else O.aggregate_minmax(rp, ci, h, aggregate)
         else:
             ry = O.spmm_csr(rp, ci, agg, h)
         assert rel_err(y.numpy(), ry) < TOL, training
     dy = rng.standard_normal(y.shape).astype(np.float32)
     dx = conv.backward(ctx.to_device(dy))
-    dh = (O.aggregate_minmax_bwd(rp, ci, h, ry, rcnt, dy.astype(np.float64)) if minmax else
+    dh = ((O.aggregate_prod_bwd if aggregate == "prod" else O.aggregate_minmax_bwd)(rp, ci, h, ry, rcnt, dy.astype(np.float64)) if minmax else
           O.spmm_csr_T(rp, ci, agg, dy.astype(np.float64)))
     rdx, rg = O.dense_bn_act_bwd(dh, cache, p, activation)
     assert rel_err(dx.numpy(), rdx) < 2 * TOL
@@ -1278,8 +1300,8 @@ def test_general_conv_layer_surface(ctx, batch_norm, activation, aggregate):
         assert rel_err(conv.grads[k].numpy(), rg[k]) < 2 * TOL or np.abs(rg[k]).max() < 1e-9, k
     if batch_norm:
         assert rel_err(conv.state["moving_mean"].numpy(), mm) < TOL and rel_err(conv.state["moving_var"].numpy(), mv) < TOL
-    with pytest.raises(NotImplementedError):
-        GeneralConv(8, aggregate="prod")
+    with pytest.raises(ValueError):
+        GeneralConv(8, aggregate="median")
 
 
 def test_general_conv_layer_dropout(ctx):

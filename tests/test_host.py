@@ -61,6 +61,32 @@ def test_no_cpu_fallback_without_gpu():
     assert "no CPU fallback" in _lib.last_error()
 
 
+def test_model_constructors_keep_spektrals_signature():
+    """GeneralGNN(output, activation=None, hidden=256, message_passing=4, pre_process=2, post_process=2,
+    connectivity="cat", batch_norm=True, dropout=0.0, aggregate="sum", hidden_activation="prelu", pool="sum") -- Spektral's names,
+    order and defaults behind an OPTIONAL leading ctx (gcn.py:320 is `GeneralGNN(dataset.n_labels, activation="softmax")`; without
+    a ctx the process-wide default context is used -- and without a GPU that raises: no CPU fallback)."""
+    import inspect
+    from gcnx.models import GCN2, GeneralGNN
+    from gcnx.layers import GCNConv, GeneralConv
+    ps = list(inspect.signature(GeneralGNN.__init__).parameters.values())
+    assert [p.name for p in ps[:2]] == ["self", "ctx"]
+    want = [("output", inspect.Parameter.empty), ("activation", None), ("hidden", 256), ("message_passing", 4), ("pre_process", 2),
+            ("post_process", 2), ("connectivity", "cat"), ("batch_norm", True), ("dropout", 0.0), ("aggregate", "sum"),
+            ("hidden_activation", "prelu"), ("pool", "sum")]
+    assert [(p.name, p.default) for p in ps[2:2 + len(want)]] == want
+    ps = list(inspect.signature(GeneralConv.__init__).parameters.values())[1:]
+    assert [(p.name, p.default) for p in ps[:6]] == [("channels", 256), ("batch_norm", True), ("dropout", 0.0), ("aggregate", "sum"),
+                                                      ("activation", "prelu"), ("use_bias", True)]
+    ps = list(inspect.signature(GCNConv.__init__).parameters.values())[1:]
+    assert [(p.name, p.default) for p in ps[:5]] == [("channels", inspect.Parameter.empty), ("activation", None), ("use_bias", True),
+                                                      ("kernel_initializer", "glorot_uniform"), ("bias_initializer", "zeros")]
+    if not os.path.exists("/dev/kfd"):
+        for make in (lambda: GeneralGNN(2, activation="softmax"), lambda: GCN2(2)):
+            with pytest.raises(RuntimeError):
+                make()                                   # the default context needs a GPU
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "gcn-string_amd")
     for dp, _, files in os.walk(pkg):

@@ -154,7 +154,8 @@ def test_finite_difference_gradcheck_gcnconv():
         assert rel_err(grad, num) < 1e-6
 
 
-@pytest.mark.parametrize("aggregate,pool", [("sum", "sum"), ("mean", "avg"), ("sum", "max"), ("mean", "sum"), ("max", "sum"), ("min", "avg")])
+@pytest.mark.parametrize("aggregate,pool", [("sum", "sum"), ("mean", "avg"), ("sum", "max"), ("mean", "sum"), ("max", "sum"), ("min", "avg"),
+                                            ("prod", "sum")])
 def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
     """n1 tier (GeneralGNN-complete): BN(train) + PReLU + concat-skip + sum-aggregation (gcn.py:320's defaults), and the
     Spektral options aggregate="mean" / pool="avg" | "max" (r3)."""
@@ -203,6 +204,8 @@ def test_general_gnn_gradients_match_torch_autograd(aggregate, pool):
     def aggregate_t(h):          # "max" / "min": per target row over its messages (torch.amax / amin share the gradient among ties)
         if aggregate in ("sum", "mean"):
             return at @ h
+        if aggregate == "prod":  # tf.math.unsorted_segment_prod (r4)
+            return torch.stack([h[torch.tensor(ix)].prod(0) for ix in nbrs])
         f = torch.amax if aggregate == "max" else torch.amin
         return torch.stack([f(h[torch.tensor(ix)], 0) for ix in nbrs])
     for p in tl["gnn"]:
@@ -244,6 +247,30 @@ def test_aggregate_minmax_ties_share_the_gradient():
         (tout * torch.tensor(dy[rows])).sum().backward()
         assert np.array_equal(out[rows], tout.detach().numpy())
         assert np.allclose(dh, th.grad.numpy(), rtol=1e-12, atol=1e-14)
+
+
+def test_aggregate_prod_follows_tensorflows_zero_aware_gradient():
+    """aggregate="prod" (r4) with exact zeros among the messages (integer values): the product, and TensorFlow's
+    _UnsortedSegmentProdGrad -- prod / message for a non-zero message, the product of the others for the ONLY zero of a row, nothing
+    where a row holds two or more zeros -- against torch.prod, whose backward handles zeros the same way; a row without messages is 1."""
+    import torch
+    rng = np.random.default_rng(11)
+    rowptr, colidx = _rand_csr(rng, 14, 0.3)
+    rowptr = rowptr.copy(); colidx = colidx.copy()
+    e0, e1 = rowptr[3], rowptr[4]                      # make row 3 empty
+    colidx = np.concatenate([colidx[:e0], colidx[e1:]]); rowptr[4:] -= (e1 - e0)
+    h = rng.integers(-2, 3, (14, 6)).astype(np.float64)
+    dy = rng.standard_normal((14, 6))
+    out, aux = O.aggregate_prod(rowptr, colidx, h)
+    dh = O.aggregate_prod_bwd(rowptr, colidx, h, out, aux, dy)
+    zeros = np.array([[(h[colidx[rowptr[t]:rowptr[t + 1]], c] == 0).sum() for c in range(6)] for t in range(14)])
+    assert (zeros == 0).any() and (zeros == 1).any() and (zeros >= 2).any()          # all three branches of the rule occur
+    assert np.all(out[3] == 1.0)
+    th = torch.tensor(h, requires_grad=True)
+    tout = torch.stack([th[torch.tensor(colidx[rowptr[t]:rowptr[t + 1]])].prod(0) for t in range(14)])
+    (tout * torch.tensor(dy)).sum().backward()
+    assert np.array_equal(out, tout.detach().numpy())
+    assert np.allclose(dh, th.grad.numpy(), rtol=1e-12, atol=1e-14)
 
 
 @pytest.mark.parametrize("connectivity,batch_norm,act,rate", [("sum", True, "prelu", 0.0), ("cat", False, "prelu", 0.0),
