@@ -1365,8 +1365,11 @@ __device__ __forceinline__ void cb_slots1(const __amdgpu_buffer_rsrc_t hbuf, uns
   }
 }
 
+#ifndef GCNX_CB_OCC
+#define GCNX_CB_OCC 8
+#endif
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256, 8) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
+__global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
                                                          const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh,
                                                          const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
                                                          int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items, int dbg) {
@@ -1981,12 +1984,13 @@ static int launch_cb(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const RowOrder* 
   const int rc = plan_cb_items(ctx, plan, order, f / kCbCols, &items, &nitems);
   if (rc) return rc;
   if (nitems == 0) return GCNX_OK;
-  int dbg = 0;
-#ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set): 1 no stores, 4 no gathers, 8 nt stores
-  if (const char* e = getenv("GCNX_CB_DBG")) dbg = atoi(e);
+  int dbg = 0, pad_lds = 0;
+#ifdef GCNX_TUNING   // timing-only ablation bits (results are WRONG when set): see scripts/cb_ablate.sh; GCNX_CB_LDS: bytes of unused
+  if (const char* e = getenv("GCNX_CB_DBG")) dbg = atoi(e);        // dynamic LDS per workgroup (caps the workgroups per CU)
+  if (const char* e = getenv("GCNX_CB_LDS")) pad_lds = atoi(e);
 #endif
-  if (vals) hipLaunchKernelGGL((spmm_cb_kernel<true>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
-  else hipLaunchKernelGGL((spmm_cb_kernel<false>), dim3(nitems), dim3(256), 0, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
+  if (vals) hipLaunchKernelGGL((spmm_cb_kernel<true>), dim3(nitems), dim3(256), pad_lds, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
+  else hipLaunchKernelGGL((spmm_cb_kernel<false>), dim3(nitems), dim3(256), pad_lds, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }

@@ -18,7 +18,7 @@ python3 bench.py --workload powerlaw --steps 20 --warmup 3 --cpu-seconds 0 > $O/
 python3 bench.py --model generalgnn --steps 50 --warmup 5 > $O/bench_generalgnn.json 2> $O/bench_generalgnn.err
 python3 bench.py --model generalgnn --prec bf16x3 --steps 50 --warmup 5 --cpu-seconds 0 > $O/bench_generalgnn_bf16x3.json 2> $O/bench_generalgnn_bf16x3.err
 python3 bench.py --model generalgnn --prec bf16 --steps 50 --warmup 5 --cpu-seconds 0 > $O/bench_generalgnn_bf16.json 2> $O/bench_generalgnn_bf16.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ecoli -- python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 > $O/trace_ecoli.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ecoli -- python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 --no-generalgnn > $O/trace_ecoli.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_block1m -- python3 bench.py --workload block1m --steps 20 --warmup 3 --cpu-seconds 0 > $O/trace_block1m.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_powerlaw -- python3 bench.py --workload powerlaw --steps 20 --warmup 3 --cpu-seconds 0 > $O/trace_powerlaw.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_generalgnn -- python3 bench.py --model generalgnn --prec bf16x3 --steps 50 --warmup 5 --cpu-seconds 0 > $O/trace_generalgnn.log 2>&1
