@@ -1326,61 +1326,72 @@ constexpr int kCbMinF = 128;         // narrower features: the whole graph fits 
 template <int N>
 __device__ __forceinline__ int row_bcast16(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false); }
 
-template <bool WEIGHTED, int S, int K>
+template <bool WEIGHTED, bool FOLD, int S, int K>
 __device__ __forceinline__ void cb_slot_row(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, int ci, float wv,
                                             int deg, float4& acc) {
   const int col = row_bcast16<K + 4 * (S & 3)>(ci);
   const unsigned off = (S < deg && !no_gather) ? ((unsigned)col * ld32 + c) * 4u : 0xFFFFFFF0u;
-  const float4 hv = buf4(hbuf, off);
+  float4 hv = buf4(hbuf, off);
+  if (FOLD) hv = f4_step(hv);                 // (the gathered operand is the saved ReLU output: its 0 / 1 mask is what is summed)
   if (WEIGHTED) acc = f4_fma(__int_as_float(row_bcast16<K + 4 * (S & 3)>(__float_as_int(wv))), hv, acc);
   else acc = f4_add(acc, hv);
 }
 
 // Entry slots [J0, J) of four rows (spmm_cb_kernel, kind 3): slot s of row k is held by lane k + 4 (s & 3) of the lane group, in
 // register set s >> 2.
-template <bool WEIGHTED, int J, int J0, int T>
+template <bool WEIGHTED, bool FOLD, int J, int J0, int T>
 __device__ __forceinline__ void cb_slots(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, const int (&ci)[T],
                                          const float (&wv)[T], const int (&deg)[4], float4 (&acc)[4]) {
   if constexpr (J0 < J) {
-    cb_slot_row<WEIGHTED, J0, 0>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[0], acc[0]);
-    cb_slot_row<WEIGHTED, J0, 1>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[1], acc[1]);
-    cb_slot_row<WEIGHTED, J0, 2>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[2], acc[2]);
-    cb_slot_row<WEIGHTED, J0, 3>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[3], acc[3]);
-    if constexpr ((J0 & 1) == 1 && J0 + 1 < J) __builtin_amdgcn_sched_barrier(0);   // (eight gathers in flight: more hoisted together spill)
-    cb_slots<WEIGHTED, J, J0 + 1, T>(hbuf, ld32, c, no_gather, ci, wv, deg, acc);
+    cb_slot_row<WEIGHTED, FOLD, J0, 0>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[0], acc[0]);
+    cb_slot_row<WEIGHTED, FOLD, J0, 1>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[1], acc[1]);
+    cb_slot_row<WEIGHTED, FOLD, J0, 2>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[2], acc[2]);
+    cb_slot_row<WEIGHTED, FOLD, J0, 3>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[3], acc[3]);
+    // (eight gathers in flight: more hoisted together spill; FOLD -- the mask arithmetic needs registers of its own -- four)
+    if constexpr ((FOLD || (J0 & 1) == 1) && J0 + 1 < J) __builtin_amdgcn_sched_barrier(0);
+    cb_slots<WEIGHTED, FOLD, J, J0 + 1, T>(hbuf, ld32, c, no_gather, ci, wv, deg, acc);
   }
 }
 
 // The same for ONE row walked by a whole wave (kinds 0 and 1): slot j of lane group g is entry 4 j + g of the current 64-entry step.
-template <bool WEIGHTED, int J, int J0>
+template <bool WEIGHTED, bool FOLD, int J, int J0>
 __device__ __forceinline__ void cb_slots1(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, int ci, float wv,
                                           int left, float4& acc) {
   if constexpr (J0 < J) {
     const int col = row_bcast16<J0>(ci);
     const unsigned off = (J0 < left && !no_gather) ? ((unsigned)col * ld32 + c) * 4u : 0xFFFFFFF0u;
-    const float4 hv = buf4(hbuf, off);
+    float4 hv = buf4(hbuf, off);
+    if (FOLD) hv = f4_step(hv);
     if (WEIGHTED) acc = f4_fma(__int_as_float(row_bcast16<J0>(__float_as_int(wv))), hv, acc);
     else acc = f4_add(acc, hv);
-    cb_slots1<WEIGHTED, J, J0 + 1>(hbuf, ld32, c, no_gather, ci, wv, left, acc);
+    cb_slots1<WEIGHTED, FOLD, J, J0 + 1>(hbuf, ld32, c, no_gather, ci, wv, left, acc);
   }
 }
 
 #ifndef GCNX_CB_OCC
 #define GCNX_CB_OCC 8
 #endif
-template <bool WEIGHTED>
+template <bool WEIGHTED, bool FOLD = false>
 __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec* __restrict__ rowrec, const int32_t* __restrict__ colidx,
                                                          const float* __restrict__ vals, const float* __restrict__ h, int64_t ldh,
                                                          const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
-                                                         int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items, int dbg) {
+                                                         int32_t n, int32_t nnz, int act, int nitems, const int4* __restrict__ items, int dbg,
+                                                         FoldArgs fo, const int32_t* __restrict__ cb_gids) {
   __shared__ float4 s_long[4][16];
   const int4 it = items[gcnx_xcd_remap(blockIdx.x, nitems)];
-  const int p0 = it.x, cnt = it.y & 0xFFFF, kind = it.y >> 16, col0 = it.z, row0 = it.w;
+  // (item: first position, rows | kind << 16, first column | index among the column-block graphs << 16, the graph's first row)
+  const int p0 = it.x, cnt = it.y & 0xFFFF, kind = it.y >> 16, col0 = it.z & 0xFFFF, row0 = it.w;
   if (dbg & 16) { if (dbg == 0x7fffffff) out[0] = (float)p0; return; }      // (tuning: launch + item load only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, sub = lane & 15;
   const int c = col0 + sub * 4;
+  // bv: the bias slice of this lane's four columns; FOLD (gcnx_spmm_csr_pool_bwd): the graph's dPooled row (x 1 / n_g for the average
+  // pool) instead, which MULTIPLIES the finished sum of the gathered ReLU masks
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bv = *reinterpret_cast<const float4*>(bias + c);
+  if (FOLD) {
+    const int gid = cb_gids[(unsigned)it.z >> 16];
+    bv = *reinterpret_cast<const float4*>(fo.dp + (int64_t)gid * fo.lddp + c);
+    if (fo.avg) { const float sc = 1.0f / (float)(fo.gp[gid + 1] - fo.gp[gid]); bv.x *= sc; bv.y *= sc; bv.z *= sc; bv.w *= sc; }
+  } else if (bias) bv = *reinterpret_cast<const float4*>(bias + c);
   // (the host checks that byte offsets into h fit 32 bits)
   const __amdgpu_buffer_rsrc_t hbuf = __builtin_amdgcn_make_buffer_rsrc((void*)h, (short)0, (int)((uint64_t)n * (uint64_t)ldh * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t cbuf = __builtin_amdgcn_make_buffer_rsrc((void*)colidx, (short)0, nnz * 4, 0x00020000);
@@ -1389,8 +1400,11 @@ __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec*
   const unsigned ld32 = (unsigned)ldh;
   constexpr unsigned kOob = 0xFFFFFFF0u;
   auto epilogue = [&](float4 acc, int r) {
-    acc = f4_add(acc, bv);
-    if (act == GCNX_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    if (FOLD) { acc.x *= bv.x; acc.y *= bv.y; acc.z *= bv.z; acc.w *= bv.w; }
+    else {
+      acc = f4_add(acc, bv);
+      if (act == GCNX_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    }
     if (dbg & 1) return;
     // non-temporal: a result row is not read again by this launch and should not push the block's source rows out of L2
     if (!(dbg & 8)) __builtin_nontemporal_store(f32x4v{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4v*>(out + (int64_t)r * ldo + c));
@@ -1437,7 +1451,7 @@ __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec*
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) dg[k] = deg[k] - base;
-      cb_slots<WEIGHTED, J, 0, T>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci, wv, dg, acc);
+      cb_slots<WEIGHTED, FOLD, J, 0, T>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci, wv, dg, acc);
     };
     if (maxd <= 1) slots(std::integral_constant<int, 1>{}, 0);
     else if (maxd <= 2) slots(std::integral_constant<int, 2>{}, 0);
@@ -1474,15 +1488,15 @@ __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec*
     cn = ld_col(ent_off(e0 + 64)); wn = ld_val(ent_off(e0 + 64));
     const int left = (wb - e0 - g + 3) >> 2;            // this group's entries from here on: slot j exists while j < left
     // (four slots at a time, more only where the step has them: all 16 gathers hoisted together spilled 8 registers)
-    cb_slots1<WEIGHTED, 4, 0>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+    cb_slots1<WEIGHTED, FOLD, 4, 0>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
     if (wb - e0 > 16) {
       __builtin_amdgcn_sched_barrier(0);
-      cb_slots1<WEIGHTED, 8, 4>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+      cb_slots1<WEIGHTED, FOLD, 8, 4>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
       if (wb - e0 > 32) {
         __builtin_amdgcn_sched_barrier(0);
-        cb_slots1<WEIGHTED, 12, 8>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+        cb_slots1<WEIGHTED, FOLD, 12, 8>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
         __builtin_amdgcn_sched_barrier(0);
-        cb_slots1<WEIGHTED, 16, 12>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
+        cb_slots1<WEIGHTED, FOLD, 16, 12>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci1, wv1, left, acc);
       }
     }
   }
@@ -1709,6 +1723,7 @@ struct gcnx_spmm_plan {
   // rows of all OTHER graphs as chunks (what the row gather takes when no tile kernel runs and the cb graphs go their own way)
   int ncb_graphs = 0, nchunks_cb = 0;
   long long cb_rows = 0;
+  int32_t* cb_gids = nullptr;           // graph index of the k-th column-block graph (the folded backward's dPooled row)
   int2* rest = nullptr;
   int nrest = 0, rest_rpc = kRowsPerChunk;
 };
@@ -1732,6 +1747,7 @@ static void plan_free(gcnx_spmm_plan* p) {
   if (p->items) (void)hipFree(p->items);
   if (p->pipe_chunks) (void)hipFree(p->pipe_chunks);
   if (p->rest) (void)hipFree(p->rest);
+  if (p->cb_gids) (void)hipFree(p->cb_gids);
   for (int i = 0; i < p->norders; ++i) {
     for (int k = 0; k < p->orders[i].ncb_sets; ++k) if (p->orders[i].cb_items[k].dev) (void)hipFree(p->orders[i].cb_items[k].dev);
     if (p->orders[i].dev) (void)hipFree(p->orders[i].dev);
@@ -1921,9 +1937,11 @@ static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder*
   try {
     std::vector<int4> items;
     size_t at = 0;                                             // position in od->cb_deg
+    int kcb = -1;                                              // index among the column-block graphs (item.z >> 16; plan->cb_gids)
     for (int g = 0; g < p->nblocks; ++g) {
       const int r0 = p->bp[g], ng = p->bp[g + 1] - p->bp[g];
       if (!cb_graph(ng, p->cap2)) continue;
+      ++kcb;
       const int* deg = od->cb_deg.data() + at;                 // descending
       at += (size_t)ng;
       int n0 = 0, n1 = 0;                                      // rows of kind 0, of kind 0 or 1
@@ -1937,9 +1955,9 @@ static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder*
       std::vector<int4> heavy, light;
       for (int b = 0; b < nblk; ++b) {
         heavy.clear(); light.clear();
-        if (kinds & 1) for (int q = 0; q < n0; ++q) heavy.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols, r0));
-        if (kinds & 2) for (int q = n0; q < n1; q += 4) heavy.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols, r0));
-        if (kinds & 8) for (int q = n1; q < ng; q += 64) light.push_back(make_int4(r0 + q, std::min(64, ng - q) | (3 << 16), b * kCbCols, r0));
+        if (kinds & 1) for (int q = 0; q < n0; ++q) heavy.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols | (kcb << 16), r0));
+        if (kinds & 2) for (int q = n0; q < n1; q += 4) heavy.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols | (kcb << 16), r0));
+        if (kinds & 8) for (int q = n1; q < ng; q += 64) light.push_back(make_int4(r0 + q, std::min(64, ng - q) | (3 << 16), b * kCbCols | (kcb << 16), r0));
         // The long rows' items gather out of L2 (the block's source rows are re-read ~degree times), the short rows' items stream
         // from HBM: dealt evenly among each other (heaviest first on either side) the two kinds of traffic run side by side.
         if (ctx->knob_spmm_cb == 2 || heavy.empty() || light.empty()) {      // (2: heaviest first, as the first version had it)
@@ -1973,12 +1991,12 @@ static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder*
 
 // Whether the column-block graphs of `plan` go through spmm_cb_kernel for this call (else: the row gather + hub segments).
 static bool cb_path_ok(const gcnx_ctx* ctx, const gcnx_spmm_plan* plan, int32_t n, int32_t f, int64_t ldh, int out16) {
-  return plan && plan->ncb_graphs > 0 && ctx->knob_spmm_cb != 0 && !out16 && f >= kCbMinF && f % kCbCols == 0 &&
-         (uint64_t)n * (uint64_t)ldh * 4u < 0xFFFFFF00ull;
+  return plan && plan->ncb_graphs > 0 && plan->ncb_graphs < 32768 && ctx->knob_spmm_cb != 0 && !out16 && f >= kCbMinF && f % kCbCols == 0 &&
+         f <= 32768 && (uint64_t)n * (uint64_t)ldh * 4u < 0xFFFFFF00ull;      // (an item packs column and graph index into 16 bits each)
 }
 
 static int launch_cb(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const RowOrder* order, const int32_t* colidx, const float* vals, const float* h,
-                     int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act) {
+                     int64_t ldh, const float* bias, float* out, int64_t ldo, int32_t n, int32_t f, int act, const FoldArgs* fold = nullptr) {
   const int4* items = nullptr;
   int nitems = 0;
   const int rc = plan_cb_items(ctx, plan, order, f / kCbCols, &items, &nitems);
@@ -1989,8 +2007,13 @@ static int launch_cb(gcnx_ctx* ctx, const gcnx_spmm_plan* plan, const RowOrder* 
   if (const char* e = getenv("GCNX_CB_DBG")) dbg = atoi(e);        // dynamic LDS per workgroup (caps the workgroups per CU)
   if (const char* e = getenv("GCNX_CB_LDS")) pad_lds = atoi(e);
 #endif
-  if (vals) hipLaunchKernelGGL((spmm_cb_kernel<true>), dim3(nitems), dim3(256), pad_lds, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
-  else hipLaunchKernelGGL((spmm_cb_kernel<false>), dim3(nitems), dim3(256), pad_lds, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, bias, out, ldo, n, order->nnz, act, nitems, items, dbg);
+  const FoldArgs fo = fold ? *fold : FoldArgs{nullptr, nullptr, 0, 0, 0};
+#define GCNX_CB_LAUNCH(W, F)                                                                                                       \
+  hipLaunchKernelGGL((spmm_cb_kernel<W, F>), dim3(nitems), dim3(256), pad_lds, ctx->stream, (const RowRec*)order->dev, colidx, vals, h, ldh, \
+                     bias, out, ldo, n, order->nnz, act, nitems, items, dbg, fo, (const int32_t*)plan->cb_gids)
+  if (vals) { if (fold) GCNX_CB_LAUNCH(true, true); else GCNX_CB_LAUNCH(true, false); }
+  else { if (fold) GCNX_CB_LAUNCH(false, true); else GCNX_CB_LAUNCH(false, false); }
+#undef GCNX_CB_LAUNCH
   GCNX_LAUNCH_OK(ctx);
   return GCNX_OK;
 }
@@ -2087,6 +2110,7 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     const int rpc = ctx->knob_spmm_tall_rpc == 32 ? kRowsPerChunk : kRowsPerChunkSmall;
     p->chunk_rpc = rpc;
     std::vector<int2> ch_cb, rest;
+    std::vector<int32_t> cb_gid_list;
     long long rest_rows = 0;
     for (int g = 0; g < nblocks; ++g) {
       const int ng = bp[g + 1] - bp[g];
@@ -2101,7 +2125,7 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
       if (ng <= cap1) { t1.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
       else if (ng <= cap2) { t2.push_back(make_int2(r0, ng)); tile_rows += ng; by_row.emplace_back(r0, g); }
       else for (int r = r0; r < r0 + ng; r += rpc) (cbg ? ch_cb : ch).push_back(make_int2(r, std::min(r + rpc, r0 + ng)));
-      if (cbg) { p->ncb_graphs++; p->cb_rows += ng; }
+      if (cbg) { p->ncb_graphs++; p->cb_rows += ng; cb_gid_list.push_back(g); }
       else for (int r = r0; r < r0 + ng; r += p->rest_rpc) rest.push_back(make_int2(r, std::min(r + p->rest_rpc, r0 + ng)));
     }
     p->nchunks_cb = (int)ch_cb.size();
@@ -2154,6 +2178,7 @@ int gcnx_spmm_plan_create(gcnx_ctx* ctx, const int32_t* block_ptr, int32_t nbloc
     if (e == hipSuccess) e = plan_upload(ctx, &p->pipe_chunks, tall);
     if (e == hipSuccess) e = plan_upload(ctx, &p->items, items);
     if (e == hipSuccess) e = plan_upload(ctx, &p->rest, rest);
+    if (e == hipSuccess) e = plan_upload(ctx, &p->cb_gids, cb_gid_list);
     if (e != hipSuccess) {
       plan_free(p);
       return gcnx_fail(ctx, e == hipErrorOutOfMemory ? GCNX_ERR_NOMEM : GCNX_ERR_HIP, "gcnx_spmm_plan_create: %s", hipGetErrorString(e));
@@ -2496,6 +2521,17 @@ static int spmm_csr_pool_bwd_impl(gcnx_ctx* ctx, const int32_t* rowptr, const in
   if (plan && plan->nblocks == b) { const int rb = plan_order(ctx, plan, rowptr, n, false, &rowrec, &order); if (rb) return rb; }
   if (out16 && (!tiles || (order && order->nsegs_tall > 0))) return GCNX_ERR_UNSUPPORTED;
   if (!tiles) {
+    if (cb_path_ok(ctx, plan, n, f, ldy, out16) && plan->nblocks == b && order != nullptr) {
+      // graphs too large for an XCD's L2 in column blocks, folded (r4: as the forward aggregation); the other graphs' rows as
+      // plan-listed chunks on the row gather, their hub rows as segments
+      if (plan->nrest > 0) {
+        const bool hubs = order->nsegs > order->nsegs_cb;
+        dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, plan->rest, plan->nrest, &fo, plan->rest_rpc, hubs ? kHubDeg : 0);
+        GCNX_LAUNCH_OK(ctx);
+        if (hubs) { const int rh = launch_hubs(ctx, order, false, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, &fo, true); if (rh) return rh; }
+      }
+      return launch_cb(ctx, plan, order, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, &fo);
+    }
     const bool hubs = order && order->nsegs > 0;
     dispatch_rows(ctx, rowptr, colidx, vals, y, ldy, nullptr, out, ldo, n, f, GCNX_ACT_NONE, nullptr, 0, &fo, kRowsPerChunk, hubs ? kHubDeg : 0);
     GCNX_LAUNCH_OK(ctx);

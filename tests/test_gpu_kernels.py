@@ -1900,6 +1900,48 @@ def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
         assert np.array_equal(outs[1][short], outs[0][short])
 
 
+@pytest.mark.parametrize("mode", ["sum", "avg"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_pool_bwd_fold_in_column_blocks(ctx, mode, weighted):
+    """The folded pool' / ReLU' backward aggregation (gcnx_spmm_csr_pool_bwd) on graphs of >= 4096 rows (r4): the column-block
+    kernel gathers the saved ReLU output as its 0 / 1 mask and multiplies the finished sums by the graph's dPooled row (x 1 / n_g
+    for the average pool) -- against A^T (pool'(dPooled) * [y > 0]) in fp64, against the r3 path (row gather + hub segments,
+    GCNX_SPMM_CB=0) on the same operands, bit-reproducible; power-law graphs (hub rows included) between graphs of ordinary size."""
+    import scipy.sparse as sp
+    from gcnx import device as D, synth
+    from gcnx.device import Segments
+    f = 256
+    big = synth.power_law_batch(2, 8192, f, seed=4)
+    small = synth.ecoli_batch(4, f, seed=9)
+    hb = synth.concat_batches([small.slice_graphs(0, 1), big, small.slice_graphs(1, 4)])
+    csr, vals = _csr(ctx, hb, weighted)
+    assert csr.plan is not None and (np.diff(hb.graph_ptr) >= 4096).sum() == 2
+    rng = np.random.default_rng(3)
+    y = np.maximum(rng.standard_normal((hb.n, f), dtype=np.float32), 0)           # a ReLU output: half zeros
+    dp = rng.standard_normal((hb.n_graphs, f)).astype(np.float32)
+    a64 = sp.csr_matrix((np.ones(hb.nnz) if vals is None else vals.astype(np.float64), hb.colidx, hb.rowptr), shape=(hb.n, hb.n))
+    ng = np.diff(hb.graph_ptr)
+    scale = (1.0 / ng if mode == "avg" else np.ones(hb.n_graphs))
+    drow = np.repeat(dp.astype(np.float64) * scale[:, None], ng, axis=0)
+    ref = (a64.T @ (y > 0).astype(np.float64)) * drow                             # (the operator is symmetric: A^T = A)
+    seg, dy, ddp = Segments(ctx, hb.graph_ptr), ctx.to_device(y), ctx.to_device(dp)
+    outs = {}
+    try:
+        for cb in (1, 0):
+            ctx.set_tuning("spmm_cb", cb)
+            o = ctx.zeros((hb.n, f))
+            D.spmm_pool_bwd(ctx, csr.transpose(), dy, seg, ddp, o, mode)
+            outs[cb] = o.numpy()
+        ctx.set_tuning("spmm_cb", 1)
+        o2 = ctx.zeros((hb.n, f)); D.spmm_pool_bwd(ctx, csr.transpose(), dy, seg, ddp, o2, mode)
+        assert np.array_equal(o2.numpy(), outs[1])
+    finally:
+        ctx.set_tuning("spmm_cb", 1)
+    assert rel_err(outs[1], ref) < TIGHT and rel_err(outs[0], ref) < TIGHT
+    short = np.diff(hb.rowptr) <= 32
+    assert rel_err(outs[1][short], outs[0][short]) < 1e-6        # same CSR-order sums; the dPooled scale is applied in one rounding either way
+
+
 def test_spmm_column_blocks_next_to_the_tile_kernels(ctx):
     """A batch with enough small graphs for the tile kernels AND two graphs of >= 4096 rows: tiles for the former, column
     blocks for the latter, one call -- against scipy, and the captured form replays (the work list is built by the eager run)."""
