@@ -1292,26 +1292,31 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
 // L2 hit rate 0.52, 1.88 x the compulsory HBM traffic).  Here such a graph is walked one 64-COLUMN block at a time: all its
 // rows for columns [0, 64), then [64, 128), ... -- consecutive work items, which the workgroup-id remap hands to ONE XCD -- so
 // the block's source rows (8 192 x 256 B = 2 MiB) stay in that XCD's L2 while they are gathered, and the graph's index
-// arrays (re-read once per block) stay there too (r4 PMC: 1.31 x the compulsory traffic).
+// arrays (re-read once per block) stay there too.
 // A 64-column block is 16 lanes x float4, so a wave holds four lane groups, and in a power-law batch 83 % of the rows have at
 // most three entries while a third of the ENTRIES sit in rows of hundreds.  The first version gave the four groups four
 // rows in row order: the traffic fell as planned and the launch got slower (895 us against 705), because a wave walked
-// max(length of its 8 rows) trips with most lanes idle and the long rows ran one after the other behind barriers.  So the
+// max(length of its rows) trips with most lanes idle and the long rows ran one after the other behind barriers.  So the
 // rows of such a graph are taken in DEGREE order (the plan's RowRec list, as for the tile kernels) and an item is one of:
-//   kind 2  32 rows of at most kCbLong entries: a lane group per row, two rows per group, two entries of each per trip --
-//           neighbours in the order have (nearly) the same length, so a wave's trips are all useful;
-//   kind 1  4 rows of kCbLong + 1 .. kCbHub entries: a wave per row, 16 entries per trip (4 groups x 4);
+//   kind 3  64 rows of at most kCbShort (32) entries, 16 per wave, four per lane group -- neighbours in the order have (nearly)
+//           the same length, so a wave's entry slots are all useful;
+//   kind 1  4 rows of kCbShort + 1 .. kCbHub entries: a wave per row, 64 entries per step (4 groups x 16 slots);
 //   kind 0  1 row of more than kCbHub entries: the four waves take a quarter each (fixed combination order).
-// Heaviest first inside every (graph, block).  Index loads run one trip ahead of the gathers that need them (range-checked
-// buffer loads throughout: a missing entry costs no fetch and adds an exact zero), so a trip is one dependent round trip.
-// A row of kind 2 adds its entries in CSR order -- the row gather's order at f = 256, bit for bit.
-// Where it stands (r4, config 5: profiles/r04/config5_column_blocks_*.txt): HBM traffic 2.31 GB = 1.10 x the algorithmic bytes
-// (row gather + hub segments: 3.93 GB = 1.88 x), L2 hit rate 0.72 (0.52) -- and 728-755 us against 713-726: with the traffic
-// gone the launch is bound by what a wave keeps in flight, not by HBM.  Measured on the way and dropped: kind-2 items of
-// 128 rows software-pipelined over four octets per wave (records up front, the next octet's indices under this octet's
-// gathers, result stores delayed behind the next gathers because the memory counter is in order: 776-1000 us at occupancy
-// 6-8), and short rows left in row order with only the rows of more than 8 entries sorted (937 us).  OPT-IN therefore
-// (GCNX_SPMM_CB=1 / gcnx_set_tuning "spmm_cb"): the product path for such graphs is still the row gather + hub segments.
+// The long rows' items are dealt among the short rows' (they gather out of L2, the short rows stream from HBM; GCNX_SPMM_CB=2:
+// heaviest first -- no difference measured).  Range-checked buffer loads throughout: a missing entry costs no fetch and adds an
+// exact zero.  A row of kind 3 adds its entries in CSR order -- the row gather's order at f = 256, bit for bit.
+// What the first version cost and why (profiles/r04/config5_column_blocks_ablation.txt): every entry was its own 4-byte broadcast
+// load per lane group -- sixteen vector-memory instructions per wave for eight rows -- and a CU's vector-memory pipeline takes ONE
+// instruction at a time whatever its width: with gathers and stores compiled out, those index loads were 259 of the short rows'
+// 607 us; and that pipeline's time ADDS to the HBM time instead of hiding under it.  Hence few, wide index instructions: one
+// record load per wave, one entry load per array and four slots (kind 3) or 64 entries (kinds 0 / 1), slots handed to their lane
+// group by DPP row broadcasts; result rows stored with the non-temporal policy.  Config 5 (same boxes): 636-657 us against 682-714
+// for the row gather + hub segments (frac 0.40 against 0.37), HBM traffic 1.22 x the algorithmic bytes against 1.88 x, L2 hit
+// 0.66 against 0.52.  The default for such graphs since (GCNX_SPMM_CB=0: the r3 path).  Measured on the way and dropped: items of
+// 128 rows software-pipelined over four octets per wave (776-1000 us), short rows left in row order (937 us), other hub
+// thresholds / entries per trip (no effect), fewer workgroups per CU for a higher L2 hit rate (slower at every setting).
+// FOLD (gcnx_spmm_csr_pool_bwd): h is the saved ReLU output of the pooled layer -- summed as its 0 / 1 mask -- and the graph's
+// dPooled row (x 1 / n_g for the average pool) multiplies the finished sum where the bias is added otherwise.
 // ----------------------------------------------------------------------------------------------
 constexpr int kCbCols = 64;          // columns per block
 constexpr int kCbMinRows = 4096;     // graphs of at least this many rows are walked this way (and fewer than 65 536: RowRec)
@@ -1414,18 +1419,12 @@ __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec*
   auto ld_val = [&](unsigned off) { return WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f; };
   auto h_off = [&](bool ok, int col) { return (ok && !(dbg & 4)) ? ((unsigned)col * ld32 + (unsigned)c) * 4u : kOob; };
   if (kind == 3) {
-    // 64 rows of at most kCbShort entries, 16 per wave: lane group g owns positions wave * 16 + g + 4 k (k = 0 .. 3).  A row's
-    // entries arrive with ONE load per array -- lane `sub` of the group takes entry a + sub, 64 contiguous bytes -- and reach the
-    // group's lanes by DPP row broadcasts; the gathers of the J entry slots x 4 rows are straight-line code (a slot past a row's
-    // end is an out-of-range buffer offset: no fetch, an exact zero), so a wave has one dependent round trip per stage -- records,
-    // entries, gathers, stores -- whatever the row lengths.  (The kind-2 form below loads every entry as its own 4-byte
-    // broadcast load, two per row and trip: with the gathers and stores compiled out its index loads alone took 210 of the
-    // launch's 607 us.)  A row's sum is still its CSR-order fma chain.
-    // Few, wide index instructions (the vector-memory pipeline of a CU takes one instruction at a time, and a 4- or 8-byte
-    // broadcast load occupies it like a 1-KiB gather does): lane j of a group stands for (row k = j & 3, entry slot j >> 2) --
-    // ONE record load per wave, and one load per array fetches slots [4 t, 4 t + 4) of all four rows of every group; rows of at
-    // most 4 entries (79 % of a power-law graph's rows) need t = 0 only.  Slot s of row k then lives in lane k + 4 (s & 3) of
-    // register set s >> 2.
+    // 64 rows of at most kCbShort entries, 16 per wave: lane group g owns positions wave * 16 + g + 4 k (k = 0 .. 3), and lane j
+    // of a group stands for (row k = j & 3, entry slot j >> 2) -- ONE record load per wave, and one load per array fetches slots
+    // [4 t, 4 t + 4) of all four rows of every group; rows of at most 4 entries (79 % of a power-law graph's rows) need t = 0
+    // only.  Slot s of row k then lives in lane k + 4 (s & 3) of register set s >> 2 and reaches the group's lanes by a DPP row
+    // broadcast; the gathers of the J entry slots x 4 rows are straight-line code (a slot past a row's end is an out-of-range
+    // buffer offset), so a wave has one dependent round trip per stage -- records, entries, gathers, stores.
     const int kq = sub & 3, sq = sub >> 2;
     const int posq = wave * 16 + g + 4 * kq;
     const RowRec rq = rowrec[p0 + min(posq, cnt - 1)];
