@@ -692,7 +692,7 @@ def main():
                     "achieved": alg16 / (ms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": alg16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg16,
                     "avg_launch_us": 1e3 * ms16, "launches": 20,
-                    "note": "a measured variant: the models keep fp32 activations (DESIGN section 7)"}
+                    "note": "a measured variant: the models keep fp32 activations (LOG.md section 7, item 7)"}
         # ... and the aggregation at BASELINE config 5 (power-law degrees up to 4096, 122 graphs of 8192 nodes), the skewed case
         hb5 = synth.power_law_batch(122, 8192, 256, seed=3, with_x=False, first_graph=0)
         a5 = DeviceCSR.from_host_csr(ctx, hb5.rowptr, hb5.colidx, synth.gcn_norm_host(hb5.rowptr, hb5.colidx), hb5.graph_ptr)

@@ -2,7 +2,7 @@
 //     out[t, :] = bf16( act( sum_e vals[e] * h[colidx[e], :] + bias ) ),   h and out bf16 [n, f], fp32 accumulation.
 // GCNConv.call / GeneralConv's aggregation (the ops behind gcn.py:334) on activations stored in bf16: half the feature
 // bytes of the fp32 form (B_alg = 4 (n + 1) + 4 nnz (+ 4 nnz weighted) + 2 * 2 n f; 1.108 GB at config 3).  A measured
-// variant next to the fp32 product path: the models keep fp32 activations.
+// variant next to the fp32 product path: the models keep fp32 activations (LOG.md section 7, item 7).
 //
 // One kernel, the row gather of csrc/fused.hip with 8 features per lane: a 512-thread workgroup owns 32 rows, stages their
 // CSR entries in LDS as {row byte offset, weight}, f / 8 lanes cover a feature row with one 16-byte load (8 bf16), every

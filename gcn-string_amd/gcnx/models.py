@@ -177,7 +177,7 @@ class GCN2(_GraphRunner):
         self.cce_train, self.cce_eval = cce_train, cce_eval
         self.comm = comm                     # gcnx.comm.Communicator or None
         self.use_graph = use_graph
-        # tuning knobs (diagnostics), read ONCE here -- the sequence a model runs never changes under it
+        # tuning knobs (diagnostics; DESIGN section 7: the knob list), read ONCE here -- the sequence a model runs never changes under it
         self._knob = {"fold": os.environ.get("GCNX_FOLD", "1") != "0", "duo": os.environ.get("GCNX_DUO", "1") != "0",
                       "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1")),
                       "head_late": os.environ.get("GCNX_HEAD_LATE", "1") != "0",
