@@ -1298,8 +1298,8 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
 // rows in row order: the traffic fell as planned and the launch got slower (895 us against 705), because a wave walked
 // max(length of its rows) trips with most lanes idle and the long rows ran one after the other behind barriers.  So the
 // rows of such a graph are taken in DEGREE order (the plan's RowRec list, as for the tile kernels) and an item is one of:
-//   kind 3  64 rows of at most kCbShort (32) entries, 16 per wave, four per lane group -- neighbours in the order have (nearly)
-//           the same length, so a wave's entry slots are all useful;
+//   kind 3  32 rows of at most kCbShort (32) entries, 8 per wave, two per lane group (kCbRpg) -- neighbours in the order have
+//           (nearly) the same length, so a wave's entry slots are all useful;
 //   kind 1  4 rows of kCbShort + 1 .. kCbHub entries: a wave per row, 64 entries per step (4 groups x 16 slots);
 //   kind 0  1 row of more than kCbHub entries: the four waves take a quarter each (fixed combination order).
 // The long rows' items are dealt among the short rows' (they gather out of L2, the short rows stream from HBM; GCNX_SPMM_CB=2:
@@ -1310,9 +1310,8 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
 // instruction at a time whatever its width: with gathers and stores compiled out, those index loads were 259 of the short rows'
 // 607 us; and that pipeline's time ADDS to the HBM time instead of hiding under it.  Hence few, wide index instructions: one
 // record load per wave, one entry load per array and four slots (kind 3) or 64 entries (kinds 0 / 1), slots handed to their lane
-// group by DPP row broadcasts; result rows stored with the non-temporal policy.  Config 5 (same boxes): 636-657 us against 682-714
-// for the row gather + hub segments (frac 0.40 against 0.37), HBM traffic 1.22 x the algorithmic bytes against 1.88 x, L2 hit
-// 0.66 against 0.52.  The default for such graphs since (GCNX_SPMM_CB=0: the r3 path).  Measured on the way and dropped: items of
+// group by DPP row broadcasts; result rows stored with the non-temporal policy.  Config 5 (same boxes): 605-640 us against 682-714
+// for the row gather + hub segments (frac 0.41-0.43 against 0.37), HBM traffic 1.04 x the algorithmic bytes against 1.88 x.  The default for such graphs since (GCNX_SPMM_CB=0: the r3 path).  Measured on the way and dropped: items of
 // 128 rows software-pipelined over four octets per wave (776-1000 us), short rows left in row order (937 us), other hub
 // thresholds / entries per trip (no effect), fewer workgroups per CU for a higher L2 hit rate (slower at every setting).
 // FOLD (gcnx_spmm_csr_pool_bwd): h is the saved ReLU output of the pooled layer -- summed as its 0 / 1 mask -- and the graph's
@@ -1321,6 +1320,14 @@ __global__ __launch_bounds__(64) void spmm_hub_combine_kernel(const HubRow* __re
 constexpr int kCbCols = 64;          // columns per block
 constexpr int kCbMinRows = 4096;     // graphs of at least this many rows are walked this way (and fewer than 65 536: RowRec)
 constexpr int kCbShort = 32;         // kind 3 (short rows) up to here
+#ifndef GCNX_CB_RPG
+#define GCNX_CB_RPG 2
+#endif
+// rows per lane group of a kind-3 item: 2 = 8 rows per wave, 32 per item; 4 = 16 / 64.  With 4 a wave issues fewer index instructions
+// per row, but 16 k rows are then in flight per XCD -- two (graph, block)s, 4 MiB of source rows against the 4-MiB L2: measured
+// (same box, profiles/r04/config5_column_blocks_rows_per_group.txt) 4: 620 us, 1.22 x the compulsory HBM bytes; 2: 605 us, 1.04 x
+constexpr int kCbRpg = GCNX_CB_RPG;
+constexpr int kCbSps = 16 / kCbRpg;  // entry slots one load fetches per row
 #ifndef GCNX_CB_HUB
 #define GCNX_CB_HUB 512
 #endif
@@ -1334,11 +1341,11 @@ __device__ __forceinline__ int row_bcast16(int v) { return __builtin_amdgcn_upda
 template <bool WEIGHTED, bool FOLD, int S, int K>
 __device__ __forceinline__ void cb_slot_row(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, int ci, float wv,
                                             int deg, float4& acc) {
-  const int col = row_bcast16<K + 4 * (S & 3)>(ci);
+  const int col = row_bcast16<K + kCbRpg * (S % kCbSps)>(ci);
   const unsigned off = (S < deg && !no_gather) ? ((unsigned)col * ld32 + c) * 4u : 0xFFFFFFF0u;
   float4 hv = buf4(hbuf, off);
   if (FOLD) hv = f4_step(hv);                 // (the gathered operand is the saved ReLU output: its 0 / 1 mask is what is summed)
-  if (WEIGHTED) acc = f4_fma(__int_as_float(row_bcast16<K + 4 * (S & 3)>(__float_as_int(wv))), hv, acc);
+  if (WEIGHTED) acc = f4_fma(__int_as_float(row_bcast16<K + kCbRpg * (S % kCbSps)>(__float_as_int(wv))), hv, acc);
   else acc = f4_add(acc, hv);
 }
 
@@ -1346,14 +1353,16 @@ __device__ __forceinline__ void cb_slot_row(const __amdgpu_buffer_rsrc_t hbuf, u
 // register set s >> 2.
 template <bool WEIGHTED, bool FOLD, int J, int J0, int T>
 __device__ __forceinline__ void cb_slots(const __amdgpu_buffer_rsrc_t hbuf, unsigned ld32, unsigned c, bool no_gather, const int (&ci)[T],
-                                         const float (&wv)[T], const int (&deg)[4], float4 (&acc)[4]) {
+                                         const float (&wv)[T], const int (&deg)[kCbRpg], float4 (&acc)[kCbRpg]) {
   if constexpr (J0 < J) {
-    cb_slot_row<WEIGHTED, FOLD, J0, 0>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[0], acc[0]);
-    cb_slot_row<WEIGHTED, FOLD, J0, 1>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[1], acc[1]);
-    cb_slot_row<WEIGHTED, FOLD, J0, 2>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[2], acc[2]);
-    cb_slot_row<WEIGHTED, FOLD, J0, 3>(hbuf, ld32, c, no_gather, ci[J0 >> 2], wv[J0 >> 2], deg[3], acc[3]);
+    cb_slot_row<WEIGHTED, FOLD, J0, 0>(hbuf, ld32, c, no_gather, ci[J0 / kCbSps], wv[J0 / kCbSps], deg[0], acc[0]);
+    cb_slot_row<WEIGHTED, FOLD, J0, 1>(hbuf, ld32, c, no_gather, ci[J0 / kCbSps], wv[J0 / kCbSps], deg[1], acc[1]);
+    if constexpr (kCbRpg == 4) {
+      cb_slot_row<WEIGHTED, FOLD, J0, 2>(hbuf, ld32, c, no_gather, ci[J0 / kCbSps], wv[J0 / kCbSps], deg[2], acc[2]);
+      cb_slot_row<WEIGHTED, FOLD, J0, 3>(hbuf, ld32, c, no_gather, ci[J0 / kCbSps], wv[J0 / kCbSps], deg[3], acc[3]);
+    }
     // (eight gathers in flight: more hoisted together spill; FOLD -- the mask arithmetic needs registers of its own -- four)
-    if constexpr ((FOLD || (J0 & 1) == 1) && J0 + 1 < J) __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((((J0 + 1) * kCbRpg) % ((FOLD || kCbRpg == 2) ? 4 : 8)) == 0 && J0 + 1 < J) __builtin_amdgcn_sched_barrier(0);
     cb_slots<WEIGHTED, FOLD, J, J0 + 1, T>(hbuf, ld32, c, no_gather, ci, wv, deg, acc);
   }
 }
@@ -1419,37 +1428,38 @@ __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec*
   auto ld_val = [&](unsigned off) { return WEIGHTED ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vbuf, off, 0, 0)) : 1.0f; };
   auto h_off = [&](bool ok, int col) { return (ok && !(dbg & 4)) ? ((unsigned)col * ld32 + (unsigned)c) * 4u : kOob; };
   if (kind == 3) {
-    // 64 rows of at most kCbShort entries, 16 per wave: lane group g owns positions wave * 16 + g + 4 k (k = 0 .. 3), and lane j
-    // of a group stands for (row k = j & 3, entry slot j >> 2) -- ONE record load per wave, and one load per array fetches slots
-    // [4 t, 4 t + 4) of all four rows of every group; rows of at most 4 entries (79 % of a power-law graph's rows) need t = 0
-    // only.  Slot s of row k then lives in lane k + 4 (s & 3) of register set s >> 2 and reaches the group's lanes by a DPP row
-    // broadcast; the gathers of the J entry slots x 4 rows are straight-line code (a slot past a row's end is an out-of-range
-    // buffer offset), so a wave has one dependent round trip per stage -- records, entries, gathers, stores.
-    const int kq = sub & 3, sq = sub >> 2;
-    const int posq = wave * 16 + g + 4 * kq;
+    // 16 kCbRpg rows of at most kCbShort entries, 4 kCbRpg per wave: lane group g owns positions wave * 4 kCbRpg + g + 4 k
+    // (k < kCbRpg), and lane j of a group stands for (row k = j % kCbRpg, entry slot j / kCbRpg) -- ONE record load per wave, and
+    // one load per array fetches 16 / kCbRpg entry slots of every row of every group (rows of at most 4 entries are 79 % of a
+    // power-law graph's rows).  Slot s of row k then lives in lane k + kCbRpg (s % kCbSps) of register set s / kCbSps and reaches
+    // the group's lanes by a DPP row broadcast; the gathers of the J entry slots are straight-line code (a slot past a row's end is
+    // an out-of-range buffer offset), so a wave has one dependent round trip per stage -- records, entries, gathers, stores.
+    const int kq = sub % kCbRpg, sq = sub / kCbRpg;
+    const int posq = wave * (4 * kCbRpg) + g + 4 * kq;
     const RowRec rq = rowrec[p0 + min(posq, cnt - 1)];
     const int aq = rq.a, dq = posq < cnt ? (int)(rq.w >> 16) : 0, rlq = posq < cnt ? (int)(rq.w & 0xFFFFu) : -1;
     if (dbg & 32) { if (aq == 0x7fffffff) out[0] = 1.f; return; }
-    int deg[4];
-    deg[0] = row_bcast16<0>(dq); deg[1] = row_bcast16<1>(dq); deg[2] = row_bcast16<2>(dq); deg[3] = row_bcast16<3>(dq);
+    int deg[kCbRpg];
+    deg[0] = row_bcast16<0>(dq); deg[1] = row_bcast16<1>(dq);
+    if constexpr (kCbRpg == 4) { deg[2] = row_bcast16<2>(dq); deg[3] = row_bcast16<3>(dq); }
     const int maxd = __builtin_amdgcn_readfirstlane(dq);          // degree order: the wave's first position holds its longest row
-    float4 acc[4];
+    float4 acc[kCbRpg];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // entry slots [base, base + J) of the group's four rows: J <= 8, two register sets of four slots each
+    for (int k = 0; k < kCbRpg; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // entry slots [base, base + J) of the group's rows: J <= 8
     auto slots = [&](auto jt, int base) {
       constexpr int J = decltype(jt)::value;
-      constexpr int T = (J + 3) / 4;
+      constexpr int T = (J + kCbSps - 1) / kCbSps;
       int ci[T];
       float wv[T];
-      int dg[4];
+      int dg[kCbRpg];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const unsigned off = (base + 4 * t + sq < dq && !(dbg & 64)) ? (unsigned)(aq + base + 4 * t + sq) * 4u : kOob;
+        const unsigned off = (base + kCbSps * t + sq < dq && !(dbg & 64)) ? (unsigned)(aq + base + kCbSps * t + sq) * 4u : kOob;
         ci[t] = ld_col(off); wv[t] = ld_val(off);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dg[k] = deg[k] - base;
+      for (int k = 0; k < kCbRpg; ++k) dg[k] = deg[k] - base;
       cb_slots<WEIGHTED, FOLD, J, 0, T>(hbuf, ld32, (unsigned)c, (dbg & 4) != 0, ci, wv, dg, acc);
     };
     if (maxd <= 1) slots(std::integral_constant<int, 1>{}, 0);
@@ -1464,8 +1474,10 @@ __global__ __launch_bounds__(256, GCNX_CB_OCC) void spmm_cb_kernel(const RowRec*
     }
     { const int r = row_bcast16<0>(rlq); if (r >= 0) epilogue(acc[0], row0 + r); }
     { const int r = row_bcast16<1>(rlq); if (r >= 0) epilogue(acc[1], row0 + r); }
-    { const int r = row_bcast16<2>(rlq); if (r >= 0) epilogue(acc[2], row0 + r); }
-    { const int r = row_bcast16<3>(rlq); if (r >= 0) epilogue(acc[3], row0 + r); }
+    if constexpr (kCbRpg == 4) {
+      { const int r = row_bcast16<2>(rlq); if (r >= 0) epilogue(acc[2], row0 + r); }
+      { const int r = row_bcast16<3>(rlq); if (r >= 0) epilogue(acc[3], row0 + r); }
+    }
     return;
   }
   // kinds 1 and 0: a wave walks entries [wa, wb) of one row, its four lane groups taking every fourth entry, 4 per group and trip
@@ -1956,7 +1968,7 @@ static int plan_cb_items(gcnx_ctx* ctx, const gcnx_spmm_plan* p, const RowOrder*
         heavy.clear(); light.clear();
         if (kinds & 1) for (int q = 0; q < n0; ++q) heavy.push_back(make_int4(r0 + q, 1 | (0 << 16), b * kCbCols | (kcb << 16), r0));
         if (kinds & 2) for (int q = n0; q < n1; q += 4) heavy.push_back(make_int4(r0 + q, std::min(4, n1 - q) | (1 << 16), b * kCbCols | (kcb << 16), r0));
-        if (kinds & 8) for (int q = n1; q < ng; q += 64) light.push_back(make_int4(r0 + q, std::min(64, ng - q) | (3 << 16), b * kCbCols | (kcb << 16), r0));
+        if (kinds & 8) for (int q = n1; q < ng; q += 16 * kCbRpg) light.push_back(make_int4(r0 + q, std::min(16 * kCbRpg, ng - q) | (3 << 16), b * kCbCols | (kcb << 16), r0));
         // The long rows' items gather out of L2 (the block's source rows are re-read ~degree times), the short rows' items stream
         // from HBM: dealt evenly among each other (heaviest first on either side) the two kinds of traffic run side by side.
         if (ctx->knob_spmm_cb == 2 || heavy.empty() || light.empty()) {      // (2: heaviest first, as the first version had it)
