@@ -656,6 +656,24 @@ __device__ __forceinline__ unsigned tile_addr(unsigned packed, unsigned row_byte
 // 32-bit word per (row, 32-column slab), slab-major (`bits[slab * n + row]`: a unit's words are contiguous), and the folded
 // backward expands those words into the 0 / 1 tile instead of DMA-ing the fp32 slab and masking it -- 4 bytes per row
 // and slab where the fp32 source is 128 (config 3: 1 GB of reads per step become 32 MB).
+// Sum over the 16 lanes l, l + 4, ..., l + 60 of a wave (the lanes of the 16 quads that hold the same columns), VALU only.
+__device__ __forceinline__ float wave_quads_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   // row_ror:8
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ unsigned wave_quads_sum_u(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = a[0] + a[1];
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return b[0] + b[1];
+}
+
 struct DuoFold {
   const int32_t* gids;     // graph index of every entry of `graphs`
   const float* dp;         // dPooled [b, f]
@@ -894,8 +912,10 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           }
         }
         if constexpr (MODE == kDuoBitsOut || MODE == kDuoBitsPool) {      // the quad's four lanes hold the row's 32 columns: one word per row
-          bword |= __shfl_xor(bword, 1);
-          bword |= __shfl_xor(bword, 2);
+          // (DPP quad permutes: pure VALU -- __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe instruction, and this kernel is
+          // bound by its LDS reads)
+          bword |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bword, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]: lane ^ 1
+          bword |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)bword, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]: lane ^ 2
           if (sub == 0 && pos < g.y) fo.bits[(size_t)(c0 / FT) * (size_t)n + g.x + r] = bword;
         }
       }
@@ -905,13 +925,13 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_duo_kernel(
           for (int i = 0; i < 4; ++i) { const float t_ = ps[i]; ps[i] = ps[4 + i]; ps[4 + i] = t_; }
           const unsigned t_ = pk[0]; pk[0] = pk[1]; pk[1] = t_;
         }
+        // the 16 quads' sums without the LDS pipe (r4; 40 ds_bpermute_b32 per wave and slab before): inside a 16-lane row two DPP
+        // rotations (lane l ends with l, l + 4, l + 8, l + 12), across the rows v_permlane16_swap / v_permlane32_swap (gfx950);
+        // lanes 0..3 hold the wave's sums in a fixed association
 #pragma unroll
-        for (int sh = 4; sh < 64; sh <<= 1) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) ps[i] += __shfl_xor(ps[i], sh);
-          pk[0] += (unsigned)__shfl_xor((int)pk[0], sh);
-          pk[1] += (unsigned)__shfl_xor((int)pk[1], sh);
-        }
+        for (int i = 0; i < 8; ++i) ps[i] = wave_quads_sum(ps[i]);
+        pk[0] = wave_quads_sum_u(pk[0]);
+        pk[1] = wave_quads_sum_u(pk[1]);
         if (lane < 4) {
           const size_t prow = ((size_t)(u / upg) * (THREADS / 64) + (tid >> 6)) * (size_t)(upg * sg * FT) + c0;
 #pragma unroll

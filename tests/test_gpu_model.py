@@ -1080,12 +1080,15 @@ def test_gcn2_pooled_layer_without_its_output_equals_the_two_launch_form(ctx, pr
         assert bool(m._bufs.get("pool_done")) == fused
         out.append((ev[0], ev[1], {"probs": ev[2]}, []))
         res[fused] = out
+    # (bf16 operands: a last-bit difference of a pooled sum -- the two forms add a graph's rows in different orders -- can move a
+    # bf16 rounding of a later GEMM operand; 1.2e-5 measured on the weights after three steps with the r4 reduction tree)
+    tol = 2e-5 if prec == "bf16" else 1e-5
     for (l1, a1, g1, w1), (l0, a0, g0, w0) in zip(res[True], res[False]):
-        assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)) and a1 == pytest.approx(a0)
+        assert abs(l1 - l0) < tol * max(1.0, abs(l0)) and a1 == pytest.approx(a0)
         for k in g1:
-            assert rel_err(g1[k], g0[k]) < 1e-5, k
+            assert rel_err(g1[k], g0[k]) < tol, k
         for u, v in zip(w1, w0):
-            assert rel_err(u, v) < 1e-5
+            assert rel_err(u, v) < tol
 
 
 @pytest.mark.parametrize("workload", ["block1m", "powerlaw"])
