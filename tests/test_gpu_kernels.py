@@ -1857,7 +1857,7 @@ def test_spmm_double_buffered_tiles_with_rows_past_the_register_held_entries(ctx
 
 
 @pytest.mark.parametrize("weighted", [False, True])
-@pytest.mark.parametrize("f", [128, 256])
+@pytest.mark.parametrize("f", [128, 192, 256, 512])
 def test_spmm_column_blocks_for_graphs_larger_than_an_xcd_l2(ctx, f, weighted):
     """BASELINE config 5 in small (r4): power-law graphs of 8 192 nodes (degrees up to 4096) are walked by spmm_cb_kernel one
     64-column block at a time -- rows of at most 32 entries sixteen to a wave (four per lane group), longer rows a wave each,
