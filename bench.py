@@ -357,7 +357,10 @@ def generalgnn_extra(ctx, steps=60, cpu_seconds=6.0):
                        f"N={hb.n}, nnz={hb.nnz}"}
     keep = []
     for prec in ("f32", "bf16x3"):
-        model = GeneralGNN(ctx, 2, activation="softmax", prec=prec)     # (captured step, also under a profiler: see PROFILED)
+        # (captured step; under a profiler this EXTRA runs eagerly: as the third and fourth model of the process its graph replays
+        # still die inside the tracer -- profiles/r04/graph_trace_repro_summary.txt, LOG "Round 4" -- although every step is
+        # synchronised; a stand-alone traced `--model generalgnn` run captures and replays without trouble)
+        model = GeneralGNN(ctx, 2, activation="softmax", prec=prec, use_graph=not PROFILED)
         for _ in range(5):
             model.train_step(batch, None, lr=0.0002, fetch=False)
         ctx.sync()
