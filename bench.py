@@ -486,7 +486,9 @@ def main():
     ap.add_argument("--model", default="gcn2", choices=["gcn2", "generalgnn"],
                     help="gcn2 = the BN-free 2-layer GCNConv model of BASELINE.md (default, the metric's model); "
                          "generalgnn = the reference's live model gcn.py:320 (F_in=16, hidden=256; single GPU)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches everywhere")
+    ap.add_argument("--graph", action="store_true", help="one captured HIP graph per step everywhere (default: the model's own choice -- "
+                                                          "eager for the five-launch step of config 2 in one process, captured otherwise)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--scipy-seconds", type=float, default=4.0, help="budget of the NumPy/SciPy baseline C2 (0 = skip)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra config-3 SpMM roofline reading")
@@ -552,7 +554,7 @@ def main():
 
     a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, hb.vals, hb.graph_ptr)
     batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
-    model = GCN2(ctx, 2, hidden=hidden, prec=args.prec, seed=0, comm=comm, use_graph=not args.no_graph)
+    model = GCN2(ctx, 2, hidden=hidden, prec=args.prec, seed=0, comm=comm, use_graph=False if args.no_graph else (True if args.graph else "auto"))
     model.build(hb.f)
     params0 = np.concatenate([w.ravel() for w in model.get_weights()])
     lr = 0.0002   # the reference's steady-state rate (gcn.py:323: values[-1]); constant so one graph serves
@@ -734,7 +736,7 @@ def main():
                        "global_graphs": global_graphs, "nodes_per_gpu": hb.n, "nnz_per_gpu": hb.nnz, "features": hb.f,
                        "hidden": hidden, "parallelism": f"dp{world} (graphs sharded, RCCL all-reduce of {model.n_params + 2} fp32"
                                                         f"{' inside the step graph' if world > 1 and model._comm_in_graph() else ''})",
-                       "hip_graph": not args.no_graph, "gemm_precision": args.prec, "cce": model.cce_train,
+                       "hip_graph": bool(model.use_graph), "gemm_precision": args.prec, "cce": model.cce_train,
                        "activation_storage": ("bf16 for the tensors only bf16-operand weight GEMMs read (S1, Y1, dH2, dZ1: results "
                                               "bit-identical to fp32 storage), fp32 elsewhere" if (model._bufs or {}).get("act16") else "fp32")},
             "burn_in": {"steps": burn_steps, "ms": args.burn_in_ms,

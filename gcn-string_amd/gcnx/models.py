@@ -165,7 +165,7 @@ class GCN2(_GraphRunner):
     PARAM_ORDER = ("w1", "b1", "w2", "b2", "w3", "b3")
 
     @D.with_default_context
-    def __init__(self, ctx, n_labels=2, hidden=None, pool="sum", prec="f32", seed=0, comm=None, use_graph=True,
+    def __init__(self, ctx, n_labels=2, hidden=None, pool="sum", prec="f32", seed=0, comm=None, use_graph="auto",
                  cce_train="logits", cce_eval="probs"):
         """cce_train / cce_eval: which branch of keras.backend.categorical_crossentropy the loss follows (see
         gcnx_cce_mode in include/gcnx.h).  train_step runs under tf.function (gcn.py:328-335), where Keras swaps the
@@ -176,7 +176,14 @@ class GCN2(_GraphRunner):
         self.ctx, self.n_labels, self.hidden, self.pool, self.prec = ctx, int(n_labels), hidden, pool, prec
         self.cce_train, self.cce_eval = cce_train, cce_eval
         self.comm = comm                     # gcnx.comm.Communicator or None
-        self.use_graph = use_graph
+        # use_graph: True -- every step replays ONE captured HIP graph (the tf.function of gcn.py:328); False -- eager launches;
+        # "auto" (default, r4): eager where the step is the five launches of the one-launch layers (E. coli-sized batches, F <= 128,
+        # binary labels, one process), captured everywhere else.  Back-to-back replays of a graph leave ~10 us between the last
+        # kernel of one and the first of the next on this runtime; five eager launches per step keep the queue full from Python
+        # and have no such boundary: config 2 0.1020 -> 0.0948 ms per step on the same box (the 12-to-88-launch steps of large
+        # batches and of GeneralGNN are host-bound when issued eagerly: there the graph wins).
+        self._graph_opt = use_graph
+        self.use_graph = use_graph is not False
         # tuning knobs (diagnostics; DESIGN section 7: the knob list), read ONCE here -- the sequence a model runs never changes under it
         self._knob = {"fold": os.environ.get("GCNX_FOLD", "1") != "0", "duo": os.environ.get("GCNX_DUO", "1") != "0",
                       "fused": os.environ.get("GCNX_FUSED", "1") != "0", "side": int(os.environ.get("GCNX_SIDE", "1")),
@@ -598,6 +605,8 @@ class GCN2(_GraphRunner):
         bufs = self._ensure(batch)
         denom = float(global_batch or batch.n_graphs)
         multi = self._world() > 1
+        if self._graph_opt == "auto":
+            self.use_graph = bool(multi or not (self._fused(batch) and self._head_late(batch)))
         fused_comm = multi and _lr is not None and self._comm_in_graph()
 
         # (the bucketed form needs the side stream inside the step: with a capturable communicator only when the collective

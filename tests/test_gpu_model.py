@@ -758,6 +758,35 @@ def test_general_gnn_matches_oracle(ctx, f_in, hidden, mp, n_graphs, strict, pre
                 assert np.allclose(wa, wb - np.float32(0.01) * got[m.layers.index(L)]["kernel"], rtol=0, atol=1e-6)
 
 
+def test_gcn2_graph_policy_auto_is_eager_for_the_five_launch_step_and_equal_to_the_captured_one(ctx):
+    """GCN2(use_graph="auto"), the default (r4): the five-launch step of E. coli-sized batches runs eagerly in one process (no ~10 us
+    graph boundary per step), every other path replays a captured graph; eager and captured steps land on the same bits."""
+    from gcnx import synth
+    from gcnx.device import DeviceCSR, Segments
+    from gcnx.models import DeviceBatch, GCN2
+    hb = synth.ecoli_batch(6, 64, seed=2)
+    vals = synth.gcn_norm_host(hb.rowptr, hb.colidx)
+    a = DeviceCSR.from_host_csr(ctx, hb.rowptr, hb.colidx, vals, hb.graph_ptr)
+    batch = DeviceBatch(ctx, ctx.to_device(hb.x), a, Segments(ctx, hb.graph_ptr), ctx.to_device(hb.y))
+    res = {}
+    for opt in ("auto", True, False):
+        m = GCN2(ctx, 2, hidden=64, seed=5, use_graph=opt)
+        out = [m.train_step(batch, None, lr=0.02) for _ in range(4)]
+        captured = sum(1 for g in m._graphs.values() if not isinstance(g, str))
+        res[opt] = (out, [w.copy() for w in m.get_weights()], captured, m.use_graph)
+    assert res["auto"][3] is False and res["auto"][2] == 0 and res[True][2] >= 1 and res[False][2] == 0
+    for opt in (True, False):
+        assert res[opt][0] == res["auto"][0]
+        assert all(np.array_equal(u, v) for u, v in zip(res[opt][1], res["auto"][1]))
+    m = GCN2(ctx, 2, hidden=144, seed=5)                    # (144 columns: not the one-launch layers -> captured)
+    hb2 = synth.ecoli_batch(3, 144, seed=2)
+    a2 = DeviceCSR.from_host_csr(ctx, hb2.rowptr, hb2.colidx, synth.gcn_norm_host(hb2.rowptr, hb2.colidx), hb2.graph_ptr)
+    b2 = DeviceBatch(ctx, ctx.to_device(hb2.x), a2, Segments(ctx, hb2.graph_ptr), ctx.to_device(hb2.y))
+    for _ in range(3):
+        m.train_step(b2, None, lr=0.02)
+    assert m.use_graph is True and sum(1 for g in m._graphs.values() if not isinstance(g, str)) >= 1
+
+
 def test_general_gnn_with_spektrals_own_signature(ctx):
     """gcn.py:320 verbatim: `GeneralGNN(dataset.n_labels, activation="softmax")` -- no ctx: the process-wide default context --
     builds the same model as the explicit-ctx form and returns the same probabilities for the loader's host tuple."""
@@ -1367,7 +1396,7 @@ def test_learning_rate_from_a_device_scalar_serves_a_schedule_with_one_captured_
         if model_kind == "general_gnn":
             m = GeneralGNN(ctx, 2, activation="softmax", hidden=32, message_passing=2, seed=3)
         else:
-            m = GCN2(ctx, 2, hidden=128 if model_kind == "gcn2_fused" else 144, seed=3)
+            m = GCN2(ctx, 2, hidden=128 if model_kind == "gcn2_fused" else 144, seed=3, use_graph=True)   # (the default, "auto", runs the five-launch step eagerly)
         m.lr_on_device = on_device
         out = [m.train_step(batch, None, lr=r) for r in rates]
         n_graphs = sum(1 for k, g in m._graphs.items() if k[0] == "grad" and not isinstance(g, str))
